@@ -1,0 +1,55 @@
+// crt_main -- still-image driver.  Replaces the reference's app/main.cpp (which hard-codes
+// /home/daniel paths, app/main.cpp:12,16) with the same flow taking its paths from the command line:
+//   parse scene -> RayTracer(scene) -> render(path, options) -> PPM.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "../host/RayTracer.h"
+#include "../host/SceneParser.h"
+
+int main(int argc, char **argv) {
+  if (argc < 3) {
+    std::fprintf(stderr,
+                 "usage: %s scene.crtscene out.ppm [--folder DIR] [--depth N] [--mode 0..9] [--device D] [--repeat K]\n",
+                 argv[0]);
+    return 2;
+  }
+  std::string scenePath = argv[1], outPath = argv[2], folder;
+  unsigned depth = 5;
+  int mode = crt::BVHBucketsThreadPool, device = 0, repeat = 1;
+  for (int i = 3; i < argc; i++) {
+    if (!strcmp(argv[i], "--folder") && i + 1 < argc) folder = argv[++i];
+    else if (!strcmp(argv[i], "--depth") && i + 1 < argc) depth = (unsigned)atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--mode") && i + 1 < argc) mode = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--repeat") && i + 1 < argc) repeat = atoi(argv[++i]);
+  }
+  try {
+    crt::SceneParser parser;
+    crt::Scene scene = parser.parseScene(scenePath, folder);
+    auto t0 = std::chrono::high_resolution_clock::now();
+    crt::RayTracer tracer(scene, device);
+    auto t1 = std::chrono::high_resolution_clock::now();
+    crt::RenderOptions options((crt::RenderOptimization)mode, depth, false);
+    double best = 1e30;
+    for (int r = 0; r < repeat; r++) {
+      auto a = std::chrono::high_resolution_clock::now();
+      tracer.render(r + 1 == repeat ? outPath : std::string(), options);
+      auto b = std::chrono::high_resolution_clock::now();
+      best = std::min(best, std::chrono::duration<double>(b - a).count());
+    }
+    crt_stats st = tracer.stats();
+    // the reference prints the elapsed seconds of the render window (MEASURE_TIME, RayTracer.cpp:289-293)
+    std::printf("%.6fs\n", best);
+    std::printf("{\"build_s\": %.6f, \"render_s\": %.6f, \"kernel_ms\": %.4f, \"width\": %u, \"height\": %u}\n",
+                std::chrono::duration<double>(t1 - t0).count(), best, st.kernel_ms, scene.sceneSettings.image.width,
+                scene.sceneSettings.image.height);
+  } catch (const std::exception &e) {
+    std::fprintf(stderr, "error: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -1,0 +1,96 @@
+// crt::RayTracer -- the seam.  Same public surface as the reference's class
+// (reference: SourceCode/include/tracer/RayTracer.h:12-50,96-101):
+//     explicit RayTracer(Scene&);  getCamera();  setCamera();
+//     std::vector<std::vector<Color>> render(const std::string& pathToImage, RenderOptions = RenderOptions());
+//     void exportPPM(const std::string&, const std::vector<std::vector<Color>>&);
+// The per-pixel work (renderRectangle -> getRay -> shootRay -> ...) runs on the MI355X through the C
+// ABI of include/crt_hip.h; scheduling (the std::thread pools of RayTracer.cpp:114-202) is replaced by
+// the GPU's own pixel queue, but WHICH pixels a render covers is still decided by the reference's bucket
+// arithmetic (RayTracer.cpp:141-152), because that is observable in the output.
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "../../include/crt_hip.h"
+#include "AccelerationStructure.h"
+#include "Scene.h"
+
+namespace crt {
+
+enum RenderOptimization {  // RayTracer.h:12-23
+  NoOptimization,
+  Regions,
+  BucketsThreadPool,
+  BucketsQueue,
+  AABB,
+  BucketsThreadPoolAABB,
+  BucketsQueueAABB,
+  BVH,
+  BVHBucketsThreadPool,
+  BVHBucketsQueue
+};
+
+struct RenderOptions {  // RayTracer.h:25-50, same fields, defaults and constructor order
+  RenderOptimization optimization = BVHBucketsThreadPool;
+  bool USE_GI = false;
+  unsigned int MAX_DEPTH = 5;
+  unsigned int GI_SAMPLE_SIZE = 2;
+  unsigned int RAYS_PER_PIXEL = 1;
+  float SHADOW_BIAS = 1e-4;
+  float REFLECTION_BIAS = 1e-4;
+  float REFRACTION_BIAS = 1e-4;
+  float MONTE_CARLO_BIAS = 1e-4;
+
+  explicit RenderOptions(const RenderOptimization optimization = BVHBucketsThreadPool, const unsigned int maxDepth = 5,
+                         const bool useGI = false, const unsigned int sampleSize = 2, const unsigned int raysPerPixel = 1,
+                         const float shadowBias = 1e-4, const float reflectionBias = 1e-4,
+                         const float refractionBias = 1e-4, const float monteCarloBias = 1e-4)
+      : optimization{optimization}, USE_GI{useGI}, MAX_DEPTH{maxDepth}, GI_SAMPLE_SIZE{sampleSize},
+        RAYS_PER_PIXEL{raysPerPixel}, SHADOW_BIAS{shadowBias}, REFLECTION_BIAS{reflectionBias},
+        REFRACTION_BIAS{refractionBias}, MONTE_CARLO_BIAS{monteCarloBias} {}
+};
+
+// The rectangles RayTracer::render hands to renderRectangle for a given optimisation mode
+// (RayTracer.cpp:209-286 + renderRegions :114-139 / renderBucketsThreadpool :141-158 / renderBucketsQueue
+// :160-202; the queue variant shuffles the same set).  `hardwareConcurrency` stands for
+// std::thread::hardware_concurrency() (used by the Regions mode only).
+std::vector<crt_rect> bucketRectangles(unsigned int width, unsigned int height, unsigned int bucketSize,
+                                       RenderOptimization optimization, unsigned int hardwareConcurrency);
+
+// P3 writer, byte-identical to RayTracer::exportPPM + PPMColor (RayTracer.cpp:540-552, Color.cpp:12-21).
+void writePPM(const std::string &path, const float *rgb, unsigned int width, unsigned int height);
+void writePPMQuantized(const std::string &path, const uint8_t *rgb8, unsigned int width, unsigned int height);
+
+class RayTracer {
+ public:
+  // Builds the two-level tree once (as RayTracer::RayTracer does, RayTracer.cpp:45-51), flattens it and
+  // uploads scene + tree to the GPU.  Throws std::runtime_error when no usable GPU exists: there is no
+  // CPU fallback.
+  explicit RayTracer(Scene &scene, int device = 0);
+  ~RayTracer();
+  RayTracer(const RayTracer &) = delete;
+  RayTracer &operator=(const RayTracer &) = delete;
+
+  const Camera &getCamera() const { return camera; }
+  Camera &setCamera() { return camera; }
+  std::vector<std::vector<Color>> render(const std::string &pathToImage, RenderOptions renderOptions = RenderOptions());
+  void exportPPM(const std::string &pathToImage, const std::vector<std::vector<Color>> &colorBuffer);
+
+  // flat access for callers that do not want the vector-of-vectors copy
+  int renderFlat(const std::string &pathToImage, const RenderOptions &renderOptions, float *outRGB, bool counters = false);
+  crt_ctx *context() const { return ctx; }
+  const FlatScene &flatScene() const { return flat; }
+  const AccelerationStructure &acceleration() const { return accelerationStructure; }
+  crt_stats stats() const;
+
+ private:
+  const AccelerationStructure accelerationStructure;
+  const Scene &scene;
+  Camera camera;
+  FlatScene flat;
+  crt_ctx *ctx = nullptr;
+  std::vector<float> frame;  // persistent colorBuffer (RayTracer.h:69)
+};
+
+}  // namespace crt

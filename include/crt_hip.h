@@ -1,0 +1,206 @@
+/* crt_hip.h -- C ABI of the MI355X-native per-pixel hot path (libcrt_hip.so).
+ *
+ * This is the drop-in boundary.  The reference has no FFI; its seam is the C++ class
+ * `RayTracer` (reference: SourceCode/include/tracer/RayTracer.h:96-101).  Each entry point below
+ * names the reference interface it replaces.  Plain pointers and sizes only: no C++ types, no
+ * torch types, no exceptions across the boundary (the reference uses assert / throw,
+ * SceneParser.cpp:41,203, Vector.cpp:21-23; here every call returns an int status).
+ *
+ * Ownership: the caller owns every array passed in and every output buffer; the context owns its
+ * device copies; no caller pointer is retained after a call returns.
+ * Threading: one context = one caller thread at a time (the reference's render() is not
+ * re-entrant either, RayTracer.cpp:205-213).
+ * There is NO CPU fallback: without a usable HIP device crt_create fails with CRT_ERR_NO_DEVICE.
+ */
+#ifndef CRT_HIP_H
+#define CRT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    CRT_OK = 0,
+    CRT_ERR_INVALID = 1,   /* bad argument / inconsistent description */
+    CRT_ERR_NO_DEVICE = 2, /* no HIP device, or the device is not usable */
+    CRT_ERR_HIP = 3,       /* a HIP runtime call failed (see crt_last_error) */
+    CRT_ERR_NOMEM = 4,
+    CRT_ERR_IO = 5,
+    CRT_ERR_PARSE = 6
+};
+
+/* Material types -- same numbering as the reference's enum MaterialType (Material.h:7). */
+enum { CRT_MAT_DIFFUSE = 0, CRT_MAT_REFLECTIVE = 1, CRT_MAT_CONSTANT = 2, CRT_MAT_REFRACTIVE = 3 };
+/* Texture kinds (Texture.h:24-58). */
+enum { CRT_TEX_ALBEDO = 0, CRT_TEX_EDGES = 1, CRT_TEX_CHECKER = 2, CRT_TEX_BITMAP = 3 };
+
+#define CRT_LINK_END 0xFFFFFFFFu  /* "no next node" */
+#define CRT_LINK_LEAF 0x80000000u /* bit 31 of crt_node.link: the node is a leaf */
+#define CRT_ENTRY_LAST 0x80000000u /* bit 31 of a leaf entry: last entry of its leaf */
+
+/* One node of the flattened ("threaded") two-level tree, 32 bytes.
+ * The reference walks its KD/AABB trees with an explicit stack, pushing children[0] then
+ * children[1] so that children[1] is visited first, and never prunes by distance
+ * (KDTree.cpp:53-74,132-155).  The visit order is therefore a fixed property of the tree, and it
+ * is encoded here as two links per node instead of a stack:
+ *   box test passes, inner node : continue at `link`            (first child in visit order)
+ *   box test passes, leaf       : process entries starting at (link & ~CRT_LINK_LEAF), then `miss`
+ *   box test fails              : continue at `miss`            (skip the whole subtree)
+ * CRT_LINK_END terminates the walk.  Node indices are global (top-level tree and all mesh trees
+ * share one array). */
+typedef struct crt_node {
+    float lo[3];
+    uint32_t miss;
+    float hi[3];
+    uint32_t link;
+} crt_node;
+
+/* Triangle record used by the intersection test, 64 bytes (Ray.cpp:9-31, Triangle.cpp:37-57):
+ * positions, the unit face normal (Triangle.cpp:13-16) and plane = -(v0 . normal) (Ray.cpp:17). */
+typedef struct crt_triangle {
+    float v0[3]; float nx;
+    float v1[3]; float ny;
+    float v2[3]; float nz;
+    float plane; uint32_t pad[3];
+} crt_triangle;
+
+typedef struct crt_mesh {
+    uint32_t root;      /* global node index of this mesh's tree root */
+    uint32_t material;  /* index into materials */
+    uint32_t flags;     /* bit 0: material is refractive (shadow rays skip it, AccelerationStructure.cpp:67-71) */
+    uint32_t pad;
+} crt_mesh;
+
+typedef struct crt_material {
+    float albedo[3];
+    float ior;
+    uint32_t type;    /* CRT_MAT_* */
+    uint32_t smooth;  /* smooth_shading */
+    int32_t texture;  /* index into textures, -1 = constant albedo */
+    uint32_t pad;
+} crt_material;
+
+typedef struct crt_texture {
+    uint32_t kind;      /* CRT_TEX_* */
+    float color_a[3];   /* albedo | inner_color | color_A */
+    float color_b[3];   /*        | edge_color  | color_B */
+    float scalar;       /*        | edge_width  | square_size */
+    uint32_t width, height; /* bitmap only */
+    uint64_t texel_offset;  /* bitmap only: first texel in crt_scene_desc.texels */
+} crt_texture;
+
+typedef struct crt_light {
+    float position[3];
+    uint32_t intensity; /* unsigned, as in the reference (Scene.h:22) */
+} crt_light;
+
+/* Everything the hot path reads (the reference's `Scene` + its AccelerationStructure, flattened). */
+typedef struct crt_scene_desc {
+    uint32_t width, height;
+    float background[3];
+
+    const crt_node *nodes;          uint32_t n_nodes;
+    uint32_t top_root;              /* node index of the top-level (object) tree root */
+    const uint32_t *leaf_triangles; uint64_t n_leaf_triangles; /* mesh-tree leaf entries: global triangle index | CRT_ENTRY_LAST */
+    const uint32_t *leaf_meshes;    uint32_t n_leaf_meshes;    /* top-tree leaf entries: mesh index | CRT_ENTRY_LAST */
+
+    const crt_triangle *triangles;  uint32_t n_triangles;
+    const uint32_t *triangle_vertices; /* 3 global vertex indices per triangle */
+    const float *vertex_normals;    /* 3 floats per vertex (Scene.cpp:21-29) */
+    const float *vertex_uvs;        /* 3 floats per vertex, may be NULL when no material has a texture */
+    uint32_t n_vertices;
+
+    const crt_mesh *meshes;         uint32_t n_meshes;
+    const crt_material *materials;  uint32_t n_materials;
+    const crt_texture *textures;    uint32_t n_textures;
+    const uint8_t *texels;          uint64_t n_texels;  /* RGB8, 3 bytes per texel, all bitmaps concatenated */
+    const crt_light *lights;        uint32_t n_lights;
+} crt_scene_desc;
+
+/* RenderOptions (RayTracer.h:25-50).  USE_GI / GI_SAMPLE_SIZE / RAYS_PER_PIXEL are not part of
+ * this path (the reference seeds its GI RNG from clock() ^ thread id, RayTracer.cpp:28-30, so no
+ * parity is definable); use_gi != 0 is rejected with CRT_ERR_INVALID. */
+typedef struct crt_options {
+    uint32_t max_depth;      /* MAX_DEPTH, default 5 */
+    float shadow_bias;       /* SHADOW_BIAS, default 1e-4 */
+    float reflection_bias;   /* REFLECTION_BIAS */
+    float refraction_bias;   /* REFRACTION_BIAS */
+    uint32_t use_gi;         /* must be 0 */
+    uint32_t collect_counters; /* != 0: run the counting build of the kernel (slower) */
+} crt_options;
+
+/* A pixel rectangle = the reference's unit of work, RayTracer::renderRectangle(row, col, w, h)
+ * (RayTracer.cpp:82-112); clamped to the image like the reference does (:84-85). */
+typedef struct crt_rect {
+    uint32_t row, col, width, height;
+} crt_rect;
+
+/* Work counters of the last counted render: properties of (scene, camera, options) under the
+ * reference's traversal semantics; they price the algorithmic bytes of SURVEY.md §8d. */
+typedef struct crt_stats {
+    double kernel_ms;          /* device time of the last render kernel (HIP events on the render stream) */
+    double total_ms;           /* kernel + device->host copy of the last crt_render */
+    uint64_t box_tests;        /* BoundingBox::hasIntersection calls */
+    uint64_t tri_tests;        /* Ray::intersectWithTriangle calls */
+    uint64_t leaf_index_reads; /* leaf index entries read (both tree levels) */
+    uint64_t shaded_hits;      /* closest hits shaded */
+    uint64_t light_evals;      /* light-loop iterations */
+    uint64_t texel_fetches;    /* bitmap texel reads */
+    uint64_t primary_rays, secondary_rays, shadow_rays;
+    uint64_t pixels;           /* pixels rendered by the last call */
+    uint32_t counters_valid;   /* 1 when the last render ran with collect_counters */
+} crt_stats;
+
+typedef struct crt_ctx crt_ctx;
+
+/* replaces RayTracer::RayTracer(Scene&) (RayTracer.cpp:45-51): copies the flattened scene + tree to
+ * HBM on `device` and allocates the persistent H*W colour buffer (zero-initialised like
+ * colorBuffer, RayTracer.h:69). */
+int crt_create(const crt_scene_desc *scene, int device, crt_ctx **out);
+
+/* replaces RayTracer::setCamera() (RayTracer.cpp:57-59): position + row-major 3x3 matrix
+ * (Camera.h:7-8).  The tree is not rebuilt. */
+int crt_set_camera(crt_ctx *ctx, const float position[3], const float matrix[9]);
+
+/* replaces RayTracer::render's bucket scheduling + renderRectangle (RayTracer.cpp:141-158,82-112):
+ * renders the pixels covered by `rects` into the context's persistent colour buffer (pixels not
+ * covered keep their previous value) and copies the whole H*W*3 float buffer (row 0 = top) to
+ * `out_rgb` (host memory, may be NULL to skip the copy). */
+int crt_render(crt_ctx *ctx, const crt_options *options, const crt_rect *rects, uint32_t n_rects, float *out_rgb);
+
+/* Device-resident variants used by the multi-GPU tile partition.
+ * The frame is cut into 8x8 pixel tiles, numbered row-major; this call renders tiles
+ * first, first+stride, first+2*stride, ... and writes them PACKED, tile after tile, 64 pixels x 3
+ * floats each (pixel k of a tile = row k/8, column k%8), to `d_packed` (device memory of at least
+ * crt_packed_tile_count(...)*192 floats).  Asynchronous on `stream` (a hipStream_t, NULL = default). */
+int crt_render_tiles_device(crt_ctx *ctx, const crt_options *options, uint32_t first, uint32_t stride,
+                            float *d_packed, void *stream);
+/* number of tiles the call above renders */
+uint32_t crt_packed_tile_count(const crt_ctx *ctx, uint32_t first, uint32_t stride);
+/* Scatter `n_parts` packed buffers (part p holds tiles p, p+n_parts, ...; laid out one after another in
+ * d_packed_all with `part_stride_floats` between parts) into the row-major H*W*3 device frame d_frame. */
+int crt_unpack_tiles_device(crt_ctx *ctx, const float *d_packed_all, uint32_t n_parts, uint64_t part_stride_floats,
+                            float *d_frame, void *stream);
+
+/* PPMColor quantiser (Color.cpp:12-16) on the device: out[i] = (uint8)(clamp(rgb[i],0,1)*255), truncating. */
+int crt_quantize_device(crt_ctx *ctx, const float *d_rgb, uint64_t n_values, uint8_t *d_out, void *stream);
+/* Quantised copy of the context's persistent colour buffer to host memory (H*W*3 bytes). */
+int crt_read_quantized(crt_ctx *ctx, uint8_t *out_rgb8);
+
+/* Device time of the most recent render kernel, from the HIP events recorded around it on the stream
+ * it was launched on (waits for that kernel to finish). */
+int crt_kernel_elapsed_ms(crt_ctx *ctx, double *ms);
+int crt_get_stats(crt_ctx *ctx, crt_stats *out);
+int crt_synchronize(crt_ctx *ctx);
+void crt_destroy(crt_ctx *ctx);
+/* last error text of a context (or of the last failed crt_create when ctx == NULL) */
+const char *crt_last_error(const crt_ctx *ctx);
+int crt_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
