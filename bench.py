@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Mpixels/s on the HW14 'Optimizations 02'-like scene, 1920x1080, depth 8.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full frame of the per-pixel hot path.  The scene and its flattened tree are resident in
+HBM before the timed region.  With N > 1 the frame's 8x8 tiles are dealt round-robin over the ranks (one
+process per GPU, scene replicated), each rank renders its tiles into a packed device buffer and one RCCL
+all_gather collects them; rank 0 scatters them into the row-major frame.  The timed region
+is bracketed by barrier + torch.cuda.synchronize() on both sides, the MAX over ranks is taken, and rank 0
+prints ONE JSON line.  `value` is the whole job's Mpixels/s with the finished frame left in HBM on rank 0;
+the device->host-inclusive rate is reported beside it as `value_incl_d2h` (never as `value`).
+
+PyTorch is plumbing here (device buffers, streams, torch.distributed); the renderer is libcrt_hip.so.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+WORKLOAD = "hw14"
+
+
+def algorithmic_bytes(c, width, height, textured=False):
+    """B_alg = 32 N_box + 48 N_tri + 4 N_leafidx + 72 N_hit (+36 textured) + 16 N_light + 12 N_texel
+    + 12 W H  (bytes per frame)."""
+    return (32 * c["box_tests"] + 48 * c["tri_tests"] + 4 * c["leaf_index_reads"]
+            + (72 + (36 if textured else 0)) * c["shaded_hits"] + 16 * c["light_evals"] + 12 * c["texel_fetches"]
+            + 12 * width * height)
+
+
+def cpu_baseline(sc, scene_name, depth, budget_s=20.0):
+    """Times the REAL reference (oracle/_ref, built from /root/reference in the dev container and shipped as
+    a binary) -- or, if that binary is absent, the oracle's C restatement -- on a bounded sample of the same
+    workload: the same scene at a reduced resolution, all host cores."""
+    from oracle import oracle_api as oa
+    w, h = 320, 180
+    scene = sc.make(scene_name, width=w, height=h)
+    blob = sc.to_blob(scene)
+    cores = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+        cores = min(cores, affinity)
+    except Exception:
+        pass
+    if oa.reference_available(textured=bool(scene.get("textures"))):
+        _, info = oa.reference_render(blob, max_depth=depth)
+        rep = 1
+        if info["render_s"] * 3 < budget_s:
+            rep = max(1, min(8, int(budget_s / max(info["render_s"], 1e-3)) - 1))
+            _, info = oa.reference_render(blob, max_depth=depth, repeat=rep)
+        secs = info["render_s"]
+        return {"value": round(w * h / secs / 1e6, 5), "unit": "Mpixels/s", "cores": int(info["threads"]),
+                "kind": "reference",
+                "sample": "same HW14-like scene (%d triangles), %dx%d, depth %d, RayTracer::render in "
+                          "BVHBucketsThreadPool mode, best of %d" % (sc.triangle_count(scene), w, h, depth, rep)}
+    o = oa.OracleScene(blob)
+    t0 = time.time()
+    o.render(depth, threads=cores)
+    secs = time.time() - t0
+    return {"value": round(w * h / secs / 1e6, 5), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": "same HW14-like scene, %dx%d, depth %d, oracle/cpu_ref.c with OpenMP over the 48 buckets"
+                      % (w, h, depth)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scene", default=WORKLOAD)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--depth", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                             % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    pkg = importlib.import_module("course-assignment-danielhalachev_amd")
+    sc = pkg.scenes
+    gen, w0, h0, d0 = sc.CONFIGS[args.scene]
+    W, H, depth = args.width or w0, args.height or h0, args.depth or d0
+    scene = sc.make(args.scene, width=W, height=H)
+    folder = ""
+    if scene.get("textures"):
+        import tempfile
+        folder = tempfile.mkdtemp(prefix="crt_bench_")
+        sc.write_bitmaps(scene, folder)
+    hs = pkg.Scene(json_text=sc.to_json(scene), folder=folder)
+    tracer = pkg.Tracer(hs, device=local_rank)
+
+    n_tiles = tracer.packed_tile_count(0, 1)
+    per_rank = (n_tiles + world - 1) // world            # tiles per rank, padded to the same count
+    part_floats = per_rank * 64 * 3
+    packed = torch.zeros(part_floats, dtype=torch.float32, device=dev)
+    gathered = torch.zeros(part_floats * world, dtype=torch.float32, device=dev) if world > 1 else packed
+    frame = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    sptr = stream.cuda_stream
+    opts = pkg.make_options(depth)
+
+    def step():
+        tracer.render_tiles_device(opts, rank, world, packed.data_ptr(), sptr)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, packed)
+        if rank == 0:
+            tracer.unpack_tiles_device(gathered.data_ptr(), world, part_floats, frame.data_ptr(), sptr)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # one counted launch (outside the timed region) prices the algorithmic bytes of this rank's launch
+    copts = pkg.make_options(depth, counters=True)
+    tracer.render_tiles_device(copts, rank, world, packed.data_ptr(), sptr)
+    torch.cuda.synchronize(dev)
+    counters = tracer.stats().counters()
+    pk_counters, ln_counters = tracer.kernel_counters()
+    my_pixels = int(tracer.stats().pixels)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = tracer.kernel_times_ms(min(args.steps, 64))
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # device->host inclusive rate (reported beside `value`, never as it)
+    d2h_elapsed = None
+    if rank == 0:
+        host = torch.empty(H * W * 3, dtype=torch.float32).pin_memory()
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(min(args.steps, 5)):
+        step()
+        if rank == 0:
+            host.copy_(frame, non_blocking=True)
+    fence()
+    d2h_elapsed = (time.perf_counter() - t1) / min(args.steps, 5)
+    if world > 1:
+        t = torch.tensor([d2h_elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        d2h_elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = W * H * args.steps / elapsed / 1e6
+        textured = bool(scene.get("textures"))
+        n_k = max(len(kernel_ms), 1)
+        pk_ms = sum(t[0] for t in kernel_ms) / n_k   # stream_trace_shade, all recursion levels
+        ln_ms = sum(t[1] for t in kernel_ms) / n_k   # stream_trace_shadow
+        rs_ms = sum(t[2] for t in kernel_ms) / n_k   # stream_resolve
+        avg_kernel_ms = pk_ms + ln_ms + rs_ms
+        b_all = algorithmic_bytes(counters, 0, 0, textured) + 12 * my_pixels
+        # the roofline object is for the DOMINANT kernel: its own algorithmic bytes over its own duration
+        b_pk = algorithmic_bytes(pk_counters, 0, 0, textured)
+        b_ln = algorithmic_bytes(ln_counters, 0, 0, textured)
+        if pk_ms >= ln_ms:
+            dom, b_alg, dom_ms, dom_counters = "stream_trace_shade<false> (all levels)", b_pk, pk_ms, pk_counters
+        else:
+            dom, b_alg, dom_ms, dom_counters = "stream_trace_shadow<false>", b_ln, ln_ms, ln_counters
+        achieved = b_alg / (dom_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tp):
+            try:
+                with open(tp) as f:
+                    tj = json.load(f)
+                key = "%s_%dx%d_d%d_n%d" % (args.scene, W, H, depth, world)
+                if key in tj:
+                    traffic = tj[key]["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mpixels/s at 1920x1080 depth 8; HBM GB/s vs roofline",
+            "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "HW14 Optimizations02-like BVH scene (seeded torus knot + room, %d triangles), "
+                                   "%dx%d, depth %d, tiles over %d GPU(s)" % (sc.triangle_count(scene), W, H, depth, world),
+                       "scene": args.scene, "width": W, "height": H, "max_depth": depth,
+                       "parallelism": "tiles8x8-roundrobin-%d" % world},
+            "value_incl_d2h": round(W * H / d2h_elapsed / 1e6, 3),
+            "kernel_ms": {"stream_trace_shade": round(pk_ms, 4), "stream_trace_shadow": round(ln_ms, 4),
+                          "stream_resolve": round(rs_ms, 4)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": dom, "kernel_ms": round(dom_ms, 4),
+                         "algorithmic_bytes_per_launch": int(b_alg), "counters": dom_counters,
+                         "whole_frame": {"algorithmic_bytes": int(b_all), "kernels_ms": round(avg_kernel_ms, 4),
+                                         "achieved": round(b_all / (avg_kernel_ms * 1e-3) / 1e9, 2),
+                                         "counters": counters}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(sc, args.scene, depth)
+            except Exception as e:  # the baseline is a reported extra; never lose the GPU line over it
+                out["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

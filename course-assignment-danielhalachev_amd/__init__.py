@@ -98,8 +98,8 @@ class Stats(C.Structure):
 
 # every symbol include/crt_hip.h and include/crt_host.h declare
 DEVICE_SYMBOLS = ["crt_create", "crt_set_camera", "crt_render", "crt_render_tiles_device", "crt_packed_tile_count",
-                  "crt_unpack_tiles_device", "crt_quantize_device", "crt_read_quantized", "crt_kernel_elapsed_ms",
-                  "crt_get_stats", "crt_synchronize", "crt_destroy", "crt_last_error", "crt_device_count"]
+                  "crt_unpack_tiles_device", "crt_quantize_device", "crt_read_quantized", "crt_kernel_elapsed_ms", "crt_kernel_times_ms",
+                  "crt_get_stats", "crt_get_kernel_counters", "crt_synchronize", "crt_destroy", "crt_last_error", "crt_device_count"]
 HOST_SYMBOLS = ["crt_host_scene_parse_file", "crt_host_scene_parse_text", "crt_host_scene_free", "crt_host_scene_desc",
                 "crt_host_scene_settings", "crt_host_scene_camera", "crt_host_scene_mesh_count",
                 "crt_host_tree_node_count", "crt_host_tree_index_total", "crt_host_tree_dump", "crt_host_mesh_sizes",
@@ -130,7 +130,9 @@ def lib():
     L.crt_quantize_device.argtypes = [vp, vp, C.c_uint64, vp, vp]
     L.crt_read_quantized.argtypes = [vp, vp]
     L.crt_kernel_elapsed_ms.argtypes = [vp, C.POINTER(C.c_double)]
+    L.crt_kernel_times_ms.argtypes = [vp, C.POINTER(C.c_double), u32, C.POINTER(u32)]
     L.crt_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.crt_get_kernel_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.crt_synchronize.argtypes = [vp]
     L.crt_destroy.argtypes = [vp]
     L.crt_destroy.restype = None
@@ -326,6 +328,15 @@ class Tracer:
         lib().crt_get_stats(self.ctx, C.byref(s))
         return s
 
+    def kernel_counters(self):
+        """(packet-kernel counters, lane-kernel counters) of the last counted render, as dicts."""
+        names = ("box_tests", "tri_tests", "leaf_index_reads", "shaded_hits", "light_evals", "texel_fetches",
+                 "primary_rays", "secondary_rays", "shadow_rays")
+        a = (C.c_uint64 * 9)()
+        b = (C.c_uint64 * 9)()
+        self._check(lib().crt_get_kernel_counters(self.ctx, a, b))
+        return ({k: int(a[i]) for i, k in enumerate(names)}, {k: int(b[i]) for i, k in enumerate(names)})
+
     def _check(self, rc):
         if rc != CRT_OK:
             raise CrtError(rc, lib().crt_last_error(self.ctx).decode(errors="replace"))
@@ -350,6 +361,13 @@ class Tracer:
         ms = C.c_double()
         self._check(lib().crt_kernel_elapsed_ms(self.ctx, C.byref(ms)))
         return ms.value
+
+    def kernel_times_ms(self, max_count=64):
+        """[(closest-hit levels ms, shadow ms, resolve ms)] of the most recent renders, oldest first."""
+        a = (C.c_double * (3 * max_count))()
+        n = C.c_uint32()
+        self._check(lib().crt_kernel_times_ms(self.ctx, a, max_count, C.byref(n)))
+        return [(a[3 * i], a[3 * i + 1], a[3 * i + 2]) for i in range(n.value)]
 
     def read_quantized(self):
         out = np.zeros((self.height, self.width, 3), dtype=np.uint8)

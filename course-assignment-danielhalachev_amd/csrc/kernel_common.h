@@ -1,0 +1,273 @@
+// kernel_common.h -- device-side constants, argument block and exact-arithmetic helpers shared by the
+// two render kernels (kernel_packet.h: coherent 8x8 packets; kernel_lane.h: one independent ray per lane).
+#pragma once
+
+constexpr uint32_t END = CRT_LINK_END;
+constexpr uint32_t LEAF = CRT_LINK_LEAF;
+constexpr uint32_t LAST = CRT_ENTRY_LAST;
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr int TILE = 8;             // 8x8 pixel tiles: 64 pixels = one wavefront's worth
+constexpr int FRAME_DWORDS = 8;     // per recursion level and lane
+constexpr int BLOCK = 256;
+constexpr float PI_F = 3.14159265358979323846f;  // M_PIf, RayTracer.cpp:27
+
+enum : int { RAY_PRIMARY = 0, RAY_SHADOW = 1, RAY_REFLECTION = 2, RAY_REFRACTION = 3 };  // Ray.h:14
+enum : int { ST_FETCH = 0, ST_TRAVERSE = 1, ST_DONE = 2 };
+enum : int { FR_REFLECT = 0, FR_REFRACT_WAIT_REFLECTION = 1, FR_REFRACT_WAIT_REFRACTION = 2, FR_REFRACT_NO_TRANSMISSION = 3 };
+enum : int { C_BOX = 0, C_TRI, C_LEAFIDX, C_HIT, C_LIGHT, C_TEXEL, C_PRIMARY, C_SECONDARY, C_SHADOW,
+              C_WAVE_NODES, C_WAVE_TRIS, C_WAVE_WALKS, C_N };  // the last three: packet-kernel diagnostics (wave-level visits)
+constexpr int C_PUBLIC = 9;
+constexpr int SC_OVERFLOW_WORD = 2 * 64 + 2;  // == SC_OVERFLOW of kernel_stream.h (static_assert there)
+
+struct DMaterial { float ax, ay, az, ior; uint32_t type, smooth; int32_t texture; uint32_t pad; };
+struct DTexture { uint32_t kind; float ax, ay, az, bx, by, bz, scalar; uint32_t w, h; uint64_t offset; };
+
+// Work item: one 8x8 tile, the lanes (pixels) of it that are to be rendered, and where its pixels go.
+struct WorkItem { uint32_t tile; uint32_t out_tile; uint64_t mask; };
+
+struct KernelArgs {
+    const float4 *nodes;          // 2 x float4 per crt_node
+    const uint32_t *leaf_tris;
+    const uint32_t *leaf_meshes;
+    const float4 *tris;           // 4 x float4 per crt_triangle
+    const uint32_t *tri_verts;    // 3 per triangle
+    const float *vnormals;        // 3 per vertex
+    const float *vuvs;            // 3 per vertex (or null)
+    const crt_mesh *meshes;
+    const DMaterial *materials;
+    const DTexture *textures;
+    const uint32_t *texels;       // RGBX8
+    const float4 *lights;         // xyz + (float)intensity
+    uint32_t n_lights, top_root;
+    float bgx, bgy, bgz;
+    uint32_t width, height, tiles_x;
+    float cam_pos[3];
+    float cam[9];
+    uint32_t max_depth;
+    float shadow_bias, reflection_bias, refraction_bias;
+    const WorkItem *items;
+    uint32_t n_items;
+    uint32_t *pixel_counter;      // next unassigned (item*64 + lane)
+    float *out;                   // frame (row major) or packed tiles
+    uint32_t packed;              // 0: out is the H*W*3 frame, 1: out is packed by out_tile
+    float *frames;                // [wave][level][FRAME_DWORDS][64]
+    uint64_t frame_wave_stride;   // floats per wave
+    unsigned long long *counters; // C_N, counting build only
+    // hand-off between the two kernels: pixels the packet kernel does not finish (their primary hit is
+    // reflective or refractive) are appended here as q = item*64 + lane and rendered by the lane kernel
+    uint32_t *deferred;           // capacity n_items*64
+    uint32_t *deferred_count;
+    uint32_t use_deferred;        // lane kernel: 0 = walk all n_items*64 pixels, 1 = walk the deferred list
+    uint32_t *tile_counter;       // packet kernel: next unassigned work item
+    uint32_t nested_boxes;        // every inner node's child boxes lie inside its own box (checked by crt_create)
+    // ray-stream buffers (kernel_stream.h)
+    float4 *s_rayq[2];            // closest-hit ray queues of alternating recursion levels, 2 x float4 per ray
+    float4 *s_shadowq;            // shadow rays of all levels: {origin, light distance}, {direction, light factor}
+    uint8_t *s_occluded;          // one flag per shadow ray
+    float4 *s_nodes;              // ray-tree nodes (TNode), 2 x float4 each
+    uint32_t *s_counts;           // SC_WORDS counters / cursors, zeroed before every frame
+    uint32_t s_ray_cap, s_shadow_cap, s_node_cap;
+    uint32_t only_if_overflow;    // lane kernel: run only when the stream pass overflowed its queues
+};
+
+// ---------------------------------------------------------------------------------------------
+// exact-arithmetic helpers (expression shapes follow Vector.cpp; compiled with -ffp-contract=off)
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+    return ax * bx + ay * by + az * bz;  // Vector.cpp:57-59
+}
+__device__ __forceinline__ float len3(float x, float y, float z) {
+    return sqrtf(x * x + y * y + z * z);  // Vector.cpp:114-117
+}
+__device__ __forceinline__ void normalize3(float &x, float &y, float &z) {  // Vector.cpp:97-106
+    float length = len3(x, y, z);
+    if (length == 0) return;
+    length = 1.0f / length;
+    x *= length; y *= length; z *= length;
+}
+__device__ __forceinline__ float std_max(float a, float b) { return (a < b) ? b : a; }
+__device__ __forceinline__ float std_min(float a, float b) { return (b < a) ? b : a; }
+
+
+// A ray as both kernels see it: origin, direction, 1/direction (BoundingBox.h:95 recomputes it per box,
+// it only depends on the ray) and the mask of axes with |d| < FLT_EPSILON (BoundingBox.h:90).
+struct Ray {
+    float ox, oy, oz, dx, dy, dz, ix, iy, iz;
+    uint32_t parmask;
+};
+
+__device__ __forceinline__ void ray_prepare(Ray &R) {
+    R.parmask = (fabsf(R.dx) < FLT_EPSILON ? 1u : 0u) | (fabsf(R.dy) < FLT_EPSILON ? 2u : 0u) |
+                (fabsf(R.dz) < FLT_EPSILON ? 4u : 0u);
+    R.ix = 1.0f / R.dx;
+    R.iy = 1.0f / R.dy;
+    R.iz = 1.0f / R.dz;
+}
+
+// BoundingBox::hasIntersection (BoundingBox.h:85-108).  The reference returns early per axis; t0 only
+// grows and t1 only shrinks and a NaN is never selected by std::max/std::min as written there, so
+// (a) testing t0 > t1 once at the end gives the same verdict and (b) IEEE minNum/maxNum (v_min_f32 /
+// v_max_f32) select the same values as the reference's compare-and-swap + std::max/std::min, up to the
+// sign of a zero, which no comparison can see.  Axes with |d| < FLT_EPSILON take the containment test.
+__device__ __forceinline__ bool slab_test_no_parallel(const Ray &R, float lox, float loy, float loz, float hix, float hiy,
+                                                      float hiz) {
+    const float ax = (lox - R.ox) * R.ix, bx = (hix - R.ox) * R.ix;
+    const float ay = (loy - R.oy) * R.iy, by = (hiy - R.oy) * R.iy;
+    const float az = (loz - R.oz) * R.iz, bz = (hiz - R.oz) * R.iz;
+    const float t0 = fmaxf(fmaxf(fmaxf(-FLT_MAX, fminf(ax, bx)), fminf(ay, by)), fminf(az, bz));
+    const float t1 = fminf(fminf(fminf(FLT_MAX, fmaxf(ax, bx)), fmaxf(ay, by)), fmaxf(az, bz));
+    return !(t0 > t1);
+}
+
+__device__ __forceinline__ bool slab_test_general(const Ray &R, float lox, float loy, float loz, float hix, float hiy,
+                                                  float hiz) {
+    const float ax = (lox - R.ox) * R.ix, bx = (hix - R.ox) * R.ix;
+    const float ay = (loy - R.oy) * R.iy, by = (hiy - R.oy) * R.iy;
+    const float az = (loz - R.oz) * R.iz, bz = (hiz - R.oz) * R.iz;
+    const bool px = R.parmask & 1u, py = R.parmask & 2u, pz = R.parmask & 4u;
+    const bool reject = (px && ((R.ox < lox) || (R.ox > hix))) || (py && ((R.oy < loy) || (R.oy > hiy))) ||
+                        (pz && ((R.oz < loz) || (R.oz > hiz)));
+    // a parallel axis leaves t0 / t1 untouched (BoundingBox.h:90-93)
+    const float nx = px ? -FLT_MAX : fminf(ax, bx), fx = px ? FLT_MAX : fmaxf(ax, bx);
+    const float ny = py ? -FLT_MAX : fminf(ay, by), fy = py ? FLT_MAX : fmaxf(ay, by);
+    const float nz = pz ? -FLT_MAX : fminf(az, bz), fz = pz ? FLT_MAX : fmaxf(az, bz);
+    const float t0 = fmaxf(fmaxf(fmaxf(-FLT_MAX, nx), ny), nz);
+    const float t1 = fminf(fminf(fminf(FLT_MAX, fx), fy), fz);
+    return !(reject || (t0 > t1));
+}
+
+__device__ __forceinline__ bool slab_test(const Ray &R, float lox, float loy, float loz, float hix, float hiy, float hiz) {
+    if (R.parmask == 0) return slab_test_no_parallel(R, lox, loy, loz, hix, hiy, hiz);
+    return slab_test_general(R, lox, loy, loz, hix, hiy, hiz);
+}
+
+// Ray::intersectWithTriangle + Triangle::pointIsInTriangle (Ray.cpp:9-31, Triangle.cpp:37-57).
+// a, b, c = vertex positions with the unit face normal in the .w lanes; plane = -(v0 . n) (Ray.cpp:17).
+__device__ __forceinline__ bool triangle_test(const Ray &R, bool primary, const float4 &a, const float4 &b, const float4 &c,
+                                              float plane, float &t_out) {
+    const float nx = a.w, ny = b.w, nz = c.w;
+    const float nd = dot3(R.dx, R.dy, R.dz, nx, ny, nz);
+    if (primary && nd >= 0) return false;
+    const float t = -(dot3(nx, ny, nz, R.ox, R.oy, R.oz) + plane) / nd;
+    if (t < 0) return false;
+    const float px = R.ox + R.dx * t, py = R.oy + R.dy * t, pz = R.oz + R.dz * t;
+    {
+        const float ex = b.x - a.x, ey = b.y - a.y, ez = b.z - a.z;
+        const float cx = px - a.x, cy = py - a.y, cz = pz - a.z;
+        if (dot3(nx, ny, nz, ey * cz - ez * cy, ez * cx - ex * cz, ex * cy - ey * cx) < -FLT_EPSILON) return false;
+    }
+    {
+        const float ex = c.x - b.x, ey = c.y - b.y, ez = c.z - b.z;
+        const float cx = px - b.x, cy = py - b.y, cz = pz - b.z;
+        if (dot3(nx, ny, nz, ey * cz - ez * cy, ez * cx - ex * cz, ex * cy - ey * cx) < -FLT_EPSILON) return false;
+    }
+    {
+        const float ex = a.x - c.x, ey = a.y - c.y, ez = a.z - c.z;
+        const float cx = px - c.x, cy = py - c.y, cz = pz - c.z;
+        if (dot3(nx, ny, nz, ey * cz - ez * cy, ez * cx - ex * cz, ex * cy - ey * cx) < -FLT_EPSILON) return false;
+    }
+    t_out = t;
+    return true;
+}
+
+// RayTracer::getRay (RayTracer.cpp:61-80), pixel centre, followed by shootRay's own normalisation
+// (RayTracer.cpp:420): every primary direction is normalised twice.
+__device__ __forceinline__ void primary_ray(const KernelArgs &A, uint32_t px, uint32_t py, Ray &R) {
+    float x = (float)px + 0.5f;
+    float y = (float)py + 0.5f;
+    x = x / (float)A.width;
+    y = y / (float)A.height;
+    x = (2.0f * x) - 1.0f;
+    y = 1.0f - (2.0f * y);
+    x = x * ((float)A.width / (float)A.height);
+    const float z = -1.0f;
+    R.dx = x * A.cam[0] + y * A.cam[3] + z * A.cam[6];   // row vector x matrix, Matrix.h:137-142
+    R.dy = x * A.cam[1] + y * A.cam[4] + z * A.cam[7];
+    R.dz = x * A.cam[2] + y * A.cam[5] + z * A.cam[8];
+    normalize3(R.dx, R.dy, R.dz);
+    R.ox = A.cam_pos[0]; R.oy = A.cam_pos[1]; R.oz = A.cam_pos[2];
+    normalize3(R.dx, R.dy, R.dz);
+    ray_prepare(R);
+}
+
+// Texture::getColor (Texture.cpp:14-72)
+template <bool COUNT>
+__device__ __forceinline__ void texture_color(const KernelArgs &A, const DTexture &T, uint32_t tri, float u, float v,
+                                              float w, float &r, float &g, float &b, bool &is_bitmap) {
+    is_bitmap = false;
+    if (T.kind == CRT_TEX_ALBEDO) { r = T.ax; g = T.ay; b = T.az; return; }
+    if (T.kind == CRT_TEX_EDGES) {
+        if (u < T.scalar || v < T.scalar || w < T.scalar) { r = T.bx; g = T.by; b = T.bz; }
+        else { r = T.ax; g = T.ay; b = T.az; }
+        return;
+    }
+    const uint32_t i0 = A.tri_verts[3 * (size_t)tri], i1 = A.tri_verts[3 * (size_t)tri + 1],
+                   i2 = A.tri_verts[3 * (size_t)tri + 2];
+    // u * UV1 + v * UV2 + (w * UV0), Texture.cpp:34-36 / 63-65 (only x and y are used)
+    const float uvx = (u * A.vuvs[3 * (size_t)i1] + v * A.vuvs[3 * (size_t)i2]) + w * A.vuvs[3 * (size_t)i0];
+    const float uvy = (u * A.vuvs[3 * (size_t)i1 + 1] + v * A.vuvs[3 * (size_t)i2 + 1]) + w * A.vuvs[3 * (size_t)i0 + 1];
+    if (T.kind == CRT_TEX_CHECKER) {
+        const unsigned int x = (unsigned int)(uvx / T.scalar);
+        const unsigned int y = (unsigned int)(uvy / T.scalar);
+        if (x % 2 == y % 2) { r = T.ax; g = T.ay; b = T.az; } else { r = T.bx; g = T.by; b = T.bz; }
+        return;
+    }
+    is_bitmap = true;
+    int x = (int)(uvx * (float)(int)T.w);
+    int y = (int)((1.0f - uvy) * (float)(int)T.h);
+    x = (x < 0) ? 0 : (((int)T.w - 1 < x) ? (int)T.w - 1 : x);  // std::clamp
+    y = (y < 0) ? 0 : (((int)T.h - 1 < y) ? (int)T.h - 1 : y);
+    const uint32_t px = A.texels[T.offset + (size_t)y * T.w + (size_t)x];
+    const float coefficient = 1.0f / 255.0f;  // Texture.cpp:53-57
+    r = (float)(px & 255u) * coefficient;
+    g = (float)((px >> 8) & 255u) * coefficient;
+    b = (float)((px >> 16) & 255u) * coefficient;
+}
+
+// What shading needs to know about a closest hit (KDTree.cpp:168-190): point, (smooth) normal,
+// barycentrics and the material of the mesh.
+struct Surface {
+    float px, py, pz, nx, ny, nz, u, v;
+    DMaterial M;
+};
+
+__device__ __forceinline__ void surface_at(const KernelArgs &A, const Ray &R, float t, uint32_t tri, uint32_t mesh, Surface &S) {
+    const float4 ta = A.tris[4 * (size_t)tri + 0], tb = A.tris[4 * (size_t)tri + 1], tc = A.tris[4 * (size_t)tri + 2];
+    S.px = R.ox + R.dx * t; S.py = R.oy + R.dy * t; S.pz = R.oz + R.dz * t;  // Ray.cpp:23
+    S.nx = ta.w; S.ny = tb.w; S.nz = tc.w;
+    S.M = A.materials[A.meshes[mesh].material];
+    S.u = 0; S.v = 0;
+    if (S.M.smooth || S.M.texture >= 0) {
+        // Triangle::getBarycentricCoordinates (Triangle.cpp:63-73)
+        const float v0px = S.px - ta.x, v0py = S.py - ta.y, v0pz = S.pz - ta.z;
+        const float e1x = tb.x - ta.x, e1y = tb.y - ta.y, e1z = tb.z - ta.z;
+        const float e2x = tc.x - ta.x, e2y = tc.y - ta.y, e2z = tc.z - ta.z;
+        const float area = len3(e1y * e2z - e1z * e2y, e1z * e2x - e1x * e2z, e1x * e2y - e1y * e2x);
+        S.u = len3(v0py * e2z - v0pz * e2y, v0pz * e2x - v0px * e2z, v0px * e2y - v0py * e2x) / area;
+        S.v = len3(e1y * v0pz - e1z * v0py, e1z * v0px - e1x * v0pz, e1x * v0py - e1y * v0px) / area;
+        if (S.M.smooth) {  // KDTree.cpp:180-185: n1*u + n2*v + n0*(1-u-v), normalised
+            const uint32_t i0 = A.tri_verts[3 * (size_t)tri], i1 = A.tri_verts[3 * (size_t)tri + 1],
+                           i2 = A.tri_verts[3 * (size_t)tri + 2];
+            const float w = 1 - S.u - S.v;
+            S.nx = (A.vnormals[3 * (size_t)i1] * S.u + A.vnormals[3 * (size_t)i2] * S.v) + A.vnormals[3 * (size_t)i0] * w;
+            S.ny = (A.vnormals[3 * (size_t)i1 + 1] * S.u + A.vnormals[3 * (size_t)i2 + 1] * S.v) + A.vnormals[3 * (size_t)i0 + 1] * w;
+            S.nz = (A.vnormals[3 * (size_t)i1 + 2] * S.u + A.vnormals[3 * (size_t)i2 + 2] * S.v) + A.vnormals[3 * (size_t)i0 + 2] * w;
+            normalize3(S.nx, S.ny, S.nz);
+        }
+    }
+}
+
+// One light of RayTracer::calculateDiffusion (RayTracer.cpp:308-318): the shadow ray towards it, its
+// length and the factor (intensity / sphereArea * angle) the albedo is multiplied by when it is unoccluded.
+__device__ __forceinline__ void light_setup(const KernelArgs &A, uint32_t li, float hpx, float hpy, float hpz, float hnx,
+                                            float hny, float hnz, Ray &R, float &dist, float &kfac) {
+    const float4 lg = A.lights[li];
+    float lx = lg.x - hpx, ly = lg.y - hpy, lz = lg.z - hpz;
+    dist = len3(lx, ly, lz);
+    const float area = 4 * dist * dist * PI_F;
+    normalize3(lx, ly, lz);
+    const float angle = std_max(0.0f, dot3(lx, ly, lz, hnx, hny, hnz));
+    kfac = lg.w / area * angle;
+    R.ox = hpx + hnx * A.shadow_bias; R.oy = hpy + hny * A.shadow_bias; R.oz = hpz + hnz * A.shadow_bias;
+    R.dx = lx; R.dy = ly; R.dz = lz;
+    ray_prepare(R);
+}

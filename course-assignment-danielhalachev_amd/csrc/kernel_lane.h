@@ -1,0 +1,325 @@
+// kernel_lane.h -- render_lanes: one independent ray per lane.
+//
+// This kernel can render any pixel (it is the complete hot path); the packet kernel hands it the pixels
+// whose rays lose coherence (primary hit on a reflective / refractive mesh).  A lane owns a pixel until
+// its colour is final, walking the reference's recursion with an explicit frame stack
+// (RayTracer.cpp:358-451); a lane that finishes fetches the next pixel from a global counter, so a
+// wavefront stays full until the work runs out.
+#pragma once
+
+#include "kernel_common.h"
+
+struct LaneWalk {
+    // traversal cursors: top-level node / position in a top-level leaf / mesh-tree node / position in a mesh leaf
+    uint32_t tnode, tleaf, mnode, mleaf, cur_mesh;
+    // mesh-level and scene-level running closest hit (KDTree.cpp:75-86, 156-167)
+    bool mhave, have, occluded;
+    float mmin, mt, tmin, bt, light_dist;
+    uint32_t mtri, btri, bmesh;
+    int rtype;
+};
+
+__device__ __forceinline__ void traversal_begin(LaneWalk &L, uint32_t top_root) {
+    L.tnode = top_root;
+    L.tleaf = NONE;
+    L.mnode = END;
+    L.mleaf = NONE;
+    L.cur_mesh = NONE;
+    L.mhave = false;
+    L.have = false;
+    L.occluded = false;
+    L.tmin = INFINITY;
+    L.mmin = INFINITY;
+}
+
+// One unit of traversal work for this lane: either one triangle test (when inside a leaf) or one
+// node visit / bookkeeping step.  Returns false when the whole two-level walk is finished.
+template <bool COUNT>
+__device__ __forceinline__ bool traversal_step(LaneWalk &L, const Ray &R, const KernelArgs &A, uint32_t *cnt) {
+    if (L.mleaf != NONE) {
+        // ---- inside a mesh-tree leaf: test one triangle (KDTree.cpp:57-65)
+        const uint32_t ent = A.leaf_tris[L.mleaf];
+        const uint32_t tri = ent & ~LAST;
+        L.mleaf = (ent & LAST) ? NONE : L.mleaf + 1;
+        const float4 a = A.tris[4 * (size_t)tri + 0];
+        const float4 b = A.tris[4 * (size_t)tri + 1];
+        const float4 c = A.tris[4 * (size_t)tri + 2];
+        const float plane = A.tris[4 * (size_t)tri + 3].x;
+        if (COUNT) { cnt[C_TRI]++; cnt[C_LEAFIDX]++; }
+        float t;
+        if (triangle_test(R, L.rtype == RAY_PRIMARY, a, b, c, plane, t)) {
+            // `closest = hits[0]; min = inf; for h: if (h.d < min) {min = h.d; closest = h}` fused into the walk
+            if (!L.mhave) { L.mhave = true; L.mt = t; L.mtri = tri; }
+            if (t < L.mmin) { L.mmin = t; L.mt = t; L.mtri = tri; }
+        }
+        return true;
+    }
+    if (L.cur_mesh != NONE) {
+        if (L.mnode != END) {
+            // ---- visit one mesh-tree node (KDTree.cpp:53-74)
+            const float4 q0 = A.nodes[2 * (size_t)L.mnode], q1 = A.nodes[2 * (size_t)L.mnode + 1];
+            const uint32_t miss = __float_as_uint(q0.w), link = __float_as_uint(q1.w);
+            if (COUNT) cnt[C_BOX]++;
+            const bool hit = slab_test(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
+            if (hit && (link & LEAF)) {
+                L.mleaf = link & ~LEAF;
+                L.mnode = miss;
+            } else {
+                L.mnode = hit ? link : miss;
+            }
+            return true;
+        }
+        // ---- this mesh is finished: hand its closest hit to the scene level
+        if (L.mhave) {
+            if (L.rtype == RAY_SHADOW) {
+                // AccelerationStructure.cpp:73-74: length(hitPoint - origin) <= distanceToLight
+                const float px = R.ox + R.dx * L.mt, py = R.oy + R.dy * L.mt, pz = R.oz + R.dz * L.mt;
+                if (len3(px - R.ox, py - R.oy, pz - R.oz) <= L.light_dist) L.occluded = true;
+            } else {
+                if (!L.have) { L.have = true; L.bt = L.mt; L.btri = L.mtri; L.bmesh = L.cur_mesh; }
+                if (L.mt < L.tmin) { L.tmin = L.mt; L.bt = L.mt; L.btri = L.mtri; L.bmesh = L.cur_mesh; }
+            }
+        }
+        L.cur_mesh = NONE;
+        return true;
+    }
+    if (L.tleaf != NONE) {
+        // ---- inside a top-level leaf: start the next mesh (KDTree.cpp:138-144, AccelerationStructure.cpp:66-72)
+        const uint32_t ent = A.leaf_meshes[L.tleaf];
+        const uint32_t mi = ent & ~LAST;
+        L.tleaf = (ent & LAST) ? NONE : L.tleaf + 1;
+        if (COUNT) cnt[C_LEAFIDX]++;
+        const crt_mesh m = A.meshes[mi];
+        if (L.rtype == RAY_SHADOW && (m.flags & 1u)) return true;
+        L.cur_mesh = mi;
+        L.mnode = m.root;
+        L.mhave = false;
+        L.mmin = INFINITY;
+        return true;
+    }
+    if (L.tnode != END) {
+        // ---- visit one top-level node (KDTree.cpp:132-155)
+        const float4 q0 = A.nodes[2 * (size_t)L.tnode], q1 = A.nodes[2 * (size_t)L.tnode + 1];
+        const uint32_t miss = __float_as_uint(q0.w), link = __float_as_uint(q1.w);
+        if (COUNT) cnt[C_BOX]++;
+        const bool hit = slab_test(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
+        if (hit && (link & LEAF)) {
+            L.tleaf = link & ~LEAF;
+            L.tnode = miss;
+        } else {
+            L.tnode = hit ? link : miss;
+        }
+        return true;
+    }
+    return false;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) void render_lanes(const KernelArgs A) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    float *frames = A.frames + (size_t)wave * A.frame_wave_stride + lane;
+    auto FR = [&](uint32_t level, int field) -> float & { return frames[((size_t)level * FRAME_DWORDS + field) * 64]; };
+    auto FRK = [&](uint32_t level) -> int & { return *reinterpret_cast<int *>(&frames[(size_t)level * FRAME_DWORDS * 64]); };
+
+    uint32_t cnt[C_N];
+    if (COUNT) for (int k = 0; k < C_N; k++) cnt[k] = 0;
+
+    Ray R;
+    LaneWalk L;
+    int state = ST_FETCH;
+    uint32_t sp = 0;           // recursion level of the current ray == number of frames below it
+    size_t out_off = 0;
+    // diffuse light loop (RayTracer.cpp:300-330)
+    float hpx = 0, hpy = 0, hpz = 0, hnx = 0, hny = 0, hnz = 0;
+    float basex = 0, basey = 0, basez = 0, accx = 0, accy = 0, accz = 0, kfac = 0;
+    uint32_t li = 0;
+    bool base_is_bitmap = false;
+    if (A.only_if_overflow && !A.s_counts[SC_OVERFLOW_WORD]) return;  // fallback of the stream pass: usually nothing to do
+    const uint32_t total_px = A.use_deferred ? *A.deferred_count : A.n_items * 64u;
+
+    for (;;) {
+        // ------------------------------------------------------------------ fetch new pixels
+        if (__ballot(state == ST_FETCH)) {
+            while (state == ST_FETCH) {
+                const unsigned long long need = __ballot(1);
+                const int n = __popcll(need);
+                const int rank = __popcll(need & ((1ull << lane) - 1ull));
+                uint32_t base = 0;
+                if (rank == 0) base = atomicAdd(A.pixel_counter, (uint32_t)n);
+                base = __shfl(base, __ffsll((long long)need) - 1);
+                uint32_t q = base + (uint32_t)rank;
+                if (q >= total_px) { state = ST_DONE; break; }
+                if (A.use_deferred) q = A.deferred[q];
+                const WorkItem wi = A.items[q >> 6];
+                const uint32_t sub = q & 63u;
+                const uint32_t px = (wi.tile % A.tiles_x) * TILE + (sub & 7u);
+                const uint32_t py = (wi.tile / A.tiles_x) * TILE + (sub >> 3);
+                if (!((wi.mask >> sub) & 1ull) || px >= A.width || py >= A.height) continue;  // not covered: take another
+                out_off = A.packed ? ((size_t)wi.out_tile * 64 + sub) * 3 : ((size_t)py * A.width + px) * 3;
+                primary_ray(A, px, py, R);  // depth 0 <= MAX_DEPTH always (RayTracer.cpp:427)
+                L.rtype = RAY_PRIMARY;
+                sp = 0;
+                if (COUNT) cnt[C_PRIMARY]++;
+                traversal_begin(L, A.top_root);
+                state = ST_TRAVERSE;
+            }
+        }
+        if (!__ballot(state != ST_DONE)) break;
+
+        // ------------------------------------------------------------------ traverse
+        bool finished = false;
+        if (state == ST_TRAVERSE) {
+            int budget = 48;
+            do {
+                if (!traversal_step<COUNT>(L, R, A, cnt)) { finished = true; break; }
+            } while (--budget > 0);
+        }
+
+        // ------------------------------------------------------------------ a walk ended: shade / continue
+        if (finished) {
+            bool returning = false;      // a colour is being returned to the caller level
+            bool new_ray = false;        // R holds a new ray that enters shootRay at level sp
+            bool next_light = false;
+            float cx = 0, cy = 0, cz = 0;
+
+            if (L.rtype == RAY_SHADOW) {
+                if (!L.occluded) {  // RayTracer.cpp:319-328
+                    if (COUNT && base_is_bitmap) cnt[C_TEXEL]++;
+                    accx += kfac * basex; accy += kfac * basey; accz += kfac * basez;
+                }
+                li++;
+                next_light = true;
+            } else if (!L.have) {
+                cx = A.bgx; cy = A.bgy; cz = A.bgz; returning = true;  // RayTracer.cpp:449-450
+            } else {
+                Surface S;
+                surface_at(A, R, L.bt, L.btri, L.bmesh, S);
+                if (COUNT) cnt[C_HIT]++;
+                if (S.M.type == CRT_MAT_DIFFUSE) {
+                    hpx = S.px; hpy = S.py; hpz = S.pz; hnx = S.nx; hny = S.ny; hnz = S.nz;
+                    base_is_bitmap = false;
+                    if (S.M.texture >= 0) {
+                        texture_color<COUNT>(A, A.textures[S.M.texture], L.btri, S.u, S.v, 1.0f - S.u - S.v, basex, basey,
+                                             basez, base_is_bitmap);
+                    } else { basex = S.M.ax; basey = S.M.ay; basez = S.M.az; }
+                    accx = accy = accz = 0;
+                    li = 0;
+                    next_light = true;
+                } else if (S.M.type == CRT_MAT_REFLECTIVE) {
+                    // RayTracer::calculateReflection (RayTracer.cpp:358-374)
+                    FRK(sp) = FR_REFLECT;
+                    FR(sp, 1) = S.M.ax; FR(sp, 2) = S.M.ay; FR(sp, 3) = S.M.az;
+                    const float k = 2 * dot3(R.dx, R.dy, R.dz, S.nx, S.ny, S.nz);  // Vector::reflect, Vector.cpp:119-122
+                    const float rx = R.dx - k * S.nx, ry = R.dy - k * S.ny, rz = R.dz - k * S.nz;
+                    R.ox = S.px + S.nx * A.reflection_bias; R.oy = S.py + S.ny * A.reflection_bias; R.oz = S.pz + S.nz * A.reflection_bias;
+                    R.dx = rx; R.dy = ry; R.dz = rz;
+                    normalize3(R.dx, R.dy, R.dz);
+                    L.rtype = RAY_REFLECTION;
+                    sp++;
+                    new_ray = true;
+                } else if (S.M.type == CRT_MAT_REFRACTIVE) {
+                    // RayTracer::calculateRefraction (RayTracer.cpp:375-417)
+                    float nx = S.nx, ny = S.ny, nz = S.nz;
+                    float eta1 = 1.0f, eta2 = S.M.ior;
+                    float idn = dot3(R.dx, R.dy, R.dz, nx, ny, nz);
+                    if (idn > 0) {
+                        const float s = eta1; eta1 = eta2; eta2 = s;
+                        nx = -1.0f * nx; ny = -1.0f * ny; nz = -1.0f * nz;
+                        idn = -idn;
+                    }
+                    const float cos_a = -idn;
+                    const float sin_a = sqrtf(std_max(0.0f, 1 - cos_a * cos_a));
+                    const float k = 2 * dot3(R.dx, R.dy, R.dz, nx, ny, nz);
+                    const float rx = R.dx - k * nx, ry = R.dy - k * ny, rz = R.dz - k * nz;
+                    const float eta_ratio = eta1 / eta2;
+                    const float sin_b = eta_ratio * sin_a;
+                    if (sin_b < 1.0f) {
+                        const float q = (eta1 - eta2) / (eta1 + eta2);
+                        const float r0 = q * q;  // std::powf(q, 2): folded to q*q by the reference's compiler at -O2
+                        const float fresnel = r0 + (1 - r0) * crt_pow5(1.0f - cos_a);
+                        const float cos_b = sqrtf(std_max(0.0f, 1 - sin_b * sin_b));
+                        float tx = eta_ratio * (R.dx + cos_a * nx) - cos_b * nx;
+                        float ty = eta_ratio * (R.dy + cos_a * ny) - cos_b * ny;
+                        float tz = eta_ratio * (R.dz + cos_a * nz) - cos_b * nz;
+                        normalize3(tx, ty, tz);
+                        FRK(sp) = FR_REFRACT_WAIT_REFLECTION;
+                        FR(sp, 1) = S.px - nx * A.refraction_bias; FR(sp, 2) = S.py - ny * A.refraction_bias;
+                        FR(sp, 3) = S.pz - nz * A.refraction_bias;
+                        FR(sp, 4) = tx; FR(sp, 5) = ty; FR(sp, 6) = tz;
+                        FR(sp, 7) = fresnel;
+                    } else {
+                        FRK(sp) = FR_REFRACT_NO_TRANSMISSION;
+                    }
+                    R.ox = S.px + nx * A.reflection_bias; R.oy = S.py + ny * A.reflection_bias; R.oz = S.pz + nz * A.reflection_bias;
+                    R.dx = rx; R.dy = ry; R.dz = rz;
+                    normalize3(R.dx, R.dy, R.dz);
+                    L.rtype = RAY_REFLECTION;
+                    sp++;
+                    new_ray = true;
+                } else {
+                    cx = A.bgx; cy = A.bgy; cz = A.bgz; returning = true;  // RayTracer.cpp:443-446
+                }
+            }
+
+            // ---- diffuse light loop: set up the next shadow ray or return the accumulated colour
+            if (next_light) {
+                if (li < A.n_lights) {
+                    if (COUNT) { cnt[C_LIGHT]++; cnt[C_SHADOW]++; }
+                    light_setup(A, li, hpx, hpy, hpz, hnx, hny, hnz, R, L.light_dist, kfac);
+                    L.rtype = RAY_SHADOW;
+                    traversal_begin(L, A.top_root);
+                } else {
+                    cx = accx; cy = accy; cz = accz; returning = true;
+                }
+            }
+
+            // ---- unwind / advance the explicit recursion (post-order, as the reference's call stack does)
+            while (returning || new_ray) {
+                if (new_ray) {
+                    // shootRay entry (RayTracer.cpp:419-429)
+                    normalize3(R.dx, R.dy, R.dz);
+                    new_ray = false;
+                    if (sp > A.max_depth) { cx = A.bgx; cy = A.bgy; cz = A.bgz; returning = true; continue; }
+                    if (COUNT) cnt[C_SECONDARY]++;
+                    ray_prepare(R);
+                    traversal_begin(L, A.top_root);
+                    break;
+                }
+                if (sp == 0) {
+                    A.out[out_off] = cx; A.out[out_off + 1] = cy; A.out[out_off + 2] = cz;  // RayTracer.cpp:106
+                    state = ST_FETCH;
+                    break;
+                }
+                const uint32_t f = sp - 1;
+                const int kind = FRK(f);
+                if (kind == FR_REFLECT) {
+                    cx = 0.0f + FR(f, 1) * cx; cy = 0.0f + FR(f, 2) * cy; cz = 0.0f + FR(f, 3) * cz;  // RayTracer.cpp:368-372
+                    sp = f;
+                } else if (kind == FR_REFRACT_NO_TRANSMISSION) {
+                    sp = f;  // `return reflectionColor`, RayTracer.cpp:416
+                } else if (kind == FR_REFRACT_WAIT_REFLECTION) {
+                    R.ox = FR(f, 1); R.oy = FR(f, 2); R.oz = FR(f, 3);
+                    R.dx = FR(f, 4); R.dy = FR(f, 5); R.dz = FR(f, 6);
+                    L.rtype = RAY_REFRACTION;
+                    FRK(f) = FR_REFRACT_WAIT_REFRACTION;
+                    FR(f, 1) = cx; FR(f, 2) = cy; FR(f, 3) = cz;  // reflectionColor
+                    returning = false;
+                    new_ray = true;   // enters shootRay at level sp (== f + 1)
+                } else {
+                    const float fr = FR(f, 7);  // RayTracer.cpp:414
+                    cx = fr * FR(f, 1) + (1 - fr) * cx; cy = fr * FR(f, 2) + (1 - fr) * cy; cz = fr * FR(f, 3) + (1 - fr) * cz;
+                    sp = f;
+                }
+            }
+        }
+    }
+
+    if (COUNT) {
+        for (int k = 0; k < C_N; k++) {
+            unsigned long long v = cnt[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+            if (lane == 0 && v) atomicAdd(&A.counters[k], v);
+        }
+    }
+}

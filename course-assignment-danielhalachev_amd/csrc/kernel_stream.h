@@ -1,0 +1,402 @@
+// kernel_stream.h -- the ray-stream form of the hot path (default).
+//
+// The reference evaluates a pixel as a depth-first recursion: shootRay -> calculateReflection /
+// calculateRefraction -> shootRay ... with calculateDiffusion's shadow rays at the leaves
+// (RayTracer.cpp:300-451).  Run that way on a GPU, ONE pixel's chain of up to 2^(MAX_DEPTH+1)-1 dependent
+// tree walks is the critical path of the whole frame.  Here the recursion is unrolled by GENERATION instead:
+//
+//   stream_trace_shade(g), g = 0 .. MAX_DEPTH   every ray of recursion level g, one ray per lane: closest-hit
+//                                               walk, then the material dispatch.  It records a node of the
+//                                               pixel's ray tree (TNode), appends the child rays (level g+1)
+//                                               to the next queue and the hit's shadow rays to the shadow queue.
+//   stream_trace_shadow                         every shadow ray of every level in ONE launch -> occlusion flag.
+//   stream_resolve                              per pixel, walks its ray tree in the reference's post-order and
+//                                               combines the colours with the reference's own expressions, so
+//                                               every float is produced by the same operations in the same order.
+//
+// All rays of a level are independent, so each launch has millions of rays of parallelism and no lane ever
+// waits for a recursion.  Queues, the ray tree and the flags live in HBM (a few hundred MB at 1080p).
+#pragma once
+
+#include "kernel_common.h"
+#include "kernel_lane.h"
+
+struct TNode {          // one node of a pixel's ray tree, 32 bytes
+    float cx, cy, cz;   // DIFFUSE: texture/albedo colour; REFLECT: albedo; after resolve of a REFRACT node: reflection colour
+    uint32_t kind;
+    uint32_t a, b;      // DIFFUSE: first shadow-ray index, stride between lights; REFLECT: child; REFRACT: reflection child, refraction child
+    float f;            // REFRACT: Fresnel coefficient
+    uint32_t pad;
+};
+enum : uint32_t { TN_CONST = 0, TN_DIFFUSE = 1, TN_REFLECT = 2, TN_REFRACT = 3, TN_SKIP = 4, TN_KIND_MASK = 0xFFu,
+                  TN_BITMAP = 0x100u };
+constexpr uint32_t CHILD_BG = 0xFFFFFFFFu;     // child ray beyond MAX_DEPTH: background without tracing (RayTracer.cpp:427-429)
+constexpr uint32_t CHILD_NONE = 0xFFFFFFFEu;   // total internal reflection: no refraction child (RayTracer.cpp:416)
+constexpr int MAX_GENERATIONS = 64;
+// layout of KernelArgs::s_counts (uint32): [g] rays of level g, [SC_FETCH + g] fetch cursor of level g
+enum : int { SC_COUNT = 0, SC_FETCH = MAX_GENERATIONS, SC_SHADOW = 2 * MAX_GENERATIONS, SC_SHADOW_FETCH, SC_OVERFLOW,
+             SC_RESOLVE_FETCH, SC_WORDS };
+
+static_assert(SC_OVERFLOW == SC_OVERFLOW_WORD, "kernel_common.h SC_OVERFLOW_WORD must match");
+
+__device__ __forceinline__ uint32_t stream_level_count(const KernelArgs &A, uint32_t g) {
+    return g == 0 ? A.n_items * 64u : A.s_counts[SC_COUNT + g];
+}
+__device__ __forceinline__ uint32_t stream_level_base(const KernelArgs &A, uint32_t g) {
+    uint32_t base = 0;
+    for (uint32_t k = 0; k < g; k++) base += stream_level_count(A, k);
+    return base;
+}
+
+// wave-aggregated fetch of one work index per requesting lane (all lanes executing this must want one)
+__device__ __forceinline__ uint32_t wave_fetch(uint32_t *cursor, uint32_t lane) {
+    const unsigned long long need = __ballot(1);
+    const int rank = __popcll(need & ((1ull << lane) - 1ull));
+    uint32_t base = 0;
+    if (rank == 0) base = atomicAdd(cursor, (uint32_t)__popcll(need));
+    base = __shfl(base, __ffsll((long long)need) - 1);
+    return base + (uint32_t)rank;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) void stream_trace_shade(const KernelArgs A, const uint32_t gen) {
+    const uint32_t lane = threadIdx.x & 63u;
+    if (A.s_counts[SC_OVERFLOW]) return;  // the fallback path redoes the frame
+    const uint32_t count = stream_level_count(A, gen);
+    const uint32_t node_base = stream_level_base(A, gen);
+    const uint32_t child_base = node_base + count;
+    const float4 *in_q = A.s_rayq[gen & 1u];
+    float4 *out_q = A.s_rayq[(gen + 1u) & 1u];
+    uint32_t *out_count = A.s_counts + SC_COUNT + gen + 1;
+    const bool spawn_allowed = gen + 1 <= A.max_depth;  // a child enters shootRay with depth gen+1 (RayTracer.cpp:427)
+
+    uint32_t cnt[C_N];
+    if (COUNT) for (int k = 0; k < C_N; k++) cnt[k] = 0;
+
+    Ray R;
+    LaneWalk L;
+    int state = ST_FETCH;
+    uint32_t r = 0;
+    uint32_t steps = 0, max_steps = 0;  // counting build: longest single walk (diagnostic)
+
+    for (;;) {
+        // ------------------------------------------------------------------ fetch
+        if (__ballot(state == ST_FETCH)) {
+            while (state == ST_FETCH) {
+                r = wave_fetch(A.s_counts + SC_FETCH + gen, lane);
+                if (r >= count) { state = ST_DONE; break; }
+                if (gen == 0) {
+                    const WorkItem wi = A.items[r >> 6];
+                    const uint32_t sub = r & 63u;
+                    const uint32_t px = (wi.tile % A.tiles_x) * TILE + (sub & 7u);
+                    const uint32_t py = (wi.tile / A.tiles_x) * TILE + (sub >> 3);
+                    if (!((wi.mask >> sub) & 1ull) || px >= A.width || py >= A.height) {
+                        reinterpret_cast<uint32_t *>(A.s_nodes + 2 * (size_t)r)[3] = TN_SKIP;
+                        continue;
+                    }
+                    primary_ray(A, px, py, R);
+                    L.rtype = RAY_PRIMARY;
+                    if (COUNT) cnt[C_PRIMARY]++;
+                } else {
+                    const float4 q0 = in_q[2 * (size_t)r], q1 = in_q[2 * (size_t)r + 1];
+                    R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
+                    R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;
+                    normalize3(R.dx, R.dy, R.dz);  // shootRay entry (RayTracer.cpp:420)
+                    ray_prepare(R);
+                    L.rtype = RAY_REFLECTION;      // reflection and refraction rays behave alike in the walk
+                    if (COUNT) cnt[C_SECONDARY]++;
+                }
+                traversal_begin(L, A.top_root);
+                state = ST_TRAVERSE;
+            }
+        }
+        if (!__ballot(state != ST_DONE)) break;
+
+        // ------------------------------------------------------------------ traverse
+        bool finished = false;
+        if (state == ST_TRAVERSE) {
+            int budget = 64;
+            do {
+                if (!traversal_step<COUNT>(L, R, A, cnt)) { finished = true; break; }
+                if (COUNT) steps++;
+            } while (--budget > 0);
+        }
+
+        // ------------------------------------------------------------------ shade (shootRay's dispatch, RayTracer.cpp:431-450)
+        if (finished) {
+            if (COUNT) { max_steps = steps > max_steps ? steps : max_steps; steps = 0; }
+            TNode N;
+            N.cx = A.bgx; N.cy = A.bgy; N.cz = A.bgz;
+            N.kind = TN_CONST; N.a = 0; N.b = 0; N.f = 0; N.pad = 0;
+            if (L.have) {
+                Surface S;
+                surface_at(A, R, L.bt, L.btri, L.bmesh, S);
+                if (COUNT) cnt[C_HIT]++;
+                if (S.M.type == CRT_MAT_DIFFUSE) {
+                    // calculateDiffusion (RayTracer.cpp:300-330): the light loop becomes n_lights shadow rays
+                    bool bitmap = false;
+                    if (S.M.texture >= 0)
+                        texture_color<COUNT>(A, A.textures[S.M.texture], L.btri, S.u, S.v, 1.0f - S.u - S.v, N.cx, N.cy, N.cz, bitmap);
+                    else { N.cx = S.M.ax; N.cy = S.M.ay; N.cz = S.M.az; }
+                    const unsigned long long mask = __ballot(1);
+                    const uint32_t cntd = (uint32_t)__popcll(mask);
+                    const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                    uint32_t base = 0;
+                    if (rank == 0) base = atomicAdd(A.s_counts + SC_SHADOW, cntd * A.n_lights);
+                    base = __shfl(base, __ffsll((long long)mask) - 1);
+                    if ((uint64_t)base + (uint64_t)cntd * A.n_lights > A.s_shadow_cap) {
+                        A.s_counts[SC_OVERFLOW] = 1;
+                        N.cx = N.cy = N.cz = 0;  // the frame is redone by the fallback path
+                    } else {
+                        N.kind = TN_DIFFUSE | (bitmap ? TN_BITMAP : 0u);
+                        N.a = base + rank;
+                        N.b = cntd;
+                        for (uint32_t li = 0; li < A.n_lights; li++) {
+                            Ray SR;
+                            float dist, kfac;
+                            light_setup(A, li, S.px, S.py, S.pz, S.nx, S.ny, S.nz, SR, dist, kfac);
+                            if (COUNT) { cnt[C_LIGHT]++; cnt[C_SHADOW]++; }
+                            const size_t slot = (size_t)base + (size_t)li * cntd + rank;
+                            A.s_shadowq[2 * slot] = make_float4(SR.ox, SR.oy, SR.oz, dist);
+                            A.s_shadowq[2 * slot + 1] = make_float4(SR.dx, SR.dy, SR.dz, kfac);
+                        }
+                    }
+                } else if (S.M.type == CRT_MAT_REFLECTIVE || S.M.type == CRT_MAT_REFRACTIVE) {
+                    const bool refractive = S.M.type == CRT_MAT_REFRACTIVE;
+                    float nx = S.nx, ny = S.ny, nz = S.nz;
+                    bool transmit = false;
+                    float tox = 0, toy = 0, toz = 0, tdx = 0, tdy = 0, tdz = 0;
+                    if (refractive) {
+                        // calculateRefraction (RayTracer.cpp:375-417)
+                        float eta1 = 1.0f, eta2 = S.M.ior;
+                        float idn = dot3(R.dx, R.dy, R.dz, nx, ny, nz);
+                        if (idn > 0) {
+                            const float s = eta1; eta1 = eta2; eta2 = s;
+                            nx = -1.0f * nx; ny = -1.0f * ny; nz = -1.0f * nz;
+                            idn = -idn;
+                        }
+                        const float cos_a = -idn;
+                        const float sin_a = sqrtf(std_max(0.0f, 1 - cos_a * cos_a));
+                        const float eta_ratio = eta1 / eta2;
+                        const float sin_b = eta_ratio * sin_a;
+                        if (sin_b < 1.0f) {
+                            const float q = (eta1 - eta2) / (eta1 + eta2);
+                            const float r0 = q * q;  // std::powf(q, 2), folded to q*q by the reference's compiler at -O2
+                            N.f = r0 + (1 - r0) * crt_pow5(1.0f - cos_a);
+                            const float cos_b = sqrtf(std_max(0.0f, 1 - sin_b * sin_b));
+                            tdx = eta_ratio * (R.dx + cos_a * nx) - cos_b * nx;
+                            tdy = eta_ratio * (R.dy + cos_a * ny) - cos_b * ny;
+                            tdz = eta_ratio * (R.dz + cos_a * nz) - cos_b * nz;
+                            normalize3(tdx, tdy, tdz);
+                            tox = S.px - nx * A.refraction_bias; toy = S.py - ny * A.refraction_bias; toz = S.pz - nz * A.refraction_bias;
+                            transmit = true;
+                        }
+                        N.kind = TN_REFRACT;
+                    } else {
+                        N.kind = TN_REFLECT;  // calculateReflection (RayTracer.cpp:358-374)
+                        N.cx = S.M.ax; N.cy = S.M.ay; N.cz = S.M.az;
+                    }
+                    // the reflection ray (both materials): origin + n*bias, reflect(d, n) normalised (Vector.cpp:119-122)
+                    const float k = 2 * dot3(R.dx, R.dy, R.dz, nx, ny, nz);
+                    float rdx = R.dx - k * nx, rdy = R.dy - k * ny, rdz = R.dz - k * nz;
+                    normalize3(rdx, rdy, rdz);
+                    const float rox = S.px + nx * A.reflection_bias, roy = S.py + ny * A.reflection_bias,
+                                roz = S.pz + nz * A.reflection_bias;
+                    N.a = CHILD_BG;
+                    N.b = refractive ? (transmit ? CHILD_BG : CHILD_NONE) : 0u;
+                    if (spawn_allowed) {
+                        // wave-aggregated append of 1 or 2 child rays per lane
+                        const unsigned long long m1 = __ballot(1), m2 = __ballot(transmit);
+                        const unsigned long long below = (1ull << lane) - 1ull;
+                        const uint32_t n1 = (uint32_t)__popcll(m1), n2 = (uint32_t)__popcll(m2);
+                        uint32_t base = 0;
+                        if ((m1 & below) == 0) base = atomicAdd(out_count, n1 + n2);
+                        base = __shfl(base, __ffsll((long long)m1) - 1);
+                        if ((uint64_t)base + n1 + n2 > A.s_ray_cap || (uint64_t)child_base + base + n1 + n2 > A.s_node_cap) {
+                            A.s_counts[SC_OVERFLOW] = 1;
+                        } else {
+                            const uint32_t i1 = base + (uint32_t)__popcll(m1 & below);
+                            out_q[2 * (size_t)i1] = make_float4(rox, roy, roz, 0.0f);
+                            out_q[2 * (size_t)i1 + 1] = make_float4(rdx, rdy, rdz, 0.0f);
+                            N.a = child_base + i1;
+                            if (transmit) {
+                                const uint32_t i2 = base + n1 + (uint32_t)__popcll(m2 & below);
+                                out_q[2 * (size_t)i2] = make_float4(tox, toy, toz, 0.0f);
+                                out_q[2 * (size_t)i2 + 1] = make_float4(tdx, tdy, tdz, 0.0f);
+                                N.b = child_base + i2;
+                            }
+                        }
+                    }
+                }
+                // any other material type (Constant): background, RayTracer.cpp:443-446
+            }
+            float4 *dst = A.s_nodes + 2 * ((size_t)node_base + r);
+            dst[0] = make_float4(N.cx, N.cy, N.cz, __uint_as_float(N.kind));
+            dst[1] = make_float4(__uint_as_float(N.a), __uint_as_float(N.b), N.f, 0.0f);
+            state = ST_FETCH;
+        }
+    }
+
+    if (COUNT) {
+        for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_down(max_steps, off); max_steps = o > max_steps ? o : max_steps; }
+        if (lane == 0) atomicMax(&A.counters[C_WAVE_NODES], (unsigned long long)max_steps);
+        for (int k = 0; k < C_N; k++) {
+            unsigned long long v = cnt[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+            if (lane == 0 && v) atomicAdd(&A.counters[k], v);
+        }
+    }
+}
+
+// Every shadow ray of the frame: RayTracer::hasIntersection in tree mode (RayTracer.cpp:507-517 ->
+// AccelerationStructure.cpp:56-94).  Writes 1 to s_occluded[i] when the light is blocked.
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) void stream_trace_shadow(const KernelArgs A) {
+    const uint32_t lane = threadIdx.x & 63u;
+    if (A.s_counts[SC_OVERFLOW]) return;  // the fallback path redoes the frame
+    const uint32_t total = A.s_counts[SC_SHADOW];
+    uint32_t cnt[C_N];
+    if (COUNT) for (int k = 0; k < C_N; k++) cnt[k] = 0;
+
+    Ray R;
+    LaneWalk L;
+    int state = ST_FETCH;
+    uint32_t r = 0;
+    for (;;) {
+        if (__ballot(state == ST_FETCH)) {
+            if (state == ST_FETCH) {
+                r = wave_fetch(A.s_counts + SC_SHADOW_FETCH, lane);
+                if (r >= total) state = ST_DONE;
+                else {
+                    const float4 q0 = A.s_shadowq[2 * (size_t)r], q1 = A.s_shadowq[2 * (size_t)r + 1];
+                    R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
+                    R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;  // already normalised once; shadow rays skip shootRay (RayTracer.cpp:313-317)
+                    ray_prepare(R);
+                    L.rtype = RAY_SHADOW;
+                    traversal_begin(L, A.top_root);
+                    L.light_dist = q0.w;
+                    state = ST_TRAVERSE;
+                }
+            }
+        }
+        if (!__ballot(state != ST_DONE)) break;
+        if (state == ST_TRAVERSE) {
+            int budget = 64;
+            bool finished = false;
+            do {
+                if (!traversal_step<COUNT>(L, R, A, cnt)) { finished = true; break; }
+            } while (--budget > 0);
+            if (finished) {
+                A.s_occluded[r] = L.occluded ? 1 : 0;
+                state = ST_FETCH;
+            }
+        }
+    }
+    if (COUNT) {
+        for (int k = 0; k < C_N; k++) {
+            unsigned long long v = cnt[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+            if (lane == 0 && v) atomicAdd(&A.counters[k], v);
+        }
+    }
+}
+
+// Colour of a finished leaf of the ray tree.
+template <bool COUNT>
+__device__ __forceinline__ void resolve_leaf(const KernelArgs &A, const float4 &n0, const float4 &n1, float &cx, float &cy,
+                                             float &cz, uint32_t *cnt) {
+    const uint32_t kind = __float_as_uint(n0.w);
+    if ((kind & TN_KIND_MASK) == TN_DIFFUSE) {
+        // finalColor += (intensity / area * angle) * albedo, light by light in the reference's order (RayTracer.cpp:319-329)
+        const uint32_t first = __float_as_uint(n1.x), stride = __float_as_uint(n1.y);
+        float ax = 0, ay = 0, az = 0;
+        for (uint32_t li = 0; li < A.n_lights; li++) {
+            const size_t slot = (size_t)first + (size_t)li * stride;
+            if (!A.s_occluded[slot]) {
+                const float k = A.s_shadowq[2 * slot + 1].w;
+                if (COUNT && (kind & TN_BITMAP)) cnt[C_TEXEL]++;
+                ax += k * n0.x; ay += k * n0.y; az += k * n0.z;
+            }
+        }
+        cx = ax; cy = ay; cz = az;
+    } else {
+        cx = n0.x; cy = n0.y; cz = n0.z;  // TN_CONST
+    }
+}
+
+// Per pixel: evaluate its ray tree in post-order -- reflection subtree, then refraction subtree, then the
+// parent's own expression -- exactly the order of the reference's recursion.
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) void stream_resolve(const KernelArgs A) {
+    const uint32_t lane = threadIdx.x & 63u;
+    if (A.s_counts[SC_OVERFLOW]) return;  // the fallback path redoes the frame
+    const uint32_t total = A.n_items * 64u;
+    const float4 *nodes = A.s_nodes;
+    float4 *wnodes = A.s_nodes;
+    uint32_t cnt[C_N];
+    if (COUNT) for (int k = 0; k < C_N; k++) cnt[k] = 0;
+    uint32_t stack[MAX_GENERATIONS];
+
+    for (uint32_t q = blockIdx.x * BLOCK + threadIdx.x; q < total; q += gridDim.x * BLOCK) {
+        const float4 root0 = nodes[2 * (size_t)q];
+        if ((__float_as_uint(root0.w) & TN_KIND_MASK) == TN_SKIP) continue;
+        float cx = 0, cy = 0, cz = 0;
+        int sp = 0;
+        uint32_t cur = q;
+        bool descending = true;
+        // iterative post-order: `descending` = entering node `cur`; otherwise (cx,cy,cz) is the value returned
+        // by the child just finished and stack[sp-1] is its parent.
+        for (;;) {
+            if (descending) {
+                if (cur == CHILD_BG) { cx = A.bgx; cy = A.bgy; cz = A.bgz; descending = false; }
+                else {
+                    const float4 n0 = nodes[2 * (size_t)cur], n1 = nodes[2 * (size_t)cur + 1];
+                    const uint32_t kind = __float_as_uint(n0.w) & TN_KIND_MASK;
+                    if (kind == TN_REFLECT || kind == TN_REFRACT) {
+                        stack[sp++] = cur;
+                        cur = __float_as_uint(n1.x);  // the reflection ray is shot first (RayTracer.cpp:366, 398-400)
+                    } else {
+                        resolve_leaf<COUNT>(A, n0, n1, cx, cy, cz, cnt);
+                        descending = false;
+                    }
+                }
+            }
+            if (!descending) {
+                if (sp == 0) break;
+                const uint32_t p = stack[sp - 1];
+                const float4 p0 = nodes[2 * (size_t)p], p1 = nodes[2 * (size_t)p + 1];
+                const uint32_t kind = __float_as_uint(p0.w);
+                if ((kind & TN_KIND_MASK) == TN_REFLECT) {
+                    cx = 0.0f + p0.x * cx; cy = 0.0f + p0.y * cy; cz = 0.0f + p0.z * cz;  // RayTracer.cpp:368-372
+                    sp--;
+                } else if (kind & 0x200u) {
+                    // both children done: fresnel * reflection + (1 - fresnel) * refraction (RayTracer.cpp:414)
+                    const float f = p1.z;
+                    cx = f * p0.x + (1 - f) * cx; cy = f * p0.y + (1 - f) * cy; cz = f * p0.z + (1 - f) * cz;
+                    sp--;
+                } else {
+                    const uint32_t refr = __float_as_uint(p1.y);
+                    if (refr == CHILD_NONE) { sp--; }  // `return reflectionColor`, RayTracer.cpp:416
+                    else {
+                        // park the reflection colour in the node, mark it, descend into the refraction child
+                        wnodes[2 * (size_t)p] = make_float4(cx, cy, cz, __uint_as_float(kind | 0x200u));
+                        cur = refr;
+                        descending = true;
+                    }
+                }
+            }
+        }
+        const WorkItem wi = A.items[q >> 6];
+        const uint32_t sub = q & 63u;
+        const uint32_t px = (wi.tile % A.tiles_x) * TILE + (sub & 7u), py = (wi.tile / A.tiles_x) * TILE + (sub >> 3);
+        const size_t out_off = A.packed ? ((size_t)wi.out_tile * 64 + sub) * 3 : ((size_t)py * A.width + px) * 3;
+        A.out[out_off] = cx; A.out[out_off + 1] = cy; A.out[out_off + 2] = cz;  // RayTracer.cpp:106
+    }
+    if (COUNT) {
+        for (int k = 0; k < C_N; k++) {
+            unsigned long long v = cnt[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+            if (lane == 0 && v) atomicAdd(&A.counters[k], v);
+        }
+    }
+}

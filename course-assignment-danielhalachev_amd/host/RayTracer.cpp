@@ -102,6 +102,10 @@ RayTracer::RayTracer(Scene &scene, int device) : accelerationStructure(scene), s
   flattenScene(scene, accelerationStructure, flat);
   int rc = crt_create(&flat.desc, device, &ctx);
   if (rc != CRT_OK) throw std::runtime_error(std::string("crt_create failed: ") + crt_last_error(nullptr));
+  {  // the context starts with the scene's camera, as RayTracer::RayTracer copies scene.camera (RayTracer.cpp:46)
+    const float pos[3] = {camera.getPosition().x, camera.getPosition().y, camera.getPosition().z};
+    crt_set_camera(ctx, pos, &camera.getRotationMatrix().m[0][0]);
+  }
   frame.assign((size_t)scene.sceneSettings.image.width * scene.sceneSettings.image.height * 3, 0.0f);
 }
 

@@ -176,7 +176,7 @@ extern "C" int crt_host_tracer_set_camera(crt_host_tracer *t, const float positi
   if (!t || !position || !matrix) return CRT_ERR_INVALID;
   t->tracer->setCamera().setPosition() = crt::Vector(position[0], position[1], position[2]);
   memcpy(&t->tracer->setCamera().setRotationMatrix().m[0][0], matrix, 9 * sizeof(float));
-  return CRT_OK;
+  return crt_set_camera(t->tracer->context(), position, matrix);  // also for callers of the device-level API
 }
 
 extern "C" int crt_host_tracer_render(crt_host_tracer *t, const char *ppm_path, int optimization, const crt_options *o,

@@ -49,7 +49,8 @@ enum { CRT_TEX_ALBEDO = 0, CRT_TEX_EDGES = 1, CRT_TEX_CHECKER = 2, CRT_TEX_BITMA
  *   box test passes, inner node : continue at `link`            (first child in visit order)
  *   box test passes, leaf       : process entries starting at (link & ~CRT_LINK_LEAF), then `miss`
  *   box test fails              : continue at `miss`            (skip the whole subtree)
- * CRT_LINK_END terminates the walk.  Node indices are global (top-level tree and all mesh trees
+ * CRT_LINK_END terminates the walk.  Nodes are stored in visit order: `link` and `miss` always point
+ * to a HIGHER index (crt_create rejects anything else), so a subtree is the index range [i, miss).  Node indices are global (top-level tree and all mesh trees
  * share one array). */
 typedef struct crt_node {
     float lo[3];
@@ -193,7 +194,16 @@ int crt_read_quantized(crt_ctx *ctx, uint8_t *out_rgb8);
 /* Device time of the most recent render kernel, from the HIP events recorded around it on the stream
  * it was launched on (waits for that kernel to finish). */
 int crt_kernel_elapsed_ms(crt_ctx *ctx, double *ms);
+/* Device times of the most recent renders (up to 64, oldest first), from the HIP events recorded around
+ * the kernels on the stream they were launched on; 3 doubles per render:
+ *   [0] stream_trace_shade, all recursion levels  [1] stream_trace_shadow  [2] stream_resolve (+ fallback).
+ * Waits for those kernels to finish. */
+int crt_kernel_times_ms(crt_ctx *ctx, double *out_phase_ms, uint32_t max_count, uint32_t *count);
 int crt_get_stats(crt_ctx *ctx, crt_stats *out);
+/* The counters of the last counted render split by kernel, in crt_stats order: box_tests, tri_tests,
+ * leaf_index_reads, shaded_hits, light_evals, texel_fetches, primary_rays, secondary_rays, shadow_rays.
+ * closest = stream_trace_shade (+ resolve), shadow = stream_trace_shadow. */
+int crt_get_kernel_counters(crt_ctx *ctx, uint64_t closest[9], uint64_t shadow[9]);
 int crt_synchronize(crt_ctx *ctx);
 void crt_destroy(crt_ctx *ctx);
 /* last error text of a context (or of the last failed crt_create when ctx == NULL) */
