@@ -363,11 +363,12 @@ class Tracer:
         return ms.value
 
     def kernel_times_ms(self, max_count=64):
-        """[(closest-hit levels ms, shadow ms, resolve ms)] of the most recent renders, oldest first."""
-        a = (C.c_double * (3 * max_count))()
+        """[(total, recursion levels, shadow pass 0 [overlapped], shadow pass 1 + heavy, resolve)] in ms of the
+        most recent renders, oldest first."""
+        a = (C.c_double * (5 * max_count))()
         n = C.c_uint32()
         self._check(lib().crt_kernel_times_ms(self.ctx, a, max_count, C.byref(n)))
-        return [(a[3 * i], a[3 * i + 1], a[3 * i + 2]) for i in range(n.value)]
+        return [tuple(a[5 * i + j] for j in range(5)) for i in range(n.value)]
 
     def read_quantized(self):
         out = np.zeros((self.height, self.width, 3), dtype=np.uint8)

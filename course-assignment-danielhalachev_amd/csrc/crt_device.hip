@@ -19,6 +19,7 @@
 //    the x86-64 reference build.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -37,6 +38,7 @@ namespace {
 #include "kernel_packet.h"
 #include "kernel_lane.h"
 #include "kernel_stream.h"
+#include "kernel_heavy.h"
 
 // scatter gathered packed tiles into the row-major frame
 __global__ void unpack_kernel(const float *packed, uint32_t n_parts, uint64_t part_stride, float *frame, uint32_t width,
@@ -94,6 +96,20 @@ struct crt_ctx {
     float4 *d_nodes = nullptr;
     uint32_t *d_scounts = nullptr;
     uint32_t *h_overflow = nullptr;   // pinned copy of the stream pass's overflow word
+    uint32_t *d_heavy = nullptr;      // evicted ray ids
+    uint32_t *d_sheavy = nullptr;     // evicted shadow ray ids
+    uint32_t *d_todo_tiles = nullptr, *d_todo_shadow = nullptr;  // what stream_packets_gen0 gave up on
+    uint32_t packet_budget = 0;       // CRT_PACKET_BUDGET: level 0 by packets, a walk abandoned after this many wave-level visits (0 = off, default: measured slower overall)
+    hipStream_t side = nullptr;       // shadow pass 0 overlaps the deeper recursion levels on this stream
+    hipEvent_t ev_fork[EV_RING] = {}, ev_s0[EV_RING] = {}, ev_s1[EV_RING] = {}, ev4[EV_RING] = {};
+    float4 *d_hits = nullptr;         // their closest hits
+    uint32_t heavy_cap = 0;
+    uint32_t step_budget = 1024;      // CRT_STEP_BUDGET: closest-hit walks are evicted to heavy_trace after this many steps (0 = never)
+    uint32_t shadow_budget = 4096;    // CRT_SHADOW_BUDGET: same for shadow walks (one big launch: only its tail matters)
+    uint32_t heavy_level_threshold = 0;  // CRT_HEAVY_LEVEL: levels with fewer rays go to heavy_trace whole
+    bool lean_ok = true;              // 32-bit byte offsets reach every node and leaf entry
+    uint32_t side_blocks_per_cu = 4;  // CRT_SIDE_BLOCKS: blocks per CU of the overlapped shadow pass
+    uint32_t debug_skip = 0;          // CRT_DEBUG_SKIP: development only, skips heavy-path launches
     uint64_t stream_items = 0;        // work items the stream buffers are sized for
     uint64_t overflows = 0;           // frames redone by the fallback (diagnostic)
     uint32_t n_lights = 0;
@@ -230,11 +246,16 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
     CK(hipGetDeviceProperties(&prop, device));
     ctx->num_cus = prop.multiProcessorCount;
     CK(hipStreamCreate(&ctx->stream));
+    CK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
     for (int i = 0; i < crt_ctx::EV_RING; i++) {
         CK(hipEventCreate(&ctx->ev0[i]));
         CK(hipEventCreate(&ctx->ev1[i]));
         CK(hipEventCreate(&ctx->ev2[i]));
         CK(hipEventCreate(&ctx->ev3[i]));
+        CK(hipEventCreate(&ctx->ev4[i]));
+        CK(hipEventCreate(&ctx->ev_fork[i]));
+        CK(hipEventCreate(&ctx->ev_s0[i]));
+        CK(hipEventCreate(&ctx->ev_s1[i]));
     }
 
     ctx->width = s->width;
@@ -247,6 +268,83 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
     if (upload(ctx, s->leaf_triangles, (size_t)s->n_leaf_triangles, &A.leaf_tris)) return fail(CRT_ERR_HIP);
     if (upload(ctx, s->leaf_meshes, (size_t)s->n_leaf_meshes, &A.leaf_meshes)) return fail(CRT_ERR_HIP);
     if (upload(ctx, (const float4 *)s->triangles, (size_t)s->n_triangles * 4, &A.tris)) return fail(CRT_ERR_HIP);
+    {
+        // leaf-order triangle records: what a walk reads inside a leaf, without the index indirection
+        std::vector<float4> lt((size_t)s->n_leaf_triangles * 4);
+        for (uint64_t e = 0; e < s->n_leaf_triangles; e++) {
+            const uint32_t ent = s->leaf_triangles[e], tri = ent & ~CRT_ENTRY_LAST;
+            const crt_triangle &T = s->triangles[tri];
+            lt[4 * e + 0] = make_float4(T.v0[0], T.v0[1], T.v0[2], T.nx);
+            lt[4 * e + 1] = make_float4(T.v1[0], T.v1[1], T.v1[2], T.ny);
+            lt[4 * e + 2] = make_float4(T.v2[0], T.v2[1], T.v2[2], T.nz);
+            float idbits, lastbits;
+            const uint32_t last = (ent & CRT_ENTRY_LAST) ? 1u : 0u;
+            memcpy(&idbits, &tri, 4);
+            memcpy(&lastbits, &last, 4);
+            lt[4 * e + 3] = make_float4(T.plane, idbits, lastbits, 0.0f);
+        }
+        if (upload(ctx, lt.data(), lt.size(), &A.ltris)) return fail(CRT_ERR_HIP);
+    }
+    {
+        // Leaf sequence of every mesh tree (kernel_heavy.h): the leaves' own boxes in visit order, then union
+        // boxes of 64 entries per level until at most 64 remain.  With forward links the nodes of a mesh tree
+        // are the index range [root, next tree's root), already in visit order.
+        std::vector<uint32_t> roots;
+        roots.push_back(s->top_root);
+        for (uint32_t m = 0; m < s->n_meshes; m++) roots.push_back(s->meshes[m].root);
+        std::sort(roots.begin(), roots.end());
+        std::vector<float4> hbox;
+        std::vector<HeavyMesh> hm(s->n_meshes);
+        for (uint32_t m = 0; m < s->n_meshes; m++) {
+            HeavyMesh &H = hm[m];
+            memset(&H, 0, sizeof(H));
+            const uint32_t root = s->meshes[m].root;
+            auto it = std::upper_bound(roots.begin(), roots.end(), root);
+            const uint32_t end = it == roots.end() ? s->n_nodes : *it;
+            std::vector<float4> level;  // 2 x float4 per entry
+            for (uint32_t i = root; i < end; i++) {
+                const crt_node &n = s->nodes[i];
+                if (!(n.link & CRT_LINK_LEAF)) continue;
+                const uint32_t begin = n.link & ~CRT_LINK_LEAF;
+                uint32_t count = 0;
+                if (begin < s->n_leaf_triangles) {
+                    uint64_t e = begin;
+                    do { count++; } while (!(s->leaf_triangles[e++] & CRT_ENTRY_LAST) && e < s->n_leaf_triangles);
+                }
+                float bb, cb;
+                memcpy(&bb, &begin, 4);
+                memcpy(&cb, &count, 4);
+                level.push_back(make_float4(n.lo[0], n.lo[1], n.lo[2], bb));
+                level.push_back(make_float4(n.hi[0], n.hi[1], n.hi[2], cb));
+            }
+            uint32_t nl = 0;
+            while (!level.empty() && nl < 4) {
+                const uint32_t cnt = (uint32_t)(level.size() / 2);
+                H.first[nl] = (uint32_t)(hbox.size() / 2);
+                H.count[nl] = cnt;
+                hbox.insert(hbox.end(), level.begin(), level.end());
+                nl++;
+                if (cnt <= 64) break;
+                std::vector<float4> up;
+                for (uint32_t g = 0; g < cnt; g += 64) {
+                    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+                    for (uint32_t k = g; k < cnt && k < g + 64; k++) {
+                        const float4 &a = level[2 * k], &b = level[2 * k + 1];
+                        lo[0] = a.x < lo[0] ? a.x : lo[0]; lo[1] = a.y < lo[1] ? a.y : lo[1]; lo[2] = a.z < lo[2] ? a.z : lo[2];
+                        hi[0] = b.x > hi[0] ? b.x : hi[0]; hi[1] = b.y > hi[1] ? b.y : hi[1]; hi[2] = b.z > hi[2] ? b.z : hi[2];
+                    }
+                    up.push_back(make_float4(lo[0], lo[1], lo[2], 0.0f));
+                    up.push_back(make_float4(hi[0], hi[1], hi[2], 0.0f));
+                }
+                level.swap(up);
+            }
+            // more than 64^4 leaves: leave n_levels = 0 for this mesh -> the heavy path is switched off below
+            H.n_levels = (!level.empty() && H.count[nl ? nl - 1 : 0] <= 64) ? nl : 0;
+            if (H.n_levels == 0 && !level.empty()) ctx->step_budget = 0;
+        }
+        if (upload(ctx, hbox.data(), hbox.size(), &A.hbox)) return fail(CRT_ERR_HIP);
+        if (upload(ctx, hm.data(), hm.size(), &A.hmesh)) return fail(CRT_ERR_HIP);
+    }
     if (upload(ctx, s->triangle_vertices, (size_t)s->n_triangles * 3, &A.tri_verts)) return fail(CRT_ERR_HIP);
     if (upload(ctx, s->vertex_normals, (size_t)s->n_vertices * 3, &A.vnormals)) return fail(CRT_ERR_HIP);
     if (s->vertex_uvs) {
@@ -317,12 +415,27 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
         else if (m && !strcmp(m, "lanes")) ctx->mode = crt_ctx::MODE_LANES;
         else ctx->mode = crt_ctx::MODE_STREAM;
     }
-    CK(hipMalloc((void **)&ctx->d_scounts, SC_WORDS * sizeof(uint32_t)));
-    CK(hipMemset(ctx->d_scounts, 0, SC_WORDS * sizeof(uint32_t)));
+    {
+        const char *ds = getenv("CRT_DEBUG_SKIP");
+        if (ds) ctx->debug_skip = (uint32_t)strtoul(ds, nullptr, 10);
+        const char *b = getenv("CRT_STEP_BUDGET");
+        if (b && ctx->step_budget) ctx->step_budget = (uint32_t)strtoul(b, nullptr, 10);
+        const char *pb = getenv("CRT_PACKET_BUDGET");
+        if (pb) ctx->packet_budget = (uint32_t)strtoul(pb, nullptr, 10);
+        const char *hl = getenv("CRT_HEAVY_LEVEL");
+        if (hl) ctx->heavy_level_threshold = (uint32_t)strtoul(hl, nullptr, 10);
+        ctx->lean_ok = s->n_nodes < (1u << 27) && s->n_leaf_triangles < (1ull << 26);
+        const char *sbl = getenv("CRT_SIDE_BLOCKS");
+        if (sbl) ctx->side_blocks_per_cu = (uint32_t)strtoul(sbl, nullptr, 10);
+        const char *sb = getenv("CRT_SHADOW_BUDGET");
+        if (sb) ctx->shadow_budget = (uint32_t)strtoul(sb, nullptr, 10);
+    }
+    CK(hipMalloc((void **)&ctx->d_scounts, 512 * sizeof(uint32_t)));
+    CK(hipMemset(ctx->d_scounts, 0, 512 * sizeof(uint32_t)));
     CK(hipHostMalloc((void **)&ctx->h_overflow, sizeof(uint32_t)));
     *ctx->h_overflow = 0;
     ctx->n_lights = s->n_lights;
-    CK(hipMalloc((void **)&ctx->d_counters, 2 * C_N * sizeof(unsigned long long)));  // [packets | lanes]
+    CK(hipMalloc((void **)&ctx->d_counters, 3 * C_N * sizeof(unsigned long long)));  // [levels | shadow pass 0 | the rest]
     // persistent grid: 8 blocks of 256 threads per CU gives every CU its 32 waves if registers allow
     ctx->grid_blocks = (uint32_t)ctx->num_cus * 8u;
 #undef CK
@@ -344,6 +457,11 @@ extern "C" void crt_destroy(crt_ctx *ctx) {
     if (ctx->d_occluded) (void)hipFree(ctx->d_occluded);
     if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
     if (ctx->d_scounts) (void)hipFree(ctx->d_scounts);
+    if (ctx->d_heavy) (void)hipFree(ctx->d_heavy);
+    if (ctx->d_sheavy) (void)hipFree(ctx->d_sheavy);
+    if (ctx->d_todo_tiles) (void)hipFree(ctx->d_todo_tiles);
+    if (ctx->d_todo_shadow) (void)hipFree(ctx->d_todo_shadow);
+    if (ctx->d_hits) (void)hipFree(ctx->d_hits);
     if (ctx->h_overflow) (void)hipHostFree(ctx->h_overflow);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_frames) (void)hipFree(ctx->d_frames);
@@ -352,8 +470,13 @@ extern "C" void crt_destroy(crt_ctx *ctx) {
         if (ctx->ev1[i]) (void)hipEventDestroy(ctx->ev1[i]);
         if (ctx->ev2[i]) (void)hipEventDestroy(ctx->ev2[i]);
         if (ctx->ev3[i]) (void)hipEventDestroy(ctx->ev3[i]);
+        if (ctx->ev4[i]) (void)hipEventDestroy(ctx->ev4[i]);
+        if (ctx->ev_fork[i]) (void)hipEventDestroy(ctx->ev_fork[i]);
+        if (ctx->ev_s0[i]) (void)hipEventDestroy(ctx->ev_s0[i]);
+        if (ctx->ev_s1[i]) (void)hipEventDestroy(ctx->ev_s1[i]);
     }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
     delete ctx;
 }
 
@@ -429,11 +552,25 @@ static int ensure_stream(crt_ctx *ctx, uint32_t n_items) {
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_shadowq, shadow_cap * 2 * sizeof(float4)));
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_occluded, shadow_cap));
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_nodes, node_cap * 2 * sizeof(float4)));
+        if (ctx->d_heavy) (void)hipFree(ctx->d_heavy);
+        if (ctx->d_sheavy) (void)hipFree(ctx->d_sheavy);
+        if (ctx->d_hits) (void)hipFree(ctx->d_hits);
+        if (ctx->d_todo_tiles) (void)hipFree(ctx->d_todo_tiles);
+        if (ctx->d_todo_shadow) (void)hipFree(ctx->d_todo_shadow);
+        ctx->d_heavy = nullptr; ctx->d_sheavy = nullptr; ctx->d_hits = nullptr; ctx->d_todo_tiles = nullptr; ctx->d_todo_shadow = nullptr;
+        CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_todo_tiles, ((size_t)n_items + 1) * sizeof(uint32_t)));
+        CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_todo_shadow, (size_t)shadow_cap * sizeof(uint32_t)));
+        ctx->heavy_cap = (uint32_t)(px < (1u << 20) ? (1u << 20) : px);
+        CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_heavy, (size_t)ctx->heavy_cap * sizeof(uint32_t)));
+        CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_sheavy, (size_t)ctx->heavy_cap * sizeof(uint32_t)));
+        CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_hits, (size_t)ctx->heavy_cap * sizeof(float4)));
         A.s_ray_cap = (uint32_t)ray_cap; A.s_shadow_cap = (uint32_t)shadow_cap; A.s_node_cap = (uint32_t)node_cap;
         ctx->stream_items = n_items;
     }
     A.s_rayq[0] = ctx->d_rayq[0]; A.s_rayq[1] = ctx->d_rayq[1];
     A.s_shadowq = ctx->d_shadowq; A.s_occluded = ctx->d_occluded; A.s_nodes = ctx->d_nodes;
+    A.s_heavy = ctx->d_heavy; A.s_sheavy = ctx->d_sheavy; A.s_hits = ctx->d_hits; A.s_heavy_cap = ctx->heavy_cap;
+    A.s_todo_tiles = ctx->d_todo_tiles; A.s_todo_shadow = ctx->d_todo_shadow;
     return CRT_OK;
 }
 
@@ -467,9 +604,11 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
     A.s_counts = ctx->d_scounts;
     A.only_if_overflow = 0;
     A.use_deferred = 0;
+    A.packet_budget = ctx->packet_budget;
+    A.use_packets = 0;
     const bool count = o->collect_counters != 0;
     CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_sync, 0, 4 * sizeof(uint32_t), stream));
-    if (count) CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_counters, 0, 2 * C_N * sizeof(unsigned long long), stream));
+    if (count) CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_counters, 0, 3 * C_N * sizeof(unsigned long long), stream));
     if (n_items == 0) return CRT_OK;
     const int slot = (int)(ctx->launches % crt_ctx::EV_RING);
     const uint32_t lane_need = (n_items * 64u + BLOCK - 1) / BLOCK;
@@ -480,18 +619,66 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         if (rc) return rc;
         CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_scounts, 0, SC_WORDS * sizeof(uint32_t), stream));
         // 1) closest-hit walks + material dispatch, one launch per recursion level
+        // the wave-per-ray path needs nested boxes; the counting build walks every ray the reference's way
+        const bool heavy = ctx->step_budget && A.nested_boxes && !count;
+        A.step_budget = heavy ? ctx->step_budget : 0u;
+        A.debug = ctx->debug_skip;
+        A.heavy_level_threshold = ctx->heavy_level_threshold;
+        const bool lean = heavy && ctx->lean_ok && !(ctx->debug_skip & 256u);
+        const uint32_t heavy_blocks = ctx->grid_blocks < 1024u ? ctx->grid_blocks : 1024u;
+        const bool packets = lean && ctx->packet_budget != 0 && !(ctx->debug_skip & 512u);
+        if (packets) {
+            // 0) recursion level 0 for every tile whose rays stay coherent: packets, scalar-load path
+            A.use_packets = 1;
+            const uint32_t need = (n_items + BLOCK / 64 - 1) / (BLOCK / 64);
+            launch(stream_packets_gen0, need < ctx->grid_blocks ? need : ctx->grid_blocks, stream, A);
+            hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, stream, A);
+        }
+        KernelArgs S = A;  // argument block of the shadow passes
+        S.counters = ctx->d_counters + C_N;
+        S.step_budget = heavy ? ctx->shadow_budget : 0u;
         for (uint32_t g = 0; g <= o->max_depth; g++) {
             if (count) launch(stream_trace_shade<true>, lane_blocks, stream, A, g);
+            else if (lean) launch(stream_trace_shade_lean, lane_blocks, stream, A, g);
             else launch(stream_trace_shade<false>, lane_blocks, stream, A, g);
+            if (heavy) {
+                if (!(ctx->debug_skip & 1u)) launch(heavy_trace_closest, heavy_blocks, stream, A, g);
+                if (!(ctx->debug_skip & 2u)) launch(stream_shade_evicted<false>, 256u, stream, A, g);
+            }
+            if (g == 0 && !packets) hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, stream, A);
+            if (g == 0 && ctx->side_blocks_per_cu) {
+                // 2a) the shadow rays level 0 queued (the bulk of them) start now, beside the deeper levels
+                CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork[slot], stream));
+                CRT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork[slot], 0));
+                CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s0[slot], ctx->side));
+                // its persistent waves must leave wave slots on every CU for the level kernels running beside it
+                const uint32_t side_blocks = (uint32_t)ctx->num_cus * ctx->side_blocks_per_cu;
+                if (count) launch(stream_trace_shadow<true>, side_blocks, ctx->side, S, 0u);
+                else if (lean) launch(stream_trace_shadow_lean<0>, side_blocks, ctx->side, S);
+                else launch(stream_trace_shadow<false>, side_blocks, ctx->side, S, 0u);
+                CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s1[slot], ctx->side));
+            }
         }
         CRT_HIP_CHECK(ctx, hipGetLastError());
         if (timed) CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev1[slot], stream));
-        // 2) every shadow ray of the frame
-        A.counters = ctx->d_counters + C_N;
-        if (count) launch(stream_trace_shadow<true>, ctx->grid_blocks, stream, A);
-        else launch(stream_trace_shadow<false>, ctx->grid_blocks, stream, A);
+        if (!ctx->side_blocks_per_cu) {  // no overlap: pass 0 here, on the caller's stream
+            CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s0[slot], stream));
+            if (count) launch(stream_trace_shadow<true>, ctx->grid_blocks, stream, S, 0u);
+            else if (lean) launch(stream_trace_shadow_lean<0>, ctx->grid_blocks, stream, S);
+            else launch(stream_trace_shadow<false>, ctx->grid_blocks, stream, S, 0u);
+            CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s1[slot], stream));
+        }
+        // 2b) the shadow rays of the deeper levels, then the evicted shadow walks of both passes
+        CRT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_s1[slot], 0));
+        S.counters = ctx->d_counters + 2 * C_N;
+        S.step_budget = heavy ? ctx->step_budget : 0u;  // few rays: all tail, so the short budget of the levels
+        if (count) launch(stream_trace_shadow<true>, lane_blocks, stream, S, 1u);
+        else if (lean) launch(stream_trace_shadow_lean<1>, lane_blocks, stream, S);
+        else launch(stream_trace_shadow<false>, lane_blocks, stream, S, 1u);
+        if (heavy && !(ctx->debug_skip & 4u)) launch(heavy_trace_shadow, heavy_blocks, stream, S);
         CRT_HIP_CHECK(ctx, hipGetLastError());
         if (timed) CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev2[slot], stream));
+        A.counters = ctx->d_counters + 2 * C_N;
         // 3) post-order combination per pixel, then the queue-less fallback, which only runs after an overflow
         if (count) launch(stream_resolve<true>, lane_blocks, stream, A);
         else launch(stream_resolve<false>, lane_blocks, stream, A);
@@ -500,6 +687,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         else launch(render_lanes<false>, lane_blocks, stream, A);
         CRT_HIP_CHECK(ctx, hipGetLastError());
         CRT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_overflow, ctx->d_scounts + SC_OVERFLOW, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        if (timed) CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev3[slot], stream));
     } else {
         if (ctx->mode == crt_ctx::MODE_PACKETS) {
             // coherent work: one wave per 8x8 tile; what it defers goes to the lane kernel
@@ -515,10 +703,15 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         if (count) launch(render_lanes<true>, lane_blocks, stream, A);
         else launch(render_lanes<false>, lane_blocks, stream, A);
         CRT_HIP_CHECK(ctx, hipGetLastError());
-        if (timed) CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev2[slot], stream));
+        if (timed) {
+            CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev2[slot], stream));
+            CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev3[slot], stream));
+            CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s0[slot], stream));
+            CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s1[slot], stream));
+        }
     }
     if (timed) {
-        CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev3[slot], stream));
+        CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev4[slot], stream));
         ctx->launches++;
     }
     return CRT_OK;
@@ -528,10 +721,10 @@ static int fetch_counters(crt_ctx *ctx, const crt_options *o, uint64_t pixels) {
     ctx->stats.pixels = pixels;
     ctx->stats.counters_valid = o->collect_counters ? 1 : 0;
     if (o->collect_counters) {
-        unsigned long long c2[2 * C_N], c[C_N];
+        unsigned long long c2[3 * C_N], c[C_N];
         CRT_HIP_CHECK(ctx, hipMemcpy(c2, ctx->d_counters, sizeof(c2), hipMemcpyDeviceToHost));
         for (int k = 0; k < C_N; k++) {
-            c[k] = c2[k] + c2[C_N + k];
+            c[k] = c2[k] + c2[C_N + k] + c2[2 * C_N + k];
             ctx->packet_counters[k] = c2[k];
             ctx->lane_counters[k] = c2[C_N + k];
         }
@@ -597,7 +790,7 @@ extern "C" int crt_render(crt_ctx *ctx, const crt_options *o, const crt_rect *re
     float ms = 0;
     if (ctx->cached_n_items) {
         const int slot = (int)((ctx->launches - 1) % crt_ctx::EV_RING);
-        CRT_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev0[slot], ctx->ev3[slot]));
+        CRT_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev0[slot], ctx->ev4[slot]));
         ctx->stats.kernel_ms = ms;
     } else ctx->stats.kernel_ms = 0;
     CRT_HIP_CHECK(ctx, hipEventElapsedTime(&ms, t0, t1));
@@ -692,9 +885,9 @@ extern "C" int crt_kernel_elapsed_ms(crt_ctx *ctx, double *ms) {
     CRT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (ctx->launches == 0) { ctx->error = "no render kernel has been launched"; return CRT_ERR_INVALID; }
     const int slot = (int)((ctx->launches - 1) % crt_ctx::EV_RING);
-    CRT_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev3[slot]));
+    CRT_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev4[slot]));
     float f = 0;
-    CRT_HIP_CHECK(ctx, hipEventElapsedTime(&f, ctx->ev0[slot], ctx->ev3[slot]));
+    CRT_HIP_CHECK(ctx, hipEventElapsedTime(&f, ctx->ev0[slot], ctx->ev4[slot]));
     *ms = f;
     ctx->stats.kernel_ms = f;
     return CRT_OK;
@@ -707,12 +900,17 @@ extern "C" int crt_kernel_times_ms(crt_ctx *ctx, double *out_phase_ms, uint32_t 
     if (n > max_count) n = max_count;
     for (uint64_t i = 0; i < n; i++) {  // oldest first
         const int slot = (int)((ctx->launches - n + i) % crt_ctx::EV_RING);
-        CRT_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev3[slot]));
-        float a = 0, b = 0, c = 0;
+        CRT_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev4[slot]));
+        float t = 0, a = 0, b = 0, c = 0, e = 0;
+        CRT_HIP_CHECK(ctx, hipEventElapsedTime(&t, ctx->ev0[slot], ctx->ev4[slot]));
         CRT_HIP_CHECK(ctx, hipEventElapsedTime(&a, ctx->ev0[slot], ctx->ev1[slot]));
-        CRT_HIP_CHECK(ctx, hipEventElapsedTime(&b, ctx->ev1[slot], ctx->ev2[slot]));
-        CRT_HIP_CHECK(ctx, hipEventElapsedTime(&c, ctx->ev2[slot], ctx->ev3[slot]));
-        if (out_phase_ms) { out_phase_ms[3 * i] = a; out_phase_ms[3 * i + 1] = b; out_phase_ms[3 * i + 2] = c; }
+        CRT_HIP_CHECK(ctx, hipEventElapsedTime(&b, ctx->ev_s0[slot], ctx->ev_s1[slot]));
+        CRT_HIP_CHECK(ctx, hipEventElapsedTime(&c, ctx->ev1[slot], ctx->ev2[slot]));
+        CRT_HIP_CHECK(ctx, hipEventElapsedTime(&e, ctx->ev2[slot], ctx->ev3[slot]));
+        if (out_phase_ms) {
+            out_phase_ms[5 * i] = t; out_phase_ms[5 * i + 1] = a; out_phase_ms[5 * i + 2] = b;
+            out_phase_ms[5 * i + 3] = c; out_phase_ms[5 * i + 4] = e;
+        }
     }
     *count = (uint32_t)n;
     if (*ctx->h_overflow) { ctx->overflows++; }
@@ -722,6 +920,16 @@ extern "C" int crt_kernel_times_ms(crt_ctx *ctx, double *out_phase_ms, uint32_t 
 extern "C" int crt_get_kernel_counters(crt_ctx *ctx, uint64_t packets[9], uint64_t lanes[9]) {
     if (!ctx || !packets || !lanes) return CRT_ERR_INVALID;
     for (int k = 0; k < C_PUBLIC; k++) { packets[k] = ctx->packet_counters[k]; lanes[k] = ctx->lane_counters[k]; }
+    return CRT_OK;
+}
+
+// diagnostics: the ray-stream pass's counters of the last frame (SC_* layout of kernel_stream.h)
+extern "C" int crt_debug_stream_counts(crt_ctx *ctx, uint32_t *out, uint32_t max_words) {
+    if (!ctx || !out) return CRT_ERR_INVALID;
+    CRT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    CRT_HIP_CHECK(ctx, hipDeviceSynchronize());
+    const uint32_t n = max_words < 512u ? max_words : 512u;
+    CRT_HIP_CHECK(ctx, hipMemcpy(out, ctx->d_scounts, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return CRT_OK;
 }
 

@@ -17,7 +17,7 @@ enum : int { FR_REFLECT = 0, FR_REFRACT_WAIT_REFLECTION = 1, FR_REFRACT_WAIT_REF
 enum : int { C_BOX = 0, C_TRI, C_LEAFIDX, C_HIT, C_LIGHT, C_TEXEL, C_PRIMARY, C_SECONDARY, C_SHADOW,
               C_WAVE_NODES, C_WAVE_TRIS, C_WAVE_WALKS, C_N };  // the last three: packet-kernel diagnostics (wave-level visits)
 constexpr int C_PUBLIC = 9;
-constexpr int SC_OVERFLOW_WORD = 2 * 64 + 2;  // == SC_OVERFLOW of kernel_stream.h (static_assert there)
+constexpr int SC_OVERFLOW_WORD = 5 * 64 + 2;  // == SC_OVERFLOW of kernel_stream.h (static_assert there)
 
 struct DMaterial { float ax, ay, az, ior; uint32_t type, smooth; int32_t texture; uint32_t pad; };
 struct DTexture { uint32_t kind; float ax, ay, az, bx, by, bz, scalar; uint32_t w, h; uint64_t offset; };
@@ -25,11 +25,20 @@ struct DTexture { uint32_t kind; float ax, ay, az, bx, by, bz, scalar; uint32_t 
 // Work item: one 8x8 tile, the lanes (pixels) of it that are to be rendered, and where its pixels go.
 struct WorkItem { uint32_t tile; uint32_t out_tile; uint64_t mask; };
 
+// Leaf sequence of one mesh tree for the wave-per-ray walk: level 0 = the leaves' own boxes in visit
+// order, level k = union boxes of 64 consecutive entries of level k-1; the top level has <= 64 entries.
+struct HeavyMesh {
+    uint32_t n_levels;            // 0: the mesh has no leaves
+    uint32_t first[4];            // first entry of each level in KernelArgs::hbox
+    uint32_t count[4];            // entries per level
+};
+
 struct KernelArgs {
     const float4 *nodes;          // 2 x float4 per crt_node
     const uint32_t *leaf_tris;
     const uint32_t *leaf_meshes;
     const float4 *tris;           // 4 x float4 per crt_triangle
+    const float4 *ltris;          // leaf-order copies: entry e of leaf_tris as {v0,nx} {v1,ny} {v2,nz} {plane, triangle id, last flag, -}
     const uint32_t *tri_verts;    // 3 per triangle
     const float *vnormals;        // 3 per vertex
     const float *vuvs;            // 3 per vertex (or null)
@@ -68,6 +77,20 @@ struct KernelArgs {
     uint32_t *s_counts;           // SC_WORDS counters / cursors, zeroed before every frame
     uint32_t s_ray_cap, s_shadow_cap, s_node_cap;
     uint32_t only_if_overflow;    // lane kernel: run only when the stream pass overflowed its queues
+    // heavy-ray path (kernel_heavy.h): leaf boxes in visit order + 64-ary group boxes above them
+    const float4 *hbox;           // 2 x float4 per entry: {lo, begin|-} {hi, count|-}
+    const HeavyMesh *hmesh;       // per mesh
+    uint32_t *s_heavy;            // evicted ray ids of the current recursion level
+    uint32_t *s_sheavy;           // evicted shadow ray ids (same capacity)
+    uint32_t s_heavy_cap;
+    float4 *s_hits;               // closest-hit records of evicted rays: {t, triangle, mesh, have}
+    uint32_t step_budget;         // a lane's walk is evicted after this many steps (0 = never)
+    uint32_t heavy_level_threshold; // a recursion level with fewer rays than this goes to heavy_trace whole
+    uint32_t packet_budget;       // packet kernel: a tile's walk is abandoned after this many wave-level visits (0 = never)
+    uint32_t use_packets;         // recursion level 0 ran as stream_packets_gen0: the per-lane kernels take its leftovers
+    uint32_t *s_todo_tiles;       // work items whose primary packet walk was abandoned
+    uint32_t *s_todo_shadow;      // shadow-queue slots whose packet walk was abandoned
+    uint32_t debug;               // development switches
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,238 @@
+// kernel_heavy.h -- heavy_trace: ONE ray per wavefront, 64 boxes / 64 triangles per instruction.
+//
+// A per-lane walk is a chain of dependent loads; a ray that crosses thousands of leaves holds its whole
+// launch hostage (measured: 8,500 steps, 6 ms, on the benchmark frame).  The per-lane kernels therefore stop
+// a walk after `step_budget` steps and queue the ray here, where the wave walks the tree for that single ray:
+//
+//  * Within one of the reference's trees a child box is its parent's box with one face moved inwards
+//    (BoundingBox.h:60-69) and the slab test (BoundingBox.h:85-108) is monotone under rounding, so a ray
+//    that passes a leaf's box passes every ancestor's: "the reference visits this leaf" == "the leaf's own
+//    box passes the test".  (crt_create verifies the nesting; without it this kernel is not used.)
+//  * So the walk can run over the LEAF SEQUENCE (leaves in the reference's visit order): 64 consecutive leaf
+//    boxes are tested by the 64 lanes at once with the reference's exact arithmetic; above them sit union
+//    boxes of 64 entries each (a ray that passes a box passes any box containing it, by the same
+//    monotonicity), which only skip leaves that would fail anyway.
+//  * The triangles of a passing leaf are tested one per lane; the winner is chosen with the reference's
+//    rule -- first collected hit, replaced only by a strictly smaller distance, in list order
+//    (KDTree.cpp:75-86) -- by a wave reduction keyed on (distance, position in the list).
+#pragma once
+
+#include "kernel_common.h"
+#include "kernel_stream.h"
+
+struct HeavyState {   // all wave-uniform
+    bool mhave;
+    float mmin, mt;
+    uint32_t mtri;
+    uint32_t guard;   // remaining loop iterations for this ray: every loop of the walk is bounded by it
+};
+
+__device__ __forceinline__ float wave_min(float v) {
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_prefix_exclusive(uint32_t v, uint32_t lane, uint32_t &total) {
+    uint32_t incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off);
+        if (lane >= (uint32_t)off) incl += o;
+    }
+    total = __shfl(incl, 63);
+    return incl - v;
+}
+
+// One batch of up to 64 triangles (lane j tests list entry e when `valid`), lanes in list order.
+__device__ __forceinline__ void heavy_batch(const KernelArgs &A, const Ray &R, const bool primary, const bool valid,
+                                            const size_t e, HeavyState &H) {
+    const float4 a = A.ltris[4 * e + 0], b = A.ltris[4 * e + 1], c = A.ltris[4 * e + 2], d = A.ltris[4 * e + 3];
+    float t = 0;
+    const bool acc = valid && triangle_test(R, primary, a, b, c, d.x, t);
+    const unsigned long long am = __ballot(acc);
+    if (!am) return;
+    if (!H.mhave) {  // `closest = intersections[0]`: the first accepted hit in list order, whatever its distance
+        const int first = __ffsll((long long)am) - 1;
+        H.mhave = true;
+        H.mt = __shfl(t, first);
+        H.mtri = __shfl(__float_as_uint(d.y), first);
+    }
+    const float key = (acc && t < INFINITY) ? t : INFINITY;  // +inf / NaN distances never win `d < min`
+    const float mn = wave_min(key);
+    if (mn < H.mmin) {  // strictly smaller than everything collected before; ties inside the batch: earliest
+        const unsigned long long wm = __ballot(acc && key == mn);
+        const int w = __ffsll((long long)wm) - 1;
+        H.mmin = mn;
+        H.mt = __shfl(t, w);
+        H.mtri = __shfl(__float_as_uint(d.y), w);
+    }
+}
+
+// The triangles of all leaves of one 64-leaf chunk whose box the ray passes (`hit` lanes: leaf = lane,
+// list [begin, begin+count)), concatenated in leaf order and tested 64 at a time.
+__device__ __forceinline__ void heavy_leaves(const KernelArgs &A, const Ray &R, const bool primary, const bool hit,
+                                             const uint32_t begin, const uint32_t count, HeavyState &H, const uint32_t lane) {
+    uint32_t total = 0;
+    const uint32_t prefix = wave_prefix_exclusive(hit ? count : 0u, lane, total);
+    const unsigned long long hm = __ballot(hit);
+    for (uint32_t base = 0; base < total && H.guard; base += 64) {
+        H.guard--;
+        const uint32_t j = base + lane;  // position in the concatenated list
+        uint32_t e = 0;
+        bool valid = false;
+        unsigned long long m = hm;
+        while (m) {  // a handful of leaves: find the one whose range holds j
+            const int k = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const uint32_t p = __shfl(prefix, k), cnt = __shfl(count, k), bg = __shfl(begin, k);
+            if (j >= p && j < p + cnt) { e = bg + (j - p); valid = true; }
+        }
+        heavy_batch(A, R, primary, valid, (size_t)e, H);
+    }
+}
+
+template <int LEVEL>
+__device__ __forceinline__ void heavy_chunk(const KernelArgs &A, const Ray &R, const bool primary, const HeavyMesh &M,
+                                            const uint32_t chunk, HeavyState &H, const uint32_t lane) {
+    const uint32_t idx = chunk * 64u + lane;
+    const bool valid = idx < M.count[LEVEL];
+    const size_t at = (size_t)M.first[LEVEL] + (valid ? idx : 0u);
+    const float4 b0 = A.hbox[2 * at], b1 = A.hbox[2 * at + 1];
+    const bool hit = valid && slab_test(R, b0.x, b0.y, b0.z, b1.x, b1.y, b1.z);
+    if constexpr (LEVEL == 0) {
+        if (__ballot(hit)) heavy_leaves(A, R, primary, hit, __float_as_uint(b0.w), __float_as_uint(b1.w), H, lane);
+    } else {
+        unsigned long long m = __ballot(hit);
+        while (m && H.guard) {
+            H.guard--;
+            const int k = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            heavy_chunk<LEVEL - 1>(A, R, primary, M, chunk * 64u + (uint32_t)k, H, lane);
+        }
+    }
+}
+
+// closest hit of the (wave-uniform) ray in one mesh
+__device__ __forceinline__ void heavy_mesh(const KernelArgs &A, const Ray &R, const bool primary, const uint32_t mesh,
+                                           HeavyState &H, const uint32_t lane) {
+    const HeavyMesh M = A.hmesh[mesh];
+    const uint32_t guard = H.guard;
+    H.guard = guard;
+    H.mhave = false;
+    H.mmin = INFINITY;
+    H.mt = 0;
+    H.mtri = 0;
+    switch (M.n_levels) {
+        case 1: heavy_chunk<0>(A, R, primary, M, 0, H, lane); break;
+        case 2: heavy_chunk<1>(A, R, primary, M, 0, H, lane); break;
+        case 3: heavy_chunk<2>(A, R, primary, M, 0, H, lane); break;
+        case 4: heavy_chunk<3>(A, R, primary, M, 0, H, lane); break;
+        default: break;
+    }
+}
+
+// The two-level walk for one ray per wave.  SHADOW: AccelerationStructure.cpp:56-94, else KDTree.cpp:127-167.
+template <bool SHADOW>
+__device__ __forceinline__ void heavy_walk(const KernelArgs &A, const Ray &R, const bool primary, const float light_dist,
+                                           bool &have, float &bt, uint32_t &btri, uint32_t &bmesh, bool &occluded,
+                                           const uint32_t lane) {
+    have = false;
+    occluded = false;
+    float tmin = INFINITY;
+    uint32_t ti = A.top_root;
+    HeavyState H;
+    H.guard = 1u << 18;
+    while (ti != END && H.guard) {  // the top-level tree is tiny: walked node by node, uniformly
+        H.guard--;
+        const float4 q0 = A.nodes[2 * (size_t)ti], q1 = A.nodes[2 * (size_t)ti + 1];
+        const uint32_t miss = __float_as_uint(q0.w), link = __float_as_uint(q1.w);
+        const bool hit = slab_test(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
+        if (!hit) { ti = miss; continue; }
+        if (!(link & LEAF)) { ti = link; continue; }
+        uint32_t e = link & ~LEAF;
+        for (;;) {
+            const uint32_t ent = A.leaf_meshes[e++];
+            const uint32_t mi = ent & ~LAST;
+            const crt_mesh m = A.meshes[mi];
+            if (!(SHADOW && (m.flags & 1u))) {
+                if (A.debug & 32u) { H.mhave = false; } else
+                heavy_mesh(A, R, primary, mi, H, lane);
+                if (H.mhave) {
+                    if (SHADOW) {
+                        const float px = R.ox + R.dx * H.mt, py = R.oy + R.dy * H.mt, pz = R.oz + R.dz * H.mt;
+                        if (len3(px - R.ox, py - R.oy, pz - R.oz) <= light_dist) occluded = true;
+                    } else {
+                        if (!have) { have = true; bt = H.mt; btri = H.mtri; bmesh = mi; }
+                        if (H.mt < tmin) { tmin = H.mt; bt = H.mt; btri = H.mtri; bmesh = mi; }
+                    }
+                }
+            }
+            if ((ent & LAST) || !H.guard) break;
+            H.guard--;
+        }
+        ti = miss;
+    }
+    if (!H.guard && lane == 0) { A.s_counts[SC_GUARD] = 1; A.s_counts[SC_OVERFLOW] = 1; }  // bound hit: let the fallback redo the frame
+}
+
+__device__ __forceinline__ float uniform_f(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
+
+// closest hits of the rays evicted from stream_trace_shade(gen); results go to s_hits[k] for list entry k
+__global__ __launch_bounds__(BLOCK) void heavy_trace_closest(const KernelArgs A, const uint32_t gen) {
+    const uint32_t lane = threadIdx.x & 63u;
+    if (A.s_counts[SC_OVERFLOW]) return;
+    uint32_t total = A.s_counts[SC_HEAVY + gen];
+    if (total > A.s_heavy_cap) total = A.s_heavy_cap;
+    const float4 *in_q = A.s_rayq[gen & 1u];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
+    const uint32_t n_waves = gridDim.x * (BLOCK / 64);
+    for (uint32_t k = wave; k < total; k += n_waves) {  // one evicted ray per wave and trip
+        const uint32_t r = A.s_heavy[k];
+        Ray R;
+        bool primary = false;
+        if (gen == 0) {
+            const WorkItem wi = A.items[r >> 6];
+            const uint32_t sub = r & 63u;
+            primary_ray(A, (wi.tile % A.tiles_x) * TILE + (sub & 7u), (wi.tile / A.tiles_x) * TILE + (sub >> 3), R);
+            primary = true;
+        } else {
+            const float4 q0 = in_q[2 * (size_t)r], q1 = in_q[2 * (size_t)r + 1];
+            R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
+            R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;
+            normalize3(R.dx, R.dy, R.dz);
+            ray_prepare(R);
+        }
+        R.ox = uniform_f(R.ox); R.oy = uniform_f(R.oy); R.oz = uniform_f(R.oz);
+        R.dx = uniform_f(R.dx); R.dy = uniform_f(R.dy); R.dz = uniform_f(R.dz);
+        R.ix = uniform_f(R.ix); R.iy = uniform_f(R.iy); R.iz = uniform_f(R.iz);
+        R.parmask = __builtin_amdgcn_readfirstlane(R.parmask);
+        bool have = false, occluded = false;
+        float bt = 0;
+        uint32_t btri = 0, bmesh = 0;
+        if (!(A.debug & 16u)) heavy_walk<false>(A, R, primary, 0.0f, have, bt, btri, bmesh, occluded, lane);
+        if (lane == 0) A.s_hits[k] = make_float4(bt, __uint_as_float(btri), __uint_as_float(bmesh), __uint_as_float(have ? 1u : 0u));
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void heavy_trace_shadow(const KernelArgs A) {
+    const uint32_t lane = threadIdx.x & 63u;
+    if (A.s_counts[SC_OVERFLOW]) return;
+    uint32_t total = A.s_counts[SC_SHEAVY];
+    if (total > A.s_heavy_cap) total = A.s_heavy_cap;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
+    const uint32_t n_waves = gridDim.x * (BLOCK / 64);
+    for (uint32_t k = wave; k < total; k += n_waves) {
+        const uint32_t r = A.s_sheavy[k];
+        const float4 q0 = A.s_shadowq[2 * (size_t)r], q1 = A.s_shadowq[2 * (size_t)r + 1];
+        Ray R;
+        R.ox = uniform_f(q0.x); R.oy = uniform_f(q0.y); R.oz = uniform_f(q0.z);
+        R.dx = uniform_f(q1.x); R.dy = uniform_f(q1.y); R.dz = uniform_f(q1.z);
+        ray_prepare(R);
+        R.ix = uniform_f(R.ix); R.iy = uniform_f(R.iy); R.iz = uniform_f(R.iz);
+        R.parmask = __builtin_amdgcn_readfirstlane(R.parmask);
+        bool have, occluded;
+        float bt = 0;
+        uint32_t btri = 0, bmesh = 0;
+        heavy_walk<true>(A, R, false, uniform_f(q0.w), have, bt, btri, bmesh, occluded, lane);
+        if (lane == 0) A.s_occluded[r] = occluded ? 1 : 0;
+    }
+}

@@ -38,13 +38,14 @@ template <bool COUNT>
 __device__ __forceinline__ bool traversal_step(LaneWalk &L, const Ray &R, const KernelArgs &A, uint32_t *cnt) {
     if (L.mleaf != NONE) {
         // ---- inside a mesh-tree leaf: test one triangle (KDTree.cpp:57-65)
-        const uint32_t ent = A.leaf_tris[L.mleaf];
-        const uint32_t tri = ent & ~LAST;
-        L.mleaf = (ent & LAST) ? NONE : L.mleaf + 1;
-        const float4 a = A.tris[4 * (size_t)tri + 0];
-        const float4 b = A.tris[4 * (size_t)tri + 1];
-        const float4 c = A.tris[4 * (size_t)tri + 2];
-        const float plane = A.tris[4 * (size_t)tri + 3].x;
+        // the leaf's triangles are stored in list order, one 64-byte record each: no index indirection
+        const float4 a = A.ltris[4 * (size_t)L.mleaf + 0];
+        const float4 b = A.ltris[4 * (size_t)L.mleaf + 1];
+        const float4 c = A.ltris[4 * (size_t)L.mleaf + 2];
+        const float4 d = A.ltris[4 * (size_t)L.mleaf + 3];
+        const float plane = d.x;
+        const uint32_t tri = __float_as_uint(d.y);
+        L.mleaf = __float_as_uint(d.z) ? NONE : L.mleaf + 1;
         if (COUNT) { cnt[C_TRI]++; cnt[C_LEAFIDX]++; }
         float t;
         if (triangle_test(R, L.rtype == RAY_PRIMARY, a, b, c, plane, t)) {

@@ -41,10 +41,9 @@ __device__ __forceinline__ v16f load_triangle(kfp tris, uint32_t index) { return
 template <bool SHADOW, bool PRIMARY, bool COUNT, bool TRACK, bool PAR>
 __device__ __forceinline__ void packet_walk_impl(const KernelArgs &A, const Ray &R, const bool on, const float light_dist,
                                                  bool &have, float &bt, uint32_t &btri, uint32_t &bmesh, bool &occluded,
-                                                 uint32_t *cnt) {
+                                                 uint32_t *cnt, int &budget) {
     const kfp nodes = (kfp)(const float *)A.nodes;
-    const kfp tris = (kfp)(const float *)A.tris;
-    const ku32p leaf_tris = (ku32p)A.leaf_tris;
+    const kfp ltris = (kfp)(const float *)A.ltris;
     const ku32p leaf_meshes = (ku32p)A.leaf_meshes;
     const ku32p meshes = (ku32p)(const uint32_t *)A.meshes;  // crt_mesh = 4 x u32: root, material, flags, pad
     auto slab = [&](const v8f &q) -> bool {
@@ -58,7 +57,7 @@ __device__ __forceinline__ void packet_walk_impl(const KernelArgs &A, const Ray 
     float tmin = INFINITY;
     uint32_t tres = on ? 0u : END;  // TRACK: the lane takes part in the top-level walk from node index `tres` on
     uint32_t ti = A.top_root;
-    while (ti != END) {
+    while (ti != END && budget >= 0) {
         const v8f q = load_node(nodes, ti);
         const uint32_t miss = __float_as_uint(q[3]), link = __float_as_uint(q[7]);
         if (COUNT && (threadIdx.x & 63u) == 0) cnt[C_WAVE_NODES]++;
@@ -82,7 +81,8 @@ __device__ __forceinline__ void packet_walk_impl(const KernelArgs &A, const Ray 
                 uint32_t mtri = 0;
                 uint32_t mres = mon ? mroot : END;
                 uint32_t i = mroot;
-                while (i != END) {
+                while (i != END && budget >= 0) {
+                    budget--;
                     const v8f n = load_node(nodes, i);
                     const uint32_t nmiss = __float_as_uint(n[3]), nlink = __float_as_uint(n[7]);
                     if (COUNT && (threadIdx.x & 63u) == 0) cnt[C_WAVE_NODES]++;
@@ -94,9 +94,10 @@ __device__ __forceinline__ void packet_walk_impl(const KernelArgs &A, const Ray 
                     if (!(nlink & LEAF)) { i = nlink; continue; }
                     uint32_t te = nlink & ~LEAF;
                     for (;;) {  // triangles of this leaf, in list order (KDTree.cpp:57-65)
-                        const uint32_t tent = leaf_tris[te++];
-                        const uint32_t tri = tent & ~LAST;
-                        const v16f T = load_triangle(tris, tri);
+                        budget--;
+                        const v16f T = load_triangle(ltris, te++);
+                        const uint32_t tri = __float_as_uint(T[13]);
+                        const uint32_t tent = __float_as_uint(T[14]) ? LAST : 0u;
                         const float4 a = make_float4(T[0], T[1], T[2], T[3]), b = make_float4(T[4], T[5], T[6], T[7]),
                                      c = make_float4(T[8], T[9], T[10], T[11]);
                         const float plane = T[12];
@@ -132,14 +133,14 @@ __device__ __forceinline__ void packet_walk_impl(const KernelArgs &A, const Ray 
 template <bool SHADOW, bool PRIMARY, bool COUNT>
 __device__ __forceinline__ void packet_walk(const KernelArgs &A, const Ray &R, const bool on, const float light_dist,
                                             bool &have, float &bt, uint32_t &btri, uint32_t &bmesh, bool &occluded,
-                                            uint32_t *cnt) {
+                                            uint32_t *cnt, int &budget) {
     const bool par = __ballot(on && R.parmask != 0) != 0;  // wave-uniform
     if (COUNT || !A.nested_boxes) {
-        if (par) packet_walk_impl<SHADOW, PRIMARY, COUNT, true, true>(A, R, on, light_dist, have, bt, btri, bmesh, occluded, cnt);
-        else packet_walk_impl<SHADOW, PRIMARY, COUNT, true, false>(A, R, on, light_dist, have, bt, btri, bmesh, occluded, cnt);
+        if (par) packet_walk_impl<SHADOW, PRIMARY, COUNT, true, true>(A, R, on, light_dist, have, bt, btri, bmesh, occluded, cnt, budget);
+        else packet_walk_impl<SHADOW, PRIMARY, COUNT, true, false>(A, R, on, light_dist, have, bt, btri, bmesh, occluded, cnt, budget);
     } else {
-        if (par) packet_walk_impl<SHADOW, PRIMARY, COUNT, false, true>(A, R, on, light_dist, have, bt, btri, bmesh, occluded, cnt);
-        else packet_walk_impl<SHADOW, PRIMARY, COUNT, false, false>(A, R, on, light_dist, have, bt, btri, bmesh, occluded, cnt);
+        if (par) packet_walk_impl<SHADOW, PRIMARY, COUNT, false, true>(A, R, on, light_dist, have, bt, btri, bmesh, occluded, cnt, budget);
+        else packet_walk_impl<SHADOW, PRIMARY, COUNT, false, false>(A, R, on, light_dist, have, bt, btri, bmesh, occluded, cnt, budget);
     }
 }
 
@@ -170,7 +171,9 @@ __global__ __launch_bounds__(BLOCK) void render_packets(const KernelArgs A) {
         bool have, occluded;
         float bt = 0;
         uint32_t btri = 0, bmesh = 0;
-        packet_walk<false, true, COUNT>(A, R, on, 0.0f, have, bt, btri, bmesh, occluded, cnt);
+        int budget = A.packet_budget ? (int)A.packet_budget : 0x7FFFFFFF;
+        packet_walk<false, true, COUNT>(A, R, on, 0.0f, have, bt, btri, bmesh, occluded, cnt, budget);
+        if (budget < 0 && lane == 0) atomicAdd(A.s_counts + 400, 1u);  // experiment: aborted walks
 
         // ---- shootRay's dispatch on the material (RayTracer.cpp:431-450)
         float cx = A.bgx, cy = A.bgy, cz = A.bgz;
@@ -209,7 +212,9 @@ __global__ __launch_bounds__(BLOCK) void render_packets(const KernelArgs A) {
                 bool shave, socc;
                 float st;
                 uint32_t stri, smesh;
-                packet_walk<true, false, COUNT>(A, SR, diffuse, dist, shave, st, stri, smesh, socc, cnt);
+                int sbudget = A.packet_budget ? (int)A.packet_budget : 0x7FFFFFFF;
+                packet_walk<true, false, COUNT>(A, SR, diffuse, dist, shave, st, stri, smesh, socc, cnt, sbudget);
+                if (sbudget < 0 && lane == 0) atomicAdd(A.s_counts + 401, 1u);
                 if (diffuse && !socc) {
                     if (COUNT && base_is_bitmap) cnt[C_TEXEL]++;
                     accx += kfac * basex; accy += kfac * basey; accz += kfac * basez;

@@ -20,6 +20,8 @@
 
 #include "kernel_common.h"
 #include "kernel_lane.h"
+#include "kernel_walk.h"
+#include "kernel_packet.h"
 
 struct TNode {          // one node of a pixel's ray tree, 32 bytes
     float cx, cy, cz;   // DIFFUSE: texture/albedo colour; REFLECT: albedo; after resolve of a REFRACT node: reflection colour
@@ -34,8 +36,11 @@ constexpr uint32_t CHILD_BG = 0xFFFFFFFFu;     // child ray beyond MAX_DEPTH: ba
 constexpr uint32_t CHILD_NONE = 0xFFFFFFFEu;   // total internal reflection: no refraction child (RayTracer.cpp:416)
 constexpr int MAX_GENERATIONS = 64;
 // layout of KernelArgs::s_counts (uint32): [g] rays of level g, [SC_FETCH + g] fetch cursor of level g
-enum : int { SC_COUNT = 0, SC_FETCH = MAX_GENERATIONS, SC_SHADOW = 2 * MAX_GENERATIONS, SC_SHADOW_FETCH, SC_OVERFLOW,
-             SC_RESOLVE_FETCH, SC_WORDS };
+//   [SC_HEAVY + g] rays evicted to the heavy kernel at level g, [SC_HEAVY_FETCH + g] / [SC_EVICT_FETCH + g] their cursors
+enum : int { SC_COUNT = 0, SC_FETCH = MAX_GENERATIONS, SC_HEAVY = 2 * MAX_GENERATIONS, SC_HEAVY_FETCH = 3 * MAX_GENERATIONS,
+             SC_EVICT_FETCH = 4 * MAX_GENERATIONS, SC_SHADOW = 5 * MAX_GENERATIONS, SC_SHADOW_FETCH, SC_OVERFLOW, SC_SHEAVY,
+             SC_SHEAVY_FETCH, SC_GUARD, SC_SHADOW_SPLIT, SC_SHADOW_FETCH2,
+             SC_TODO_TILES, SC_TODO_SHADOW, SC_TILE_FETCH, SC_WORDS };
 
 static_assert(SC_OVERFLOW == SC_OVERFLOW_WORD, "kernel_common.h SC_OVERFLOW_WORD must match");
 
@@ -58,6 +63,129 @@ __device__ __forceinline__ uint32_t wave_fetch(uint32_t *cursor, uint32_t lane) 
     return base + (uint32_t)rank;
 }
 
+// shootRay's dispatch on the closest hit (RayTracer.cpp:431-450) for ray `r` of level `gen`: writes the ray-tree
+// node, appends the child rays of level gen+1 and the shadow rays.  Called by every lane whose walk has just
+// ended (any subset of the wave); allocations are aggregated over those lanes.
+template <bool COUNT>
+__device__ __forceinline__ void shade_and_emit(const KernelArgs &A, const uint32_t gen, const uint32_t r, const uint32_t node_base,
+                                       const uint32_t child_base, const Ray &R, const bool have, const float bt,
+                                       const uint32_t btri, const uint32_t bmesh, uint32_t *cnt, const uint32_t lane,
+                                       bool *out_diffuse = nullptr, uint32_t *out_first = nullptr, uint32_t *out_stride = nullptr) {
+    if (out_diffuse) *out_diffuse = false;
+    float4 *out_q = A.s_rayq[(gen + 1u) & 1u];
+    uint32_t *out_count = A.s_counts + SC_COUNT + gen + 1;
+    const bool spawn_allowed = gen + 1 <= A.max_depth;  // a child enters shootRay with depth gen+1 (RayTracer.cpp:427)
+    TNode N;
+    N.cx = A.bgx; N.cy = A.bgy; N.cz = A.bgz;
+    N.kind = TN_CONST; N.a = 0; N.b = 0; N.f = 0; N.pad = 0;
+    if (have) {
+        Surface S;
+        surface_at(A, R, bt, btri, bmesh, S);
+        if (COUNT) cnt[C_HIT]++;
+        if (S.M.type == CRT_MAT_DIFFUSE) {
+            // calculateDiffusion (RayTracer.cpp:300-330): the light loop becomes n_lights shadow rays
+            bool bitmap = false;
+            if (S.M.texture >= 0)
+                texture_color<COUNT>(A, A.textures[S.M.texture], btri, S.u, S.v, 1.0f - S.u - S.v, N.cx, N.cy, N.cz, bitmap);
+            else { N.cx = S.M.ax; N.cy = S.M.ay; N.cz = S.M.az; }
+            const unsigned long long mask = __ballot(1);
+            const uint32_t cntd = (uint32_t)__popcll(mask);
+            const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            uint32_t base = 0;
+            if (rank == 0) base = atomicAdd(A.s_counts + SC_SHADOW, cntd * A.n_lights);
+            base = __shfl(base, __ffsll((long long)mask) - 1);
+            if ((uint64_t)base + (uint64_t)cntd * A.n_lights > A.s_shadow_cap) {
+                A.s_counts[SC_OVERFLOW] = 1;
+                N.cx = N.cy = N.cz = 0;  // the frame is redone by the fallback path
+            } else {
+                N.kind = TN_DIFFUSE | (bitmap ? TN_BITMAP : 0u);
+                N.a = base + rank;
+                N.b = cntd;
+                if (out_diffuse) { *out_diffuse = true; *out_first = N.a; *out_stride = cntd; }
+                for (uint32_t li = 0; li < A.n_lights; li++) {
+                    Ray SR;
+                    float dist, kfac;
+                    light_setup(A, li, S.px, S.py, S.pz, S.nx, S.ny, S.nz, SR, dist, kfac);
+                    if (COUNT) { cnt[C_LIGHT]++; cnt[C_SHADOW]++; }
+                    const size_t slot = (size_t)base + (size_t)li * cntd + rank;
+                    A.s_shadowq[2 * slot] = make_float4(SR.ox, SR.oy, SR.oz, dist);
+                    A.s_shadowq[2 * slot + 1] = make_float4(SR.dx, SR.dy, SR.dz, kfac);
+                }
+            }
+        } else if (S.M.type == CRT_MAT_REFLECTIVE || S.M.type == CRT_MAT_REFRACTIVE) {
+            const bool refractive = S.M.type == CRT_MAT_REFRACTIVE;
+            float nx = S.nx, ny = S.ny, nz = S.nz;
+            bool transmit = false;
+            float tox = 0, toy = 0, toz = 0, tdx = 0, tdy = 0, tdz = 0;
+            if (refractive) {
+                // calculateRefraction (RayTracer.cpp:375-417)
+                float eta1 = 1.0f, eta2 = S.M.ior;
+                float idn = dot3(R.dx, R.dy, R.dz, nx, ny, nz);
+                if (idn > 0) {
+                    const float s = eta1; eta1 = eta2; eta2 = s;
+                    nx = -1.0f * nx; ny = -1.0f * ny; nz = -1.0f * nz;
+                    idn = -idn;
+                }
+                const float cos_a = -idn;
+                const float sin_a = sqrtf(std_max(0.0f, 1 - cos_a * cos_a));
+                const float eta_ratio = eta1 / eta2;
+                const float sin_b = eta_ratio * sin_a;
+                if (sin_b < 1.0f) {
+                    const float q = (eta1 - eta2) / (eta1 + eta2);
+                    const float r0 = q * q;  // std::powf(q, 2), folded to q*q by the reference's compiler at -O2
+                    N.f = r0 + (1 - r0) * crt_pow5(1.0f - cos_a);
+                    const float cos_b = sqrtf(std_max(0.0f, 1 - sin_b * sin_b));
+                    tdx = eta_ratio * (R.dx + cos_a * nx) - cos_b * nx;
+                    tdy = eta_ratio * (R.dy + cos_a * ny) - cos_b * ny;
+                    tdz = eta_ratio * (R.dz + cos_a * nz) - cos_b * nz;
+                    normalize3(tdx, tdy, tdz);
+                    tox = S.px - nx * A.refraction_bias; toy = S.py - ny * A.refraction_bias; toz = S.pz - nz * A.refraction_bias;
+                    transmit = true;
+                }
+                N.kind = TN_REFRACT;
+            } else {
+                N.kind = TN_REFLECT;  // calculateReflection (RayTracer.cpp:358-374)
+                N.cx = S.M.ax; N.cy = S.M.ay; N.cz = S.M.az;
+            }
+            // the reflection ray (both materials): origin + n*bias, reflect(d, n) normalised (Vector.cpp:119-122)
+            const float k = 2 * dot3(R.dx, R.dy, R.dz, nx, ny, nz);
+            float rdx = R.dx - k * nx, rdy = R.dy - k * ny, rdz = R.dz - k * nz;
+            normalize3(rdx, rdy, rdz);
+            const float rox = S.px + nx * A.reflection_bias, roy = S.py + ny * A.reflection_bias,
+                        roz = S.pz + nz * A.reflection_bias;
+            N.a = CHILD_BG;
+            N.b = refractive ? (transmit ? CHILD_BG : CHILD_NONE) : 0u;
+            if (spawn_allowed) {
+                // wave-aggregated append of 1 or 2 child rays per lane
+                const unsigned long long m1 = __ballot(1), m2 = __ballot(transmit);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const uint32_t n1 = (uint32_t)__popcll(m1), n2 = (uint32_t)__popcll(m2);
+                uint32_t base = 0;
+                if ((m1 & below) == 0) base = atomicAdd(out_count, n1 + n2);
+                base = __shfl(base, __ffsll((long long)m1) - 1);
+                if ((uint64_t)base + n1 + n2 > A.s_ray_cap || (uint64_t)child_base + base + n1 + n2 > A.s_node_cap) {
+                    A.s_counts[SC_OVERFLOW] = 1;
+                } else {
+                    const uint32_t i1 = base + (uint32_t)__popcll(m1 & below);
+                    out_q[2 * (size_t)i1] = make_float4(rox, roy, roz, 0.0f);
+                    out_q[2 * (size_t)i1 + 1] = make_float4(rdx, rdy, rdz, 0.0f);
+                    N.a = child_base + i1;
+                    if (transmit) {
+                        const uint32_t i2 = base + n1 + (uint32_t)__popcll(m2 & below);
+                        out_q[2 * (size_t)i2] = make_float4(tox, toy, toz, 0.0f);
+                        out_q[2 * (size_t)i2 + 1] = make_float4(tdx, tdy, tdz, 0.0f);
+                        N.b = child_base + i2;
+                    }
+                }
+            }
+        }
+        // any other material type (Constant): background, RayTracer.cpp:443-446
+    }
+    float4 *dst = A.s_nodes + 2 * ((size_t)node_base + r);
+    dst[0] = make_float4(N.cx, N.cy, N.cz, __uint_as_float(N.kind));
+    dst[1] = make_float4(__uint_as_float(N.a), __uint_as_float(N.b), N.f, 0.0f);
+}
+
 template <bool COUNT>
 __global__ __launch_bounds__(BLOCK) void stream_trace_shade(const KernelArgs A, const uint32_t gen) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -66,9 +194,6 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade(const KernelArgs A, 
     const uint32_t node_base = stream_level_base(A, gen);
     const uint32_t child_base = node_base + count;
     const float4 *in_q = A.s_rayq[gen & 1u];
-    float4 *out_q = A.s_rayq[(gen + 1u) & 1u];
-    uint32_t *out_count = A.s_counts + SC_COUNT + gen + 1;
-    const bool spawn_allowed = gen + 1 <= A.max_depth;  // a child enters shootRay with depth gen+1 (RayTracer.cpp:427)
 
     uint32_t cnt[C_N];
     if (COUNT) for (int k = 0; k < C_N; k++) cnt[k] = 0;
@@ -118,122 +243,27 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade(const KernelArgs A, 
             int budget = 64;
             do {
                 if (!traversal_step<COUNT>(L, R, A, cnt)) { finished = true; break; }
-                if (COUNT) steps++;
+                steps++;
             } while (--budget > 0);
         }
 
-        // ------------------------------------------------------------------ shade (shootRay's dispatch, RayTracer.cpp:431-450)
+        // ------------------------------------------------------------------ shade, or hand a long walk to heavy_trace
         if (finished) {
-            if (COUNT) { max_steps = steps > max_steps ? steps : max_steps; steps = 0; }
-            TNode N;
-            N.cx = A.bgx; N.cy = A.bgy; N.cz = A.bgz;
-            N.kind = TN_CONST; N.a = 0; N.b = 0; N.f = 0; N.pad = 0;
-            if (L.have) {
-                Surface S;
-                surface_at(A, R, L.bt, L.btri, L.bmesh, S);
-                if (COUNT) cnt[C_HIT]++;
-                if (S.M.type == CRT_MAT_DIFFUSE) {
-                    // calculateDiffusion (RayTracer.cpp:300-330): the light loop becomes n_lights shadow rays
-                    bool bitmap = false;
-                    if (S.M.texture >= 0)
-                        texture_color<COUNT>(A, A.textures[S.M.texture], L.btri, S.u, S.v, 1.0f - S.u - S.v, N.cx, N.cy, N.cz, bitmap);
-                    else { N.cx = S.M.ax; N.cy = S.M.ay; N.cz = S.M.az; }
-                    const unsigned long long mask = __ballot(1);
-                    const uint32_t cntd = (uint32_t)__popcll(mask);
-                    const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                    uint32_t base = 0;
-                    if (rank == 0) base = atomicAdd(A.s_counts + SC_SHADOW, cntd * A.n_lights);
-                    base = __shfl(base, __ffsll((long long)mask) - 1);
-                    if ((uint64_t)base + (uint64_t)cntd * A.n_lights > A.s_shadow_cap) {
-                        A.s_counts[SC_OVERFLOW] = 1;
-                        N.cx = N.cy = N.cz = 0;  // the frame is redone by the fallback path
-                    } else {
-                        N.kind = TN_DIFFUSE | (bitmap ? TN_BITMAP : 0u);
-                        N.a = base + rank;
-                        N.b = cntd;
-                        for (uint32_t li = 0; li < A.n_lights; li++) {
-                            Ray SR;
-                            float dist, kfac;
-                            light_setup(A, li, S.px, S.py, S.pz, S.nx, S.ny, S.nz, SR, dist, kfac);
-                            if (COUNT) { cnt[C_LIGHT]++; cnt[C_SHADOW]++; }
-                            const size_t slot = (size_t)base + (size_t)li * cntd + rank;
-                            A.s_shadowq[2 * slot] = make_float4(SR.ox, SR.oy, SR.oz, dist);
-                            A.s_shadowq[2 * slot + 1] = make_float4(SR.dx, SR.dy, SR.dz, kfac);
-                        }
-                    }
-                } else if (S.M.type == CRT_MAT_REFLECTIVE || S.M.type == CRT_MAT_REFRACTIVE) {
-                    const bool refractive = S.M.type == CRT_MAT_REFRACTIVE;
-                    float nx = S.nx, ny = S.ny, nz = S.nz;
-                    bool transmit = false;
-                    float tox = 0, toy = 0, toz = 0, tdx = 0, tdy = 0, tdz = 0;
-                    if (refractive) {
-                        // calculateRefraction (RayTracer.cpp:375-417)
-                        float eta1 = 1.0f, eta2 = S.M.ior;
-                        float idn = dot3(R.dx, R.dy, R.dz, nx, ny, nz);
-                        if (idn > 0) {
-                            const float s = eta1; eta1 = eta2; eta2 = s;
-                            nx = -1.0f * nx; ny = -1.0f * ny; nz = -1.0f * nz;
-                            idn = -idn;
-                        }
-                        const float cos_a = -idn;
-                        const float sin_a = sqrtf(std_max(0.0f, 1 - cos_a * cos_a));
-                        const float eta_ratio = eta1 / eta2;
-                        const float sin_b = eta_ratio * sin_a;
-                        if (sin_b < 1.0f) {
-                            const float q = (eta1 - eta2) / (eta1 + eta2);
-                            const float r0 = q * q;  // std::powf(q, 2), folded to q*q by the reference's compiler at -O2
-                            N.f = r0 + (1 - r0) * crt_pow5(1.0f - cos_a);
-                            const float cos_b = sqrtf(std_max(0.0f, 1 - sin_b * sin_b));
-                            tdx = eta_ratio * (R.dx + cos_a * nx) - cos_b * nx;
-                            tdy = eta_ratio * (R.dy + cos_a * ny) - cos_b * ny;
-                            tdz = eta_ratio * (R.dz + cos_a * nz) - cos_b * nz;
-                            normalize3(tdx, tdy, tdz);
-                            tox = S.px - nx * A.refraction_bias; toy = S.py - ny * A.refraction_bias; toz = S.pz - nz * A.refraction_bias;
-                            transmit = true;
-                        }
-                        N.kind = TN_REFRACT;
-                    } else {
-                        N.kind = TN_REFLECT;  // calculateReflection (RayTracer.cpp:358-374)
-                        N.cx = S.M.ax; N.cy = S.M.ay; N.cz = S.M.az;
-                    }
-                    // the reflection ray (both materials): origin + n*bias, reflect(d, n) normalised (Vector.cpp:119-122)
-                    const float k = 2 * dot3(R.dx, R.dy, R.dz, nx, ny, nz);
-                    float rdx = R.dx - k * nx, rdy = R.dy - k * ny, rdz = R.dz - k * nz;
-                    normalize3(rdx, rdy, rdz);
-                    const float rox = S.px + nx * A.reflection_bias, roy = S.py + ny * A.reflection_bias,
-                                roz = S.pz + nz * A.reflection_bias;
-                    N.a = CHILD_BG;
-                    N.b = refractive ? (transmit ? CHILD_BG : CHILD_NONE) : 0u;
-                    if (spawn_allowed) {
-                        // wave-aggregated append of 1 or 2 child rays per lane
-                        const unsigned long long m1 = __ballot(1), m2 = __ballot(transmit);
-                        const unsigned long long below = (1ull << lane) - 1ull;
-                        const uint32_t n1 = (uint32_t)__popcll(m1), n2 = (uint32_t)__popcll(m2);
-                        uint32_t base = 0;
-                        if ((m1 & below) == 0) base = atomicAdd(out_count, n1 + n2);
-                        base = __shfl(base, __ffsll((long long)m1) - 1);
-                        if ((uint64_t)base + n1 + n2 > A.s_ray_cap || (uint64_t)child_base + base + n1 + n2 > A.s_node_cap) {
-                            A.s_counts[SC_OVERFLOW] = 1;
-                        } else {
-                            const uint32_t i1 = base + (uint32_t)__popcll(m1 & below);
-                            out_q[2 * (size_t)i1] = make_float4(rox, roy, roz, 0.0f);
-                            out_q[2 * (size_t)i1 + 1] = make_float4(rdx, rdy, rdz, 0.0f);
-                            N.a = child_base + i1;
-                            if (transmit) {
-                                const uint32_t i2 = base + n1 + (uint32_t)__popcll(m2 & below);
-                                out_q[2 * (size_t)i2] = make_float4(tox, toy, toz, 0.0f);
-                                out_q[2 * (size_t)i2 + 1] = make_float4(tdx, tdy, tdz, 0.0f);
-                                N.b = child_base + i2;
-                            }
-                        }
-                    }
-                }
-                // any other material type (Constant): background, RayTracer.cpp:443-446
-            }
-            float4 *dst = A.s_nodes + 2 * ((size_t)node_base + r);
-            dst[0] = make_float4(N.cx, N.cy, N.cz, __uint_as_float(N.kind));
-            dst[1] = make_float4(__uint_as_float(N.a), __uint_as_float(N.b), N.f, 0.0f);
+            shade_and_emit<COUNT>(A, gen, r, node_base, child_base, R, L.have, L.bt, L.btri, L.bmesh, cnt, lane);
+            if (COUNT) { max_steps = steps > max_steps ? steps : max_steps; }
+            steps = 0;
             state = ST_FETCH;
+        } else if (state == ST_TRAVERSE && A.step_budget && steps >= A.step_budget) {
+            const unsigned long long em = __ballot(1);
+            uint32_t base = 0;
+            if ((em & ((1ull << lane) - 1ull)) == 0) base = atomicAdd(A.s_counts + SC_HEAVY + gen, (uint32_t)__popcll(em));
+            base = __shfl(base, __ffsll((long long)em) - 1);
+            const uint32_t slot = base + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
+            if (slot < A.s_heavy_cap) {
+                A.s_heavy[slot] = r;
+                state = ST_FETCH;
+            }
+            steps = 0;  // list full: keep walking here
         }
     }
 
@@ -248,26 +278,265 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade(const KernelArgs A, 
     }
 }
 
+// wave-aggregated append of this lane's ray id to an eviction list; false when the list is full
+__device__ __forceinline__ bool evict_ray(uint32_t *list, uint32_t cap, uint32_t *count, uint32_t r, uint32_t lane) {
+    const unsigned long long em = __ballot(1);
+    uint32_t base = 0;
+    if ((em & ((1ull << lane) - 1ull)) == 0) base = atomicAdd(count, (uint32_t)__popcll(em));
+    base = __shfl(base, __ffsll((long long)em) - 1);
+    const uint32_t slot = base + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
+    if (slot >= cap) return false;
+    list[slot] = r;
+    return true;
+}
+
+// stream_trace_shade with the lean walk (kernel_walk.h): the non-counting build when heavy_trace is available.
+// Rays with a parallel axis and walks longer than step_budget go to heavy_trace_closest.
+__global__ __launch_bounds__(BLOCK) void stream_trace_shade_lean(const KernelArgs A, const uint32_t gen) {
+    const uint32_t lane = threadIdx.x & 63u;
+    if (A.s_counts[SC_OVERFLOW]) return;
+    const uint32_t count = stream_level_count(A, gen);
+    const uint32_t node_base = stream_level_base(A, gen);
+    const uint32_t child_base = node_base + count;
+    const float4 *in_q = A.s_rayq[gen & 1u];
+    const bool primary = gen == 0;
+    // level 0 after stream_packets_gen0: only the tiles that kernel gave up on
+    const bool todo = gen == 0 && A.use_packets;
+    const uint32_t fetch_count = todo ? A.s_counts[SC_TODO_TILES] * 64u : count;
+    // a small level is all tail: hand every ray to the wave-per-ray kernel straight away
+    const bool all_heavy = gen > 0 && count < A.heavy_level_threshold;
+
+    Ray R;
+    LeanWalk W;
+    int state = ST_FETCH;
+    uint32_t r = 0, steps = 0;
+    for (;;) {
+        if (__ballot(state == ST_FETCH)) {
+            while (state == ST_FETCH) {
+                r = wave_fetch(A.s_counts + SC_FETCH + gen, lane);
+                if (r >= fetch_count) { state = ST_DONE; break; }
+                if (todo) r = A.s_todo_tiles[r >> 6] * 64u + (r & 63u);
+                if (gen == 0) {
+                    const WorkItem wi = A.items[r >> 6];
+                    const uint32_t sub = r & 63u;
+                    const uint32_t px = (wi.tile % A.tiles_x) * TILE + (sub & 7u);
+                    const uint32_t py = (wi.tile / A.tiles_x) * TILE + (sub >> 3);
+                    if (!((wi.mask >> sub) & 1ull) || px >= A.width || py >= A.height) {
+                        reinterpret_cast<uint32_t *>(A.s_nodes + 2 * (size_t)r)[3] = TN_SKIP;
+                        continue;
+                    }
+                    primary_ray(A, px, py, R);
+                } else {
+                    const float4 q0 = in_q[2 * (size_t)r], q1 = in_q[2 * (size_t)r + 1];
+                    R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
+                    R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;
+                    normalize3(R.dx, R.dy, R.dz);  // shootRay entry (RayTracer.cpp:420)
+                    ray_prepare(R);
+                }
+                if (all_heavy || R.parmask != 0) {
+                    if (evict_ray(A.s_heavy, A.s_heavy_cap, A.s_counts + SC_HEAVY + gen, r, lane)) continue;
+                    if (R.parmask != 0) { A.s_counts[SC_OVERFLOW] = 1; continue; }  // cannot walk it here: let the fallback redo the frame
+                }
+                lean_begin(W, A.top_root);
+                steps = 0;
+                state = ST_TRAVERSE;
+            }
+        }
+        if (!__ballot(state != ST_DONE)) break;
+        if (state == ST_TRAVERSE) {
+            if (lean_walk<false>(W, R, primary, A, 64, steps)) {
+                shade_and_emit<false>(A, gen, r, node_base, child_base, R, W.have, W.bt, W.btri, W.bmesh, nullptr, lane);
+                state = ST_FETCH;
+            } else if (steps >= A.step_budget) {
+                if (evict_ray(A.s_heavy, A.s_heavy_cap, A.s_counts + SC_HEAVY + gen, r, lane)) state = ST_FETCH;
+                steps = 0;
+            }
+        }
+    }
+}
+
+template <uint32_t pass>  // a template parameter so that the two passes are two kernels in a profile
+__global__ __launch_bounds__(BLOCK) void stream_trace_shadow_lean(const KernelArgs A) {
+    const uint32_t lane = threadIdx.x & 63u;
+    if (A.s_counts[SC_OVERFLOW]) return;
+    // pass 0: after stream_packets_gen0, the shadow walks that kernel gave up on (a list of queue slots);
+    //         otherwise the queue below the split mark.  pass 1: the queue from the split mark on.
+    const uint32_t split = A.s_counts[SC_SHADOW_SPLIT];
+    const bool listed = pass == 0 && A.use_packets;
+    const uint32_t first = pass == 0 ? 0u : split;
+    const uint32_t total = listed ? A.s_counts[SC_TODO_SHADOW] : (pass == 0 ? split : A.s_counts[SC_SHADOW] - split);
+    uint32_t *cursor = A.s_counts + (pass == 0 ? SC_SHADOW_FETCH : SC_SHADOW_FETCH2);
+    Ray R;
+    LeanWalk W;
+    int state = ST_FETCH;
+    uint32_t r = 0, steps = 0;
+    for (;;) {
+        if (__ballot(state == ST_FETCH)) {
+            while (state == ST_FETCH) {
+                r = wave_fetch(cursor, lane);
+                if (r >= total) { state = ST_DONE; break; }
+                r = listed ? A.s_todo_shadow[r] : r + first;
+                const float4 q0 = A.s_shadowq[2 * (size_t)r], q1 = A.s_shadowq[2 * (size_t)r + 1];
+                R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
+                R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;  // already normalised once; shadow rays skip shootRay (RayTracer.cpp:313-317)
+                ray_prepare(R);
+                if (R.parmask != 0) {
+                    if (evict_ray(A.s_sheavy, A.s_heavy_cap, A.s_counts + SC_SHEAVY, r, lane)) continue;
+                    A.s_counts[SC_OVERFLOW] = 1;
+                    continue;
+                }
+                lean_begin(W, A.top_root);
+                W.light_dist = q0.w;
+                steps = 0;
+                state = ST_TRAVERSE;
+            }
+        }
+        if (!__ballot(state != ST_DONE)) break;
+        if (state == ST_TRAVERSE) {
+            if (lean_walk<true>(W, R, false, A, 64, steps)) {
+                A.s_occluded[r] = W.occluded ? 1 : 0;
+                state = ST_FETCH;
+            } else if (steps >= A.step_budget) {
+                if (evict_ray(A.s_sheavy, A.s_heavy_cap, A.s_counts + SC_SHEAVY, r, lane)) state = ST_FETCH;
+                steps = 0;
+            }
+        }
+    }
+}
+
+// Recursion level 0 by PACKETS (kernel_packet.h): one wave per 8x8 tile walks the tree once for the tile's 64
+// primary rays and once per light for the shadow rays of its diffuse hits, fetching nodes and triangles with
+// scalar loads -- a different memory path from the per-lane kernels' vector gathers.  A walk that needs more
+// than packet_budget wave-level visits is abandoned (its rays have lost coherence, and one wave would hold the
+// launch): an abandoned primary walk puts the tile on s_todo_tiles for stream_trace_shade_lean(0), an abandoned
+// shadow walk puts its queue slots on s_todo_shadow for stream_trace_shadow_lean pass 0.  Everything else --
+// ray-tree nodes, child rays, shadow-ray records -- is produced by the same shade_and_emit as the other kernels.
+__global__ __launch_bounds__(BLOCK) void stream_packets_gen0(const KernelArgs A) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t count = A.n_items * 64u;
+    // static round-robin over the tiles: wave w takes items w, w + n_waves, ...  (no `continue` / `break` on
+    // wave-uniform conditions inside this loop: see DESIGN.md "compiler notes")
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
+    const uint32_t n_waves = gridDim.x * (BLOCK / 64);
+    for (uint32_t item = wave; item < A.n_items; item += n_waves) {
+        const WorkItem wi = A.items[item];
+        const uint32_t px = (wi.tile % A.tiles_x) * TILE + (lane & 7u);
+        const uint32_t py = (wi.tile / A.tiles_x) * TILE + (lane >> 3);
+        const bool on = ((wi.mask >> lane) & 1ull) && px < A.width && py < A.height;
+        const uint32_t r = item * 64u + lane;
+        Ray R;
+        primary_ray(A, px, py, R);
+        bool have, occluded;
+        float bt = 0;
+        uint32_t btri = 0, bmesh = 0;
+        int budget = (int)A.packet_budget;
+        packet_walk<false, true, false>(A, R, on, 0.0f, have, bt, btri, bmesh, occluded, nullptr, budget);
+        const bool gave_up = __builtin_amdgcn_readfirstlane(budget < 0 ? 1 : 0) != 0;
+        if (gave_up) {  // the whole tile goes to the per-lane kernel
+            if (lane == 0) A.s_todo_tiles[atomicAdd(A.s_counts + SC_TODO_TILES, 1u)] = item;
+        } else {
+            bool diffuse = false;
+            uint32_t first = 0, stride = 0;
+            if (on) shade_and_emit<false>(A, 0u, r, 0u, count, R, have, bt, btri, bmesh, nullptr, lane, &diffuse, &first, &stride);
+            else reinterpret_cast<uint32_t *>(A.s_nodes + 2 * (size_t)r)[3] = TN_SKIP;
+            if (__ballot(diffuse)) {
+                for (uint32_t li = 0; li < A.n_lights; li++) {
+                    const size_t slot = (size_t)first + (size_t)li * stride;
+                    Ray SR;
+                    float dist = 0;
+                    if (diffuse) {  // the record shade_and_emit has just written (this lane's own store)
+                        const float4 q0 = A.s_shadowq[2 * slot], q1 = A.s_shadowq[2 * slot + 1];
+                        SR.ox = q0.x; SR.oy = q0.y; SR.oz = q0.z; dist = q0.w;
+                        SR.dx = q1.x; SR.dy = q1.y; SR.dz = q1.z;
+                    } else { SR.ox = SR.oy = SR.oz = 0; SR.dx = SR.dy = 0; SR.dz = 1; }
+                    ray_prepare(SR);
+                    bool shave, socc;
+                    float st;
+                    uint32_t stri, smesh;
+                    int sbudget = (int)A.packet_budget;
+                    packet_walk<true, false, false>(A, SR, diffuse, dist, shave, st, stri, smesh, socc, nullptr, sbudget);
+                    const bool sgave_up = __builtin_amdgcn_readfirstlane(sbudget < 0 ? 1 : 0) != 0;
+                    if (diffuse) {
+                        if (!sgave_up) A.s_occluded[slot] = socc ? 1 : 0;
+                        else evict_ray(A.s_todo_shadow, A.s_shadow_cap, A.s_counts + SC_TODO_SHADOW, (uint32_t)slot, lane);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Shading of the rays stream_trace_shade(gen) evicted, after heavy_trace_closest(gen) has found their hits.
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) void stream_shade_evicted(const KernelArgs A, const uint32_t gen) {
+    const uint32_t lane = threadIdx.x & 63u;
+    if (A.s_counts[SC_OVERFLOW]) return;
+    uint32_t total = A.s_counts[SC_HEAVY + gen];
+    if (total > A.s_heavy_cap) total = A.s_heavy_cap;
+    const uint32_t count = stream_level_count(A, gen);
+    const uint32_t node_base = stream_level_base(A, gen);
+    const uint32_t child_base = node_base + count;
+    const float4 *in_q = A.s_rayq[gen & 1u];
+    uint32_t cnt[C_N];
+    if (COUNT) for (int k = 0; k < C_N; k++) cnt[k] = 0;
+    for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < total; k += gridDim.x * BLOCK) {
+        const uint32_t r = A.s_heavy[k];
+        Ray R;
+        if (gen == 0) {
+            const WorkItem wi = A.items[r >> 6];
+            const uint32_t sub = r & 63u;
+            primary_ray(A, (wi.tile % A.tiles_x) * TILE + (sub & 7u), (wi.tile / A.tiles_x) * TILE + (sub >> 3), R);
+        } else {
+            const float4 q0 = in_q[2 * (size_t)r], q1 = in_q[2 * (size_t)r + 1];
+            R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
+            R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;
+            normalize3(R.dx, R.dy, R.dz);
+            ray_prepare(R);
+        }
+        const float4 h = A.s_hits[k];
+        shade_and_emit<COUNT>(A, gen, r, node_base, child_base, R, __float_as_uint(h.w) != 0, h.x, __float_as_uint(h.y),
+                              __float_as_uint(h.z), cnt, lane);
+    }
+    if (COUNT) {
+        for (int k = 0; k < C_N; k++) {
+            unsigned long long v = cnt[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+            if (lane == 0 && v) atomicAdd(&A.counters[k], v);
+        }
+    }
+}
+
 // Every shadow ray of the frame: RayTracer::hasIntersection in tree mode (RayTracer.cpp:507-517 ->
 // AccelerationStructure.cpp:56-94).  Writes 1 to s_occluded[i] when the light is blocked.
+// The shadow queue is traced in two passes so that the first can overlap the deeper recursion levels:
+// pass 0 = the rays queued by level 0 (indices below the split mark), on a side stream as soon as level 0 is
+// done; pass 1 = the rest, after the last level.
+__global__ void stream_mark_split(const KernelArgs A) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) A.s_counts[SC_SHADOW_SPLIT] = A.s_counts[SC_SHADOW];
+}
+
 template <bool COUNT>
-__global__ __launch_bounds__(BLOCK) void stream_trace_shadow(const KernelArgs A) {
+__global__ __launch_bounds__(BLOCK) void stream_trace_shadow(const KernelArgs A, const uint32_t pass) {
     const uint32_t lane = threadIdx.x & 63u;
     if (A.s_counts[SC_OVERFLOW]) return;  // the fallback path redoes the frame
-    const uint32_t total = A.s_counts[SC_SHADOW];
+    const uint32_t split = A.s_counts[SC_SHADOW_SPLIT];
+    const uint32_t first = pass == 0 ? 0u : split;
+    const uint32_t total = pass == 0 ? split : A.s_counts[SC_SHADOW] - split;
+    uint32_t *cursor = A.s_counts + (pass == 0 ? SC_SHADOW_FETCH : SC_SHADOW_FETCH2);
     uint32_t cnt[C_N];
     if (COUNT) for (int k = 0; k < C_N; k++) cnt[k] = 0;
 
     Ray R;
     LaneWalk L;
     int state = ST_FETCH;
-    uint32_t r = 0;
+    uint32_t r = 0, steps = 0;
     for (;;) {
         if (__ballot(state == ST_FETCH)) {
             if (state == ST_FETCH) {
-                r = wave_fetch(A.s_counts + SC_SHADOW_FETCH, lane);
+                r = wave_fetch(cursor, lane);
                 if (r >= total) state = ST_DONE;
                 else {
+                    r += first;
                     const float4 q0 = A.s_shadowq[2 * (size_t)r], q1 = A.s_shadowq[2 * (size_t)r + 1];
                     R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
                     R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;  // already normalised once; shadow rays skip shootRay (RayTracer.cpp:313-317)
@@ -285,10 +554,23 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shadow(const KernelArgs A)
             bool finished = false;
             do {
                 if (!traversal_step<COUNT>(L, R, A, cnt)) { finished = true; break; }
+                steps++;
             } while (--budget > 0);
             if (finished) {
                 A.s_occluded[r] = L.occluded ? 1 : 0;
+                steps = 0;
                 state = ST_FETCH;
+            } else if (A.step_budget && steps >= A.step_budget) {  // a long walk: hand it to heavy_trace_shadow
+                const unsigned long long em = __ballot(1);
+                uint32_t base = 0;
+                if ((em & ((1ull << lane) - 1ull)) == 0) base = atomicAdd(A.s_counts + SC_SHEAVY, (uint32_t)__popcll(em));
+                base = __shfl(base, __ffsll((long long)em) - 1);
+                const uint32_t slot = base + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
+                if (slot < A.s_heavy_cap) {
+                    A.s_sheavy[slot] = r;
+                    state = ST_FETCH;
+                }
+                steps = 0;
             }
         }
     }

@@ -194,15 +194,19 @@ int crt_read_quantized(crt_ctx *ctx, uint8_t *out_rgb8);
 /* Device time of the most recent render kernel, from the HIP events recorded around it on the stream
  * it was launched on (waits for that kernel to finish). */
 int crt_kernel_elapsed_ms(crt_ctx *ctx, double *ms);
-/* Device times of the most recent renders (up to 64, oldest first), from the HIP events recorded around
- * the kernels on the stream they were launched on; 3 doubles per render:
- *   [0] stream_trace_shade, all recursion levels  [1] stream_trace_shadow  [2] stream_resolve (+ fallback).
+/* Device times of the most recent renders (up to 64, oldest first), from HIP events recorded around the
+ * kernels on the streams they were launched on; 5 doubles per render:
+ *   [0] whole render, first kernel to last
+ *   [1] the recursion levels: stream_trace_shade + heavy_trace_closest + stream_shade_evicted, all levels
+ *   [2] stream_trace_shadow pass 0 (level-0 shadow rays; runs on a side stream BESIDE [1])
+ *   [3] stream_trace_shadow pass 1 + heavy_trace_shadow   [4] stream_resolve (+ fallback)
  * Waits for those kernels to finish. */
 int crt_kernel_times_ms(crt_ctx *ctx, double *out_phase_ms, uint32_t max_count, uint32_t *count);
 int crt_get_stats(crt_ctx *ctx, crt_stats *out);
 /* The counters of the last counted render split by kernel, in crt_stats order: box_tests, tri_tests,
  * leaf_index_reads, shaded_hits, light_evals, texel_fetches, primary_rays, secondary_rays, shadow_rays.
- * closest = stream_trace_shade (+ resolve), shadow = stream_trace_shadow. */
+ * closest = stream_trace_shade of all recursion levels, shadow = stream_trace_shadow pass 0 (the level-0 shadow
+ * rays); shadow pass 1 and the resolve are only in crt_stats' totals. */
 int crt_get_kernel_counters(crt_ctx *ctx, uint64_t closest[9], uint64_t shadow[9]);
 int crt_synchronize(crt_ctx *ctx);
 void crt_destroy(crt_ctx *ctx);

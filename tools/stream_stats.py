@@ -1,0 +1,17 @@
+"""Dev helper: per-level ray counts / evictions of the ray-stream pass on a full-size BASELINE scene."""
+import importlib, sys, ctypes as C
+sys.path.insert(0, '.')
+pkg = importlib.import_module('course-assignment-danielhalachev_amd'); sc = pkg.scenes
+name = sys.argv[1] if len(sys.argv) > 1 else 'hw14'
+s = sc.make(name); hs = pkg.Scene(json_text=sc.to_json(s)); tr = pkg.Tracer(hs)
+depth = sc.CONFIGS[name][3]
+for i in range(3):
+    tr.render(max_depth=depth)
+print('phase ms', tr.kernel_times_ms(3))
+out = (C.c_uint32 * 512)()
+L = pkg.lib(); L.crt_debug_stream_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]
+L.crt_debug_stream_counts(tr.ctx, out, 512)
+print('rays per level   ', [out[g] for g in range(depth + 2)])
+print('evicted per level', [out[128 + g] for g in range(depth + 1)])
+print('todo tiles', out[328], 'todo shadow slots', out[329], 'split', out[326])
+print('shadow rays', out[320], 'evicted shadow', out[323], 'overflow', out[322], 'guard', out[325])
