@@ -99,7 +99,7 @@ class Stats(C.Structure):
 # every symbol include/crt_hip.h and include/crt_host.h declare
 DEVICE_SYMBOLS = ["crt_create", "crt_set_camera", "crt_render", "crt_render_tiles_device", "crt_packed_tile_count",
                   "crt_unpack_tiles_device", "crt_quantize_device", "crt_read_quantized", "crt_kernel_elapsed_ms", "crt_kernel_times_ms",
-                  "crt_get_stats", "crt_get_kernel_counters", "crt_synchronize", "crt_destroy", "crt_last_error", "crt_device_count"]
+                  "crt_get_stats", "crt_get_kernel_counters", "crt_synchronize", "crt_destroy", "crt_last_error", "crt_device_count", "crt_test_pow5"]
 HOST_SYMBOLS = ["crt_host_scene_parse_file", "crt_host_scene_parse_text", "crt_host_scene_free", "crt_host_scene_desc",
                 "crt_host_scene_settings", "crt_host_scene_camera", "crt_host_scene_mesh_count",
                 "crt_host_tree_node_count", "crt_host_tree_index_total", "crt_host_tree_dump", "crt_host_mesh_sizes",
@@ -374,6 +374,18 @@ class Tracer:
         out = np.zeros((self.height, self.width, 3), dtype=np.uint8)
         self._check(lib().crt_read_quantized(self.ctx, _p(out)))
         return out
+
+
+def test_pow5(x, device=0):
+    """Device build of the restated glibc powf(x, 5) on a float32 array (unit-test hook)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(x)
+    L = lib()
+    L.crt_test_pow5.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]
+    rc = L.crt_test_pow5(device, _p(x), _p(out), x.size)
+    if rc != CRT_OK:
+        raise CrtError(rc, "crt_test_pow5 failed")
+    return out
 
 
 def device_count():

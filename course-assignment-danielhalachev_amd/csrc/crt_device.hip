@@ -54,6 +54,12 @@ __global__ void unpack_kernel(const float *packed, uint32_t n_parts, uint64_t pa
     dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
 }
 
+// unit-test kernel: the device build of csrc/glibc_powf.h
+__global__ void pow5_kernel(const float *x, float *out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = crt_pow5(x[i]);
+}
+
 // PPMColor (Color.cpp:12-16): (unsigned short)(std::clamp(c, 0.0f, 1.0f) * 255)
 __global__ void quantize_kernel(const float *rgb, uint64_t n, uint8_t *out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -141,6 +147,26 @@ static int upload(crt_ctx *ctx, const T *src, size_t count, const T **dst) {
     if (count) CRT_HIP_CHECK(ctx, hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
     *dst = (const T *)p;
     return CRT_OK;
+}
+
+// Unit-test hook: evaluates the device build of the restated glibc powf(x, 5) (csrc/glibc_powf.h) on host arrays.
+extern "C" int crt_test_pow5(int device, const float *x, float *out, uint64_t n) {
+    if (!x || !out) return CRT_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return CRT_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return CRT_ERR_HIP;
+    float *dx = nullptr, *dout = nullptr;
+    if (hipMalloc((void **)&dx, n * sizeof(float)) != hipSuccess) return CRT_ERR_NOMEM;
+    if (hipMalloc((void **)&dout, n * sizeof(float)) != hipSuccess) { (void)hipFree(dx); return CRT_ERR_NOMEM; }
+    int rc = CRT_OK;
+    if (hipMemcpy(dx, x, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = CRT_ERR_HIP;
+    if (rc == CRT_OK && n) {
+        hipLaunchKernelGGL(pow5_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, dx, dout, n);
+        if (hipGetLastError() != hipSuccess || hipMemcpy(out, dout, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = CRT_ERR_HIP;
+    }
+    (void)hipFree(dx);
+    (void)hipFree(dout);
+    return rc;
 }
 
 extern "C" int crt_device_count(void) {

@@ -214,6 +214,9 @@ void crt_destroy(crt_ctx *ctx);
 const char *crt_last_error(const crt_ctx *ctx);
 int crt_device_count(void);
 
+/* Test hook: out[i] = the device build of the restated glibc powf(x[i], 5) (the Fresnel term, RayTracer.cpp:407). */
+int crt_test_pow5(int device, const float *x, float *out, uint64_t n);
+
 #ifdef __cplusplus
 }
 #endif
