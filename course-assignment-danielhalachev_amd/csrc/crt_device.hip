@@ -191,7 +191,7 @@ static int validate_scene(const crt_scene_desc *s, std::string &err) {
     for (uint32_t i = 0; i < s->n_nodes; i++) {
         const crt_node &n = s->nodes[i];
         if (n.miss != CRT_LINK_END && (n.miss >= s->n_nodes || n.miss <= i)) return bad("node miss link must point forward");
-        if (n.link & CRT_LINK_LEAF) continue;
+        if (is_leaf_link(n.link)) continue;
         if (n.link != CRT_LINK_END && (n.link >= s->n_nodes || n.link <= i)) return bad("node hit link must point forward");
         if (n.link != CRT_LINK_END && n.miss != CRT_LINK_END && n.link > n.miss) return bad("node hit link beyond its miss link");
     }
@@ -230,7 +230,7 @@ static int validate_scene(const crt_scene_desc *s, std::string &err) {
     // builder's own tests pin the exact structure
     for (uint32_t i = 0; i < s->n_nodes; i++) {
         const crt_node &n = s->nodes[i];
-        if (!(n.link & CRT_LINK_LEAF)) continue;
+        if (!is_leaf_link(n.link)) continue;
         uint64_t b = n.link & ~CRT_LINK_LEAF;
         if (b >= s->n_leaf_triangles && b >= s->n_leaf_meshes) return bad("leaf begin out of range");
     }
@@ -330,7 +330,7 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
             std::vector<float4> level;  // 2 x float4 per entry
             for (uint32_t i = root; i < end; i++) {
                 const crt_node &n = s->nodes[i];
-                if (!(n.link & CRT_LINK_LEAF)) continue;
+                if (!is_leaf_link(n.link)) continue;
                 const uint32_t begin = n.link & ~CRT_LINK_LEAF;
                 uint32_t count = 0;
                 if (begin < s->n_leaf_triangles) {
@@ -420,7 +420,7 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
                 for (int a = 0; a < 3; a++)
                     if (!(c.lo[a] >= p.lo[a] && c.hi[a] <= p.hi[a])) nested = false;
             }
-            if (!(s->nodes[i].link & CRT_LINK_LEAF)) stack.push_back(i);
+            if (!is_leaf_link(s->nodes[i].link)) stack.push_back(i);
         }
         A.nested_boxes = nested ? 1u : 0u;
     }

@@ -19,6 +19,10 @@ enum : int { C_BOX = 0, C_TRI, C_LEAFIDX, C_HIT, C_LIGHT, C_TEXEL, C_PRIMARY, C_
 constexpr int C_PUBLIC = 9;
 constexpr int SC_OVERFLOW_WORD = 5 * 64 + 2;  // == SC_OVERFLOW of kernel_stream.h (static_assert there)
 
+// A node is a leaf when bit 31 of its link is set -- except the all-ones END value, which an inner node without
+// children (the root of an empty tree) carries as "nothing below, nothing after".
+__host__ __device__ __forceinline__ bool is_leaf_link(uint32_t link) { return (link & LEAF) != 0 && link != END; }
+
 struct DMaterial { float ax, ay, az, ior; uint32_t type, smooth; int32_t texture; uint32_t pad; };
 struct DTexture { uint32_t kind; float ax, ay, az, bx, by, bz, scalar; uint32_t w, h; uint64_t offset; };
 

@@ -147,7 +147,7 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const Ray &R, co
         const uint32_t miss = __float_as_uint(q0.w), link = __float_as_uint(q1.w);
         const bool hit = slab_test(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
         if (!hit) { ti = miss; continue; }
-        if (!(link & LEAF)) { ti = link; continue; }
+        if (!is_leaf_link(link)) { ti = link; continue; }
         uint32_t e = link & ~LEAF;
         for (;;) {
             const uint32_t ent = A.leaf_meshes[e++];

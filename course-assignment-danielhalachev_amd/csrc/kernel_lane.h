@@ -62,7 +62,7 @@ __device__ __forceinline__ bool traversal_step(LaneWalk &L, const Ray &R, const 
             const uint32_t miss = __float_as_uint(q0.w), link = __float_as_uint(q1.w);
             if (COUNT) cnt[C_BOX]++;
             const bool hit = slab_test(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
-            if (hit && (link & LEAF)) {
+            if (hit && is_leaf_link(link)) {
                 L.mleaf = link & ~LEAF;
                 L.mnode = miss;
             } else {
@@ -104,7 +104,7 @@ __device__ __forceinline__ bool traversal_step(LaneWalk &L, const Ray &R, const 
         const uint32_t miss = __float_as_uint(q0.w), link = __float_as_uint(q1.w);
         if (COUNT) cnt[C_BOX]++;
         const bool hit = slab_test(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
-        if (hit && (link & LEAF)) {
+        if (hit && is_leaf_link(link)) {
             L.tleaf = link & ~LEAF;
             L.tnode = miss;
         } else {

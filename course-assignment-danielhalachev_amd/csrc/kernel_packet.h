@@ -66,7 +66,7 @@ __device__ __forceinline__ void packet_walk_impl(const KernelArgs &A, const Ray 
         if (COUNT && act) cnt[C_BOX]++;
         if (TRACK && act && !hit) tres = miss;
         if (!__ballot(hit)) { ti = miss; continue; }
-        if (!(link & LEAF)) { ti = link; continue; }
+        if (!is_leaf_link(link)) { ti = link; continue; }
         uint32_t e = link & ~LEAF;
         for (;;) {  // meshes of this top-level leaf, in list order (KDTree.cpp:138-144)
             const uint32_t ent = leaf_meshes[e++];
@@ -91,7 +91,7 @@ __device__ __forceinline__ void packet_walk_impl(const KernelArgs &A, const Ray 
                     if (COUNT && nact) cnt[C_BOX]++;
                     if (TRACK && nact && !nhit) mres = nmiss;
                     if (!__ballot(nhit)) { i = nmiss; continue; }
-                    if (!(nlink & LEAF)) { i = nlink; continue; }
+                    if (!is_leaf_link(nlink)) { i = nlink; continue; }
                     uint32_t te = nlink & ~LEAF;
                     for (;;) {  // triangles of this leaf, in list order (KDTree.cpp:57-65)
                         budget--;

@@ -78,7 +78,7 @@ __device__ __forceinline__ bool lean_walk(LeanWalk &W, const Ray &R, const bool 
             const float4 q0 = N[0], q1 = N[1];
             const uint32_t miss = __float_as_uint(q0.w), link = __float_as_uint(q1.w);
             const bool hit = slab_test_no_parallel(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
-            const bool leaf = (link & LEAF) != 0;
+            const bool leaf = is_leaf_link(link);
             W.e = (hit && leaf) ? (link & ~LEAF) : NONE;
             W.n = (hit && !leaf) ? link : miss;
         } else {
@@ -111,7 +111,7 @@ __device__ __forceinline__ bool lean_walk(LeanWalk &W, const Ray &R, const bool 
                 const float4 q0 = N[0], q1 = N[1];
                 const uint32_t miss = __float_as_uint(q0.w), link = __float_as_uint(q1.w);
                 const bool hit = slab_test_no_parallel(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
-                const bool leaf = (link & LEAF) != 0;
+                const bool leaf = is_leaf_link(link);
                 W.tleaf = (hit && leaf) ? (link & ~LEAF) : NONE;
                 W.tnode = (hit && !leaf) ? link : miss;
             } else {

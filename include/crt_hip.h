@@ -38,7 +38,7 @@ enum { CRT_MAT_DIFFUSE = 0, CRT_MAT_REFLECTIVE = 1, CRT_MAT_CONSTANT = 2, CRT_MA
 enum { CRT_TEX_ALBEDO = 0, CRT_TEX_EDGES = 1, CRT_TEX_CHECKER = 2, CRT_TEX_BITMAP = 3 };
 
 #define CRT_LINK_END 0xFFFFFFFFu  /* "no next node" */
-#define CRT_LINK_LEAF 0x80000000u /* bit 31 of crt_node.link: the node is a leaf */
+#define CRT_LINK_LEAF 0x80000000u /* bit 31 of crt_node.link: the node is a leaf (unless link == CRT_LINK_END) */
 #define CRT_ENTRY_LAST 0x80000000u /* bit 31 of a leaf entry: last entry of its leaf */
 
 /* One node of the flattened ("threaded") two-level tree, 32 bytes.

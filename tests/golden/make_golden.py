@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the REAL reference (oracle/_ref/ref_render[_tex], compiled from
+/root/reference by oracle/Makefile).  Run in the development container only:
+
+    python tests/golden/make_golden.py
+
+Each fixture is DATA: the scene (CRTS blob, see oracle/scene_blob.h), the options, and the reference's
+float colour buffer for it; `hw07_ppm` additionally holds the bytes of the PPM file the reference's own
+exportPPM wrote.  The reference has no tests or golden vectors of its own, so these frames
+are what pins the oracle (tests/test_golden.py) and, through it, the GPU path.
+"""
+import gzip
+import hashlib
+import importlib
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import small_case  # noqa: E402
+from oracle import oracle_api as oa  # noqa: E402
+
+sc = importlib.import_module("course-assignment-danielhalachev_amd").scenes
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    oa.build()
+    for name in ("hw07", "hw08", "hw11", "hw14", "hw12"):
+        scene, depth, _ = small_case(sc, name)
+        blob = sc.to_blob(scene)
+        ppm = None
+        with tempfile.TemporaryDirectory() as td:
+            ppm_path = os.path.join(td, "out.ppm") if name == "hw07" else None
+            rgb, info = oa.reference_render(blob, max_depth=depth, ppm_path=ppm_path)
+            if ppm_path:
+                ppm = open(ppm_path, "rb").read()
+        # the three tree modes must agree; pin that too
+        rgb_bvh, _ = oa.reference_render(blob, max_depth=depth, mode="bvh")
+        assert np.array_equal(rgb.view(np.uint32), rgb_bvh.view(np.uint32))
+        out = {"blob": np.frombuffer(blob, dtype=np.uint8), "depth": np.int32(depth), "rgb": rgb,
+               "json_sha256": np.frombuffer(hashlib.sha256(sc.to_json(scene).encode()).digest(), dtype=np.uint8)}
+        if ppm is not None:
+            out["ppm_gz"] = np.frombuffer(gzip.compress(ppm, 9), dtype=np.uint8)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, rgb.shape, "depth", depth, "blob", len(blob), "bytes")
+    # a partial-coverage case: bucket count 7 on a 100x60 frame leaves pixels unrendered
+    scene = sc.make("hw08", width=100, height=60, detail=0.3)
+    scene["settings"]["image_settings"]["bucket_size"] = 7
+    blob = sc.to_blob(scene)
+    rgb, _ = oa.reference_render(blob, max_depth=1)
+    np.savez_compressed(os.path.join(HERE, "coverage.npz"), blob=np.frombuffer(blob, dtype=np.uint8), depth=np.int32(1),
+                        rgb=rgb)
+    print("coverage", rgb.shape, "unrendered pixels:", int((rgb.sum(axis=2) == 0).sum()))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,27 +1,207 @@
-"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle on the same inputs.
-Bar: bit-exact floats (stricter than the 1e-5 north-star tolerance) and identical work counters."""
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle and the committed reference
+fixtures on the same inputs.  Bar: bit-exact floats (stricter than the 1e-5 north-star tolerance), identical
+quantised bytes, identical work counters."""
+import os
+
 import numpy as np
 import pytest
 
-from helpers import assert_same_floats, small_case
+from helpers import assert_same_floats, blob_to_scene, load_golden, small_case
 
 pytestmark = pytest.mark.gpu
 
+CONFIGS = ["hw07", "hw08", "hw11", "hw14", "hw12"]
 
-@pytest.mark.parametrize("name", ["hw07", "hw08", "hw11", "hw14", "hw12"])
+
+def make_tracer(pkg, scenes, scene, folder=""):
+    if scene.get("textures") and folder:
+        scenes.write_bitmaps(scene, folder)
+    return pkg.Tracer(pkg.Scene(json_text=scenes.to_json(scene), folder=folder))
+
+
+@pytest.mark.parametrize("name", CONFIGS)
 def test_frame_matches_oracle(pkg, scenes, oracle, name, tmp_path):
     scene, depth, folder = small_case(scenes, name, tmp_path)
-    hs = pkg.Scene(json_text=scenes.to_json(scene), folder=folder)
-    tracer = pkg.Tracer(hs)
-    got = tracer.render(max_depth=depth, counters=True)
+    tracer = make_tracer(pkg, scenes, scene, folder)
+    got = tracer.render(max_depth=depth, counters=True)   # counting build: every ray walked the reference's way
     stats = tracer.stats()
     want, counters = oracle.OracleScene(scenes.to_blob(scene)).render(depth)
     assert_same_floats(got, want, name)
     assert stats.counters_valid == 1
     assert stats.counters() == counters
-    # the non-counting build of the kernel must give the same pixels
-    again = tracer.render(max_depth=depth)
-    assert_same_floats(again, want, name + " (plain kernel)")
-    # quantised bytes (PPMColor) from the device
-    q = tracer.read_quantized()
+    again = tracer.render(max_depth=depth)                # production build: lean walk + heavy_trace
+    assert_same_floats(again, want, name + " (production kernels)")
+    q = tracer.read_quantized()                           # PPMColor on the device
     assert np.array_equal(q.astype(np.uint16), oracle.quantize(want))
+
+
+@pytest.mark.parametrize("name", CONFIGS + ["coverage"])
+def test_frame_matches_reference_fixture(pkg, scenes, name, tmp_path):
+    g = load_golden(name)
+    scene = blob_to_scene(g["blob"])
+    tracer = make_tracer(pkg, scenes, scene, str(tmp_path))
+    got = tracer.render(max_depth=g["depth"])
+    assert_same_floats(got, g["rgb"], name)               # the REAL reference's frame, bit for bit
+
+
+def test_ppm_file_matches_reference_bytes(pkg, scenes, tmp_path):
+    g = load_golden("hw07")
+    tracer = make_tracer(pkg, scenes, blob_to_scene(g["blob"]))
+    path = str(tmp_path / "frame.ppm")
+    tracer.render(max_depth=g["depth"], ppm_path=path)    # RayTracer::render(pathToImage, ...) writes the file
+    assert open(path, "rb").read() == g["ppm"]
+
+
+@pytest.mark.parametrize("env", [
+    {"CRT_MODE": "lanes"},                                             # recursive one-ray-per-lane kernel for every pixel
+    {"CRT_MODE": "packets"},                                           # wave-per-tile packets + lanes for the deferred pixels
+    {"CRT_STEP_BUDGET": "8", "CRT_SHADOW_BUDGET": "8"},                # nearly every walk through heavy_trace
+    {"CRT_STEP_BUDGET": "0"},                                          # heavy_trace off: faithful stream kernels
+    {"CRT_HEAVY_LEVEL": "1000000"},                                    # deeper levels entirely by heavy_trace
+    {"CRT_PACKET_BUDGET": "60", "CRT_STEP_BUDGET": "64"},              # level 0 by packets, most walks abandoned to the stream
+    {"CRT_PACKET_BUDGET": "100000"},                                   # level 0 by packets, nothing abandoned
+    {"CRT_SIDE_BLOCKS": "0"},                                          # no side stream
+])
+@pytest.mark.parametrize("name", ["hw11", "hw12", "hw14"])
+def test_every_kernel_path_gives_the_same_frame(pkg, scenes, oracle, name, env, tmp_path, monkeypatch):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)                          # read by crt_create
+    scene, depth, folder = small_case(scenes, name, tmp_path)
+    tracer = make_tracer(pkg, scenes, scene, folder)
+    got = tracer.render(max_depth=depth)
+    want, _ = oracle.OracleScene(scenes.to_blob(scene)).render(depth)
+    assert_same_floats(got, want, "%s %r" % (name, env))
+
+
+def test_depth_rule_and_bias_options(pkg, scenes, oracle):
+    scene, _, _ = small_case(scenes, "hw11")
+    tracer = make_tracer(pkg, scenes, scene)
+    o = oracle.OracleScene(scenes.to_blob(scene))
+    for depth in (0, 1, 2, 5):                            # depth == MAX_DEPTH is traced, depth > MAX_DEPTH is background
+        assert_same_floats(tracer.render(max_depth=depth), o.render(depth)[0], "depth %d" % depth)
+    opts = pkg.make_options(3, shadow_bias=1e-3, reflection_bias=2e-4, refraction_bias=5e-4)
+    want, _ = o.render(3, options=oracle.make_options(3, 1e-3, 2e-4, 5e-4))
+    assert_same_floats(tracer.render(options=opts), want, "biases")
+
+
+def test_camera_updates_keep_the_scene_resident(pkg, scenes, oracle):
+    # the animation driver's loop (app/animation.cpp:24-38): new camera, same tracer
+    scene, depth, _ = small_case(scenes, "hw14")
+    tracer = make_tracer(pkg, scenes, scene)
+    o = oracle.OracleScene(scenes.to_blob(scene))
+    pos0, mat0 = np.array(scene["camera"]["position"], dtype=np.float32), np.array(scene["camera"]["matrix"], dtype=np.float32)
+    for deg in (0.0, 17.5, -40.0):
+        pos, mat = pkg.camera_apply(pos0, mat0, "pan", deg)
+        pos, mat = pkg.camera_apply(pos, mat, "truck", [0.1, 0.05, -0.3])
+        tracer.set_camera(pos, mat)
+        o.set_camera(pos, mat)
+        assert_same_floats(tracer.render(max_depth=depth), o.render(depth)[0], "pan %g" % deg)
+
+
+def test_uncovered_pixels_keep_their_previous_value(pkg, scenes, oracle):
+    # bucket_size 7 on 100x60 covers only part of the frame; the colour buffer persists between renders
+    scene = scenes.make("hw08", width=100, height=60, detail=0.3)
+    scene["settings"]["image_settings"]["bucket_size"] = 7
+    tracer = make_tracer(pkg, scenes, scene)
+    o = oracle.OracleScene(scenes.to_blob(scene))
+    first = tracer.render(max_depth=1)
+    want = o.render(1)[0]
+    assert_same_floats(first, want, "partial coverage")
+    full = tracer.render(max_depth=1, optimization=pkg.OPT_BVH)           # one rectangle: the whole frame
+    pos, mat = pkg.camera_apply(scene["camera"]["position"], scene["camera"]["matrix"], "pan", 25.0)
+    tracer.set_camera(pos, mat)
+    o.set_camera(pos, mat)
+    mixed = tracer.render(max_depth=1)                                    # partial again: uncovered pixels keep `full`
+    covered = np.zeros((60, 100), dtype=bool)
+    for row, col, w, h in oracle.bucket_grid(100, 60, 7):
+        covered[row:min(60, row + h), col:min(100, col + w)] = True
+    moved = o.render(1, buffer=np.ascontiguousarray(full.copy()))[0]
+    assert_same_floats(mixed, moved, "persistence")
+    assert np.array_equal(mixed[~covered], full[~covered]) and not np.array_equal(mixed[covered], full[covered])
+
+
+def test_empty_and_degenerate_scenes(pkg, scenes, oracle):
+    # no objects at all; a mesh with a degenerate (zero-area) triangle; a constant-material mesh; no lights
+    base = scenes.make("hw07", width=48, height=32, detail=0.3)
+    empty = dict(base, objects=[])
+    t = make_tracer(pkg, scenes, empty)
+    assert_same_floats(t.render(max_depth=2), oracle.OracleScene(scenes.to_blob(empty)).render(2)[0], "empty scene")
+    const = dict(base, materials=[{"type": "constant", "albedo": [1, 0, 0], "smooth_shading": False}])
+    t = make_tracer(pkg, scenes, const)
+    assert_same_floats(t.render(max_depth=2), oracle.OracleScene(scenes.to_blob(const)).render(2)[0], "constant material")
+    dark = dict(base, lights=[])
+    t = make_tracer(pkg, scenes, dark)
+    assert_same_floats(t.render(max_depth=2), oracle.OracleScene(scenes.to_blob(dark)).render(2)[0], "no lights")
+    odd = scenes.make("hw08", width=50, height=30, detail=0.3)           # frame not a multiple of the 8x8 tile
+    t = make_tracer(pkg, scenes, odd)
+    assert_same_floats(t.render(max_depth=1), oracle.OracleScene(scenes.to_blob(odd)).render(1)[0], "ragged tiles")
+
+
+def test_axis_parallel_rays(pkg, scenes, oracle):
+    # camera square-on to the room: rays through the image centre column/row have direction components below
+    # FLT_EPSILON only for odd sizes; an odd frame makes the centre pixel's x and y exactly 0 -> the parallel-axis
+    # branch of the box test (BoundingBox.h:90-93) and shadow rays straight up from the floor under a light
+    scene = scenes.make("hw11", width=65, height=37, detail=0.2)
+    scene["lights"].append({"intensity": 20, "position": [0.0, 2.0, -4.0]})
+    scene["camera"]["position"] = [0.0, 0.0, 0.5]
+    t = make_tracer(pkg, scenes, scene)
+    assert_same_floats(t.render(max_depth=4), oracle.OracleScene(scenes.to_blob(scene)).render(4)[0], "axis-parallel rays")
+
+
+# ---------------------------------------------------------------------------------------------- full-size properties
+@pytest.fixture(scope="module")
+def full_hw14(pkg, scenes):
+    scene = scenes.make("hw14")                                           # 1920x1080, ~208k triangles
+    tracer = pkg.Tracer(pkg.Scene(json_text=scenes.to_json(scene)))
+    return scene, tracer
+
+
+def test_full_size_render_is_reproducible_and_quantises(full_hw14, oracle):
+    scene, tracer = full_hw14
+    a = tracer.render(max_depth=8).copy()
+    b = tracer.render(max_depth=8)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))           # no run-to-run variation (no float atomics)
+    assert np.isfinite(a).all()
+    q = tracer.read_quantized()
+    assert np.array_equal(q.astype(np.uint16), oracle.quantize(a))        # device quantiser == PPMColor rule
+    assert len(np.unique(q.reshape(-1, 3), axis=0)) > 1000                # an actual image, not a constant
+
+
+def test_full_size_tile_partition_reassembles_the_frame(pkg, full_hw14):
+    import torch
+    scene, tracer = full_hw14
+    want = tracer.render(max_depth=8).copy()
+    tiles = __import__("importlib").import_module("course-assignment-danielhalachev_amd.tiles")
+    W, H, world = tracer.width, tracer.height, 4
+    per = tiles.tiles_per_rank(W, H, world)
+    dev = torch.device("cuda", 0)
+    gathered = torch.zeros(world * per * 192, dtype=torch.float32, device=dev)
+    frame = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
+    opts = pkg.make_options(8)
+    for rank in range(world):                                             # the four "GPUs" one after another on this one
+        part = gathered[rank * per * 192:(rank + 1) * per * 192]
+        tracer.render_tiles_device(opts, rank, world, part.data_ptr())
+        torch.cuda.synchronize()
+    tracer.unpack_tiles_device(gathered.data_ptr(), world, per * 192, frame.data_ptr())
+    torch.cuda.synchronize()
+    got = frame.cpu().numpy().reshape(H, W, 3)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # and the numpy mirror of the packed layout agrees with the device kernels
+    host = tiles.unpack_tiles(gathered.cpu().numpy().reshape(world, per, 64, 3), W, H, world)
+    assert np.array_equal(host.view(np.uint32), want.view(np.uint32))
+
+
+def test_full_size_sample_against_oracle(full_hw14, oracle, scenes):
+    # the oracle is too slow for the whole 1080p frame in a test, so check a band of rows: same scene, same camera
+    scene, tracer = full_hw14
+    got = tracer.render(max_depth=8)
+    o = oracle.OracleScene(scenes.to_blob(scene))
+    band = dict(scene)
+    rows = slice(520, 544)                                                # 24 rows through the knot and both spheres
+    buf = np.zeros((1080, 1920, 3), dtype=np.float32)
+    # render only those rows with the oracle by giving it a one-bucket grid covering them: emulate via per-ray shoots
+    for row in range(rows.start, rows.stop, 4):
+        for col in range(0, 1920, 3):
+            org, d = o.camera_ray(row, col)
+            buf[row, col] = o.shoot(org, d, ray_type=0, depth=0, max_depth=8)
+            assert np.array_equal(buf[row, col].view(np.uint32), got[row, col].view(np.uint32)), (row, col)
