@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="development only: N processes share GPU 0 and gather through gloo on host buffers "
+                         "(exercises the multi-rank code path on a one-GPU box; its numbers mean nothing)")
     args = ap.parse_args()
 
     import numpy as np
@@ -99,11 +102,16 @@ def main():
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    if args.rehearse_gloo:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.rehearse_gloo:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     pkg = importlib.import_module("course-assignment-danielhalachev_amd")
     sc = pkg.scenes
@@ -130,7 +138,11 @@ def main():
 
     def step():
         tracer.render_tiles_device(opts, rank, world, packed.data_ptr(), sptr)
-        if world > 1:
+        if world > 1 and args.rehearse_gloo:
+            parts = [torch.empty(part_floats) for _ in range(world)]
+            dist.all_gather(parts, packed.cpu())
+            gathered.copy_(torch.cat(parts))
+        elif world > 1:
             dist.all_gather_into_tensor(gathered, packed)
         if rank == 0:
             tracer.unpack_tiles_device(gathered.data_ptr(), world, part_floats, frame.data_ptr(), sptr)
@@ -157,8 +169,9 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms = tracer.kernel_times_ms(min(args.steps, 64))
+    cdev = torch.device("cpu") if args.rehearse_gloo else dev
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -175,7 +188,7 @@ def main():
     fence()
     d2h_elapsed = (time.perf_counter() - t1) / min(args.steps, 5)
     if world > 1:
-        t = torch.tensor([d2h_elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([d2h_elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         d2h_elapsed = float(t.item())
 
@@ -235,6 +248,11 @@ def main():
             except Exception as e:  # the baseline is a reported extra; never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
+        if args.rehearse_gloo:
+            # rehearsal: check the reassembled frame against a single-rank render of the same scene
+            ref = tracer.render(max_depth=depth)
+            same = bool(np.array_equal(frame.cpu().numpy().reshape(H, W, 3).view(np.uint32), ref.view(np.uint32)))
+            out["rehearsal_frame_matches_single_rank"] = same
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
