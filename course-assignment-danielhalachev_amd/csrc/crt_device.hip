@@ -114,6 +114,9 @@ struct crt_ctx {
     uint32_t shadow_budget = 4096;    // CRT_SHADOW_BUDGET: same for shadow walks (one big launch: only its tail matters)
     uint32_t heavy_level_threshold = 0;  // CRT_HEAVY_LEVEL: levels with fewer rays go to heavy_trace whole
     bool lean_ok = true;              // 32-bit byte offsets reach every node and leaf entry
+    uint32_t use_quads = 7;           // CRT_QUAD: which lean kernels walk quad nodes (bit 0 levels, 1 shadow pass 0, 2 shadow pass 1)
+    uint32_t quad_stack_depth = 16;   // CRT_QUAD_STACK
+    uint32_t n_quads = 0;
     uint32_t side_blocks_per_cu = 4;  // CRT_SIDE_BLOCKS: blocks per CU of the overlapped shadow pass
     uint32_t debug_skip = 0;          // CRT_DEBUG_SKIP: development only, skips heavy-path launches
     uint64_t stream_items = 0;        // work items the stream buffers are sized for
@@ -371,6 +374,75 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
         if (upload(ctx, hbox.data(), hbox.size(), &A.hbox)) return fail(CRT_ERR_HIP);
         if (upload(ctx, hm.data(), hm.size(), &A.hmesh)) return fail(CRT_ERR_HIP);
     }
+    {
+        // Quad nodes of the mesh trees (kernel_walk.h).  quad(i) for an inner node i: its children in visit order
+        // -- link(i) first, then that child's miss link unless it already leaves i's subtree -- and, while fewer
+        // than four slots are filled, the inner slot with the largest box replaced by its own children, in place.
+        std::vector<float4> quads;
+        std::vector<uint32_t> qroots(s->n_meshes, 0);
+        struct Builder {
+            const crt_scene_desc *s;
+            std::vector<float4> &quads;
+            void children(uint32_t i, std::vector<uint32_t> &out) const {
+                const crt_node &n = s->nodes[i];
+                if (is_leaf_link(n.link) || n.link == CRT_LINK_END) return;
+                const uint32_t c1 = n.link;
+                out.push_back(c1);
+                const uint32_t c2 = s->nodes[c1].miss;
+                if (c2 != n.miss && c2 != CRT_LINK_END) out.push_back(c2);
+            }
+            static float area(const crt_node &n) {
+                const float dx = n.hi[0] - n.lo[0], dy = n.hi[1] - n.lo[1], dz = n.hi[2] - n.lo[2];
+                return dx * dy + dy * dz + dz * dx;
+            }
+            bool too_deep = false;
+            uint32_t build(std::vector<uint32_t> slots, int depth = 0) {
+                if (depth > 128) { too_deep = true; return NONE; }  // not a tree the reference's builder makes (depth <= 25)
+                for (;;) {
+                    if (slots.size() >= 4) break;
+                    int pick = -1;
+                    float best = -1.0f;
+                    for (size_t k = 0; k < slots.size(); k++) {
+                        const crt_node &n = s->nodes[slots[k]];
+                        if (is_leaf_link(n.link)) continue;
+                        const float a = area(n);
+                        if (pick < 0 || a > best) { pick = (int)k; best = a; }
+                    }
+                    if (pick < 0) break;
+                    std::vector<uint32_t> kids;
+                    children(slots[pick], kids);
+                    slots.erase(slots.begin() + pick);
+                    slots.insert(slots.begin() + pick, kids.begin(), kids.end());
+                }
+                const uint32_t q = (uint32_t)(quads.size() / 8);
+                quads.resize(quads.size() + 8, make_float4(0, 0, 0, 0));
+                float box[6][4];
+                uint32_t link[4] = {NONE, NONE, NONE, NONE};
+                for (int k = 0; k < 4; k++) for (int a = 0; a < 6; a++) box[a][k] = 0.0f;
+                for (size_t k = 0; k < slots.size(); k++) {
+                    const crt_node &n = s->nodes[slots[k]];
+                    for (int a = 0; a < 3; a++) { box[a][k] = n.lo[a]; box[3 + a][k] = n.hi[a]; }
+                    if (is_leaf_link(n.link)) {
+                        link[k] = n.link;  // LEAF + first entry
+                    } else {
+                        std::vector<uint32_t> kids;
+                        children(slots[k], kids);
+                        link[k] = build(kids, depth + 1);
+                    }
+                }
+                for (int a = 0; a < 6; a++) quads[(size_t)q * 8 + a] = make_float4(box[a][0], box[a][1], box[a][2], box[a][3]);
+                float lb[4];
+                memcpy(lb, link, 16);
+                quads[(size_t)q * 8 + 6] = make_float4(lb[0], lb[1], lb[2], lb[3]);
+                return q;
+            }
+        } builder{s, quads};
+        for (uint32_t m = 0; m < s->n_meshes; m++) qroots[m] = builder.build(std::vector<uint32_t>{s->meshes[m].root});
+        ctx->n_quads = (uint32_t)(quads.size() / 8);
+        if (builder.too_deep || quads.size() / 8 >= (1u << 24)) ctx->use_quads = 0;
+        if (upload(ctx, quads.data(), quads.size(), &A.quads)) return fail(CRT_ERR_HIP);
+        if (upload(ctx, qroots.data(), qroots.size(), &A.quad_roots)) return fail(CRT_ERR_HIP);
+    }
     if (upload(ctx, s->triangle_vertices, (size_t)s->n_triangles * 3, &A.tri_verts)) return fail(CRT_ERR_HIP);
     if (upload(ctx, s->vertex_normals, (size_t)s->n_vertices * 3, &A.vnormals)) return fail(CRT_ERR_HIP);
     if (s->vertex_uvs) {
@@ -451,6 +523,12 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
         const char *hl = getenv("CRT_HEAVY_LEVEL");
         if (hl) ctx->heavy_level_threshold = (uint32_t)strtoul(hl, nullptr, 10);
         ctx->lean_ok = s->n_nodes < (1u << 27) && s->n_leaf_triangles < (1ull << 26);
+        const char *qd = getenv("CRT_QUAD");
+        if (qd && ctx->use_quads) ctx->use_quads = (uint32_t)atoi(qd) & 7u;
+        const char *qs = getenv("CRT_QUAD_STACK");
+        if (qs) ctx->quad_stack_depth = (uint32_t)atoi(qs);
+        if (ctx->quad_stack_depth < 4) ctx->quad_stack_depth = 4;
+        if (ctx->quad_stack_depth > 60) ctx->quad_stack_depth = 60;  // 60 KB of the workgroup's 64 KB
         const char *sbl = getenv("CRT_SIDE_BLOCKS");
         if (sbl) ctx->side_blocks_per_cu = (uint32_t)strtoul(sbl, nullptr, 10);
         const char *sb = getenv("CRT_SHADOW_BUDGET");
@@ -604,6 +682,10 @@ template <typename K, typename... Args>
 static void launch(K kernel, uint32_t blocks, hipStream_t stream, Args... args) {
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK), 0, stream, args...);
 }
+template <typename K, typename... Args>
+static void launch_lds(K kernel, uint32_t blocks, uint32_t lds_bytes, hipStream_t stream, Args... args) {
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK), lds_bytes, stream, args...);
+}
 
 static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, float *d_out, uint32_t packed,
                          hipStream_t stream, bool timed) {
@@ -651,6 +733,9 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         A.debug = ctx->debug_skip;
         A.heavy_level_threshold = ctx->heavy_level_threshold;
         const bool lean = heavy && ctx->lean_ok && !(ctx->debug_skip & 256u);
+        const uint32_t quad = lean ? ctx->use_quads : 0u;  // bit 0: the levels, bit 1: shadow pass 0, bit 2: shadow pass 1
+        A.quad_stack_depth = ctx->quad_stack_depth;
+        const uint32_t qlds = ctx->quad_stack_depth * BLOCK * (uint32_t)sizeof(uint32_t);
         const uint32_t heavy_blocks = ctx->grid_blocks < 1024u ? ctx->grid_blocks : 1024u;
         const bool packets = lean && ctx->packet_budget != 0 && !(ctx->debug_skip & 512u);
         if (packets) {
@@ -665,7 +750,8 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         S.step_budget = heavy ? ctx->shadow_budget : 0u;
         for (uint32_t g = 0; g <= o->max_depth; g++) {
             if (count) launch(stream_trace_shade<true>, lane_blocks, stream, A, g);
-            else if (lean) launch(stream_trace_shade_lean, lane_blocks, stream, A, g);
+            else if (lean && (quad & 1u)) launch_lds(stream_trace_shade_lean<true>, lane_blocks, qlds, stream, A, g);
+            else if (lean) launch(stream_trace_shade_lean<false>, lane_blocks, stream, A, g);
             else launch(stream_trace_shade<false>, lane_blocks, stream, A, g);
             if (heavy) {
                 if (!(ctx->debug_skip & 1u)) launch(heavy_trace_closest, heavy_blocks, stream, A, g);
@@ -680,7 +766,8 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
                 // its persistent waves must leave wave slots on every CU for the level kernels running beside it
                 const uint32_t side_blocks = (uint32_t)ctx->num_cus * ctx->side_blocks_per_cu;
                 if (count) launch(stream_trace_shadow<true>, side_blocks, ctx->side, S, 0u);
-                else if (lean) launch(stream_trace_shadow_lean<0>, side_blocks, ctx->side, S);
+                else if (lean && (quad & 2u)) launch_lds(stream_trace_shadow_lean<0, true>, side_blocks, qlds, ctx->side, S);
+                else if (lean) launch(stream_trace_shadow_lean<0, false>, side_blocks, ctx->side, S);
                 else launch(stream_trace_shadow<false>, side_blocks, ctx->side, S, 0u);
                 CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s1[slot], ctx->side));
             }
@@ -690,7 +777,8 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         if (!ctx->side_blocks_per_cu) {  // no overlap: pass 0 here, on the caller's stream
             CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s0[slot], stream));
             if (count) launch(stream_trace_shadow<true>, ctx->grid_blocks, stream, S, 0u);
-            else if (lean) launch(stream_trace_shadow_lean<0>, ctx->grid_blocks, stream, S);
+            else if (lean && (quad & 2u)) launch_lds(stream_trace_shadow_lean<0, true>, ctx->grid_blocks, qlds, stream, S);
+            else if (lean) launch(stream_trace_shadow_lean<0, false>, ctx->grid_blocks, stream, S);
             else launch(stream_trace_shadow<false>, ctx->grid_blocks, stream, S, 0u);
             CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s1[slot], stream));
         }
@@ -699,7 +787,8 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         S.counters = ctx->d_counters + 2 * C_N;
         S.step_budget = heavy ? ctx->step_budget : 0u;  // few rays: all tail, so the short budget of the levels
         if (count) launch(stream_trace_shadow<true>, lane_blocks, stream, S, 1u);
-        else if (lean) launch(stream_trace_shadow_lean<1>, lane_blocks, stream, S);
+        else if (lean && (quad & 4u)) launch_lds(stream_trace_shadow_lean<1, true>, lane_blocks, qlds, stream, S);
+        else if (lean) launch(stream_trace_shadow_lean<1, false>, lane_blocks, stream, S);
         else launch(stream_trace_shadow<false>, lane_blocks, stream, S, 1u);
         if (heavy && !(ctx->debug_skip & 4u)) launch(heavy_trace_shadow, heavy_blocks, stream, S);
         CRT_HIP_CHECK(ctx, hipGetLastError());

@@ -95,6 +95,11 @@ struct KernelArgs {
     uint32_t *s_todo_tiles;       // work items whose primary packet walk was abandoned
     uint32_t *s_todo_shadow;      // shadow-queue slots whose packet walk was abandoned
     uint32_t debug;               // development switches
+    // quad nodes of the mesh trees (kernel_walk.h): 128 bytes each = {lo.x[4]} {lo.y[4]} {lo.z[4]} {hi.x[4]} {hi.y[4]} {hi.z[4]}
+    // {slot links: quad index | LEAF + first leaf entry | NONE} {unused}
+    const float4 *quads;
+    const uint32_t *quad_roots;   // per mesh
+    uint32_t quad_stack_depth;    // words of LDS stack per lane
 };
 
 // ---------------------------------------------------------------------------------------------

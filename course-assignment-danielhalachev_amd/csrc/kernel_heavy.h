@@ -27,19 +27,31 @@ struct HeavyState {   // all wave-uniform
     uint32_t guard;   // remaining loop iterations for this ray: every loop of the walk is bounded by it
 };
 
-__device__ __forceinline__ float wave_min(float v) {
-    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
-    return v;
+// Cross-lane helpers on the DPP / readlane paths (a ds_bpermute round trip per step is what the walk would
+// otherwise wait on: every step of it is wave-uniform control flow around one reduction).
+__device__ __forceinline__ float lane_value(float v, int lane_uniform) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_uniform));
+}
+__device__ __forceinline__ uint32_t lane_value(uint32_t v, int lane_uniform) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, lane_uniform);
 }
 
-__device__ __forceinline__ uint32_t wave_prefix_exclusive(uint32_t v, uint32_t lane, uint32_t &total) {
-    uint32_t incl = v;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_up(incl, off);
-        if (lane >= (uint32_t)off) incl += o;
-    }
-    total = __shfl(incl, 63);
-    return incl - v;
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_min_step(float v) {
+    // lanes without a source (or outside ROW_MASK) read their own value back: min(v, v) = v
+    const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+    return fminf(v, o);
+}
+
+// minimum over the wave, returned uniformly (NaNs never reach it: callers pass +inf for "no value")
+__device__ __forceinline__ float wave_min(float v) {
+    v = dpp_min_step<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_min_step<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_min_step<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_min_step<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds its row's minimum
+    v = dpp_min_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_min_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's minimum
+    return lane_value(v, 63);
 }
 
 // One batch of up to 64 triangles (lane j tests list entry e when `valid`), lanes in list order.
@@ -53,8 +65,8 @@ __device__ __forceinline__ void heavy_batch(const KernelArgs &A, const Ray &R, c
     if (!H.mhave) {  // `closest = intersections[0]`: the first accepted hit in list order, whatever its distance
         const int first = __ffsll((long long)am) - 1;
         H.mhave = true;
-        H.mt = __shfl(t, first);
-        H.mtri = __shfl(__float_as_uint(d.y), first);
+        H.mt = lane_value(t, first);
+        H.mtri = lane_value(__float_as_uint(d.y), first);
     }
     const float key = (acc && t < INFINITY) ? t : INFINITY;  // +inf / NaN distances never win `d < min`
     const float mn = wave_min(key);
@@ -62,51 +74,70 @@ __device__ __forceinline__ void heavy_batch(const KernelArgs &A, const Ray &R, c
         const unsigned long long wm = __ballot(acc && key == mn);
         const int w = __ffsll((long long)wm) - 1;
         H.mmin = mn;
-        H.mt = __shfl(t, w);
-        H.mtri = __shfl(__float_as_uint(d.y), w);
+        H.mt = lane_value(t, w);
+        H.mtri = lane_value(__float_as_uint(d.y), w);
     }
 }
 
 // The triangles of all leaves of one 64-leaf chunk whose box the ray passes (`hit` lanes: leaf = lane,
-// list [begin, begin+count)), concatenated in leaf order and tested 64 at a time.
+// list [begin, begin+count)), concatenated in leaf order and tested 64 at a time.  The concatenation is laid
+// over the lanes with wave-uniform arithmetic: `off` lanes of the batch under construction are taken.
 __device__ __forceinline__ void heavy_leaves(const KernelArgs &A, const Ray &R, const bool primary, const bool hit,
                                              const uint32_t begin, const uint32_t count, HeavyState &H, const uint32_t lane) {
-    uint32_t total = 0;
-    const uint32_t prefix = wave_prefix_exclusive(hit ? count : 0u, lane, total);
-    const unsigned long long hm = __ballot(hit);
-    for (uint32_t base = 0; base < total && H.guard; base += 64) {
+    unsigned long long m = __ballot(hit);
+    uint32_t off = 0, e = 0;
+    bool valid = false;
+    while (m && H.guard) {
         H.guard--;
-        const uint32_t j = base + lane;  // position in the concatenated list
-        uint32_t e = 0;
-        bool valid = false;
-        unsigned long long m = hm;
-        while (m) {  // a handful of leaves: find the one whose range holds j
-            const int k = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const uint32_t p = __shfl(prefix, k), cnt = __shfl(count, k), bg = __shfl(begin, k);
-            if (j >= p && j < p + cnt) { e = bg + (j - p); valid = true; }
+        const int k = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        uint32_t bg = lane_value(begin, k), cnt = lane_value(count, k);
+        while (cnt && H.guard) {  // a leaf longer than the free lanes continues in the next batch
+            const uint32_t take = cnt < 64u - off ? cnt : 64u - off;
+            if (lane >= off && lane < off + take) { e = bg + (lane - off); valid = true; }
+            off += take; bg += take; cnt -= take;
+            if (off == 64u) {
+                H.guard--;
+                heavy_batch(A, R, primary, valid, (size_t)e, H);
+                off = 0;
+                valid = false;
+            }
         }
-        heavy_batch(A, R, primary, valid, (size_t)e, H);
     }
+    if (off) heavy_batch(A, R, primary, valid, (size_t)e, H);
+}
+
+struct ChunkBoxes { float4 b0, b1; bool valid; };
+
+template <int LEVEL>
+__device__ __forceinline__ ChunkBoxes heavy_chunk_load(const KernelArgs &A, const HeavyMesh &M, const uint32_t chunk, const uint32_t lane) {
+    ChunkBoxes C;
+    const uint32_t idx = chunk * 64u + lane;
+    C.valid = idx < M.count[LEVEL];
+    const size_t at = (size_t)M.first[LEVEL] + (C.valid ? idx : 0u);
+    C.b0 = A.hbox[2 * at];
+    C.b1 = A.hbox[2 * at + 1];
+    return C;
 }
 
 template <int LEVEL>
 __device__ __forceinline__ void heavy_chunk(const KernelArgs &A, const Ray &R, const bool primary, const HeavyMesh &M,
-                                            const uint32_t chunk, HeavyState &H, const uint32_t lane) {
-    const uint32_t idx = chunk * 64u + lane;
-    const bool valid = idx < M.count[LEVEL];
-    const size_t at = (size_t)M.first[LEVEL] + (valid ? idx : 0u);
-    const float4 b0 = A.hbox[2 * at], b1 = A.hbox[2 * at + 1];
-    const bool hit = valid && slab_test(R, b0.x, b0.y, b0.z, b1.x, b1.y, b1.z);
+                                            const uint32_t chunk, const ChunkBoxes &C, HeavyState &H, const uint32_t lane) {
+    const bool hit = C.valid && slab_test(R, C.b0.x, C.b0.y, C.b0.z, C.b1.x, C.b1.y, C.b1.z);
     if constexpr (LEVEL == 0) {
-        if (__ballot(hit)) heavy_leaves(A, R, primary, hit, __float_as_uint(b0.w), __float_as_uint(b1.w), H, lane);
+        if (__ballot(hit)) heavy_leaves(A, R, primary, hit, __float_as_uint(C.b0.w), __float_as_uint(C.b1.w), H, lane);
     } else {
         unsigned long long m = __ballot(hit);
+        if (!m) return;
+        // the boxes of the next passing child chunk are requested before the current one is worked on
+        ChunkBoxes next = heavy_chunk_load<LEVEL - 1>(A, M, chunk * 64u + (uint32_t)(__ffsll((long long)m) - 1), lane);
         while (m && H.guard) {
             H.guard--;
             const int k = __ffsll((long long)m) - 1;
             m &= m - 1;
-            heavy_chunk<LEVEL - 1>(A, R, primary, M, chunk * 64u + (uint32_t)k, H, lane);
+            const ChunkBoxes cur = next;
+            if (m) next = heavy_chunk_load<LEVEL - 1>(A, M, chunk * 64u + (uint32_t)(__ffsll((long long)m) - 1), lane);
+            heavy_chunk<LEVEL - 1>(A, R, primary, M, chunk * 64u + (uint32_t)k, cur, H, lane);
         }
     }
 }
@@ -122,10 +153,10 @@ __device__ __forceinline__ void heavy_mesh(const KernelArgs &A, const Ray &R, co
     H.mt = 0;
     H.mtri = 0;
     switch (M.n_levels) {
-        case 1: heavy_chunk<0>(A, R, primary, M, 0, H, lane); break;
-        case 2: heavy_chunk<1>(A, R, primary, M, 0, H, lane); break;
-        case 3: heavy_chunk<2>(A, R, primary, M, 0, H, lane); break;
-        case 4: heavy_chunk<3>(A, R, primary, M, 0, H, lane); break;
+        case 1: heavy_chunk<0>(A, R, primary, M, 0, heavy_chunk_load<0>(A, M, 0, lane), H, lane); break;
+        case 2: heavy_chunk<1>(A, R, primary, M, 0, heavy_chunk_load<1>(A, M, 0, lane), H, lane); break;
+        case 3: heavy_chunk<2>(A, R, primary, M, 0, heavy_chunk_load<2>(A, M, 0, lane), H, lane); break;
+        case 4: heavy_chunk<3>(A, R, primary, M, 0, heavy_chunk_load<3>(A, M, 0, lane), H, lane); break;
         default: break;
     }
 }

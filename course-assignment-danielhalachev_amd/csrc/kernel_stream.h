@@ -292,7 +292,10 @@ __device__ __forceinline__ bool evict_ray(uint32_t *list, uint32_t cap, uint32_t
 
 // stream_trace_shade with the lean walk (kernel_walk.h): the non-counting build when heavy_trace is available.
 // Rays with a parallel axis and walks longer than step_budget go to heavy_trace_closest.
+template <bool QUAD>
 __global__ __launch_bounds__(BLOCK) void stream_trace_shade_lean(const KernelArgs A, const uint32_t gen) {
+    extern __shared__ uint32_t qstack[];  // QUAD: A.quad_stack_depth x BLOCK words
+    uint32_t *const stk = qstack + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     if (A.s_counts[SC_OVERFLOW]) return;
     const uint32_t count = stream_level_count(A, gen);
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_lean(const KernelArg
     const bool all_heavy = gen > 0 && count < A.heavy_level_threshold;
 
     Ray R;
-    LeanWalk W;
+    typename std::conditional<QUAD, QuadWalk, LeanWalk>::type W;
     int state = ST_FETCH;
     uint32_t r = 0, steps = 0;
     for (;;) {
@@ -344,8 +347,12 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_lean(const KernelArg
         }
         if (!__ballot(state != ST_DONE)) break;
         if (state == ST_TRAVERSE) {
-            if (lean_walk<false>(W, R, primary, A, 64, steps)) {
+            const int w = quad_walk<false>(W, R, primary, A, 64, steps, stk);
+            if (w == WALK_DONE) {
                 shade_and_emit<false>(A, gen, r, node_base, child_base, R, W.have, W.bt, W.btri, W.bmesh, nullptr, lane);
+                state = ST_FETCH;
+            } else if (w == WALK_STACK_FULL) {  // restart it in the wave-per-ray kernel, which needs no stack
+                if (!evict_ray(A.s_heavy, A.s_heavy_cap, A.s_counts + SC_HEAVY + gen, r, lane)) A.s_counts[SC_OVERFLOW] = 1;
                 state = ST_FETCH;
             } else if (steps >= A.step_budget) {
                 if (evict_ray(A.s_heavy, A.s_heavy_cap, A.s_counts + SC_HEAVY + gen, r, lane)) state = ST_FETCH;
@@ -355,8 +362,10 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_lean(const KernelArg
     }
 }
 
-template <uint32_t pass>  // a template parameter so that the two passes are two kernels in a profile
+template <uint32_t pass, bool QUAD>  // `pass` is a template parameter so that the two passes are two kernels in a profile
 __global__ __launch_bounds__(BLOCK) void stream_trace_shadow_lean(const KernelArgs A) {
+    extern __shared__ uint32_t qstack[];  // QUAD: A.quad_stack_depth x BLOCK words
+    uint32_t *const stk = qstack + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     if (A.s_counts[SC_OVERFLOW]) return;
     // pass 0: after stream_packets_gen0, the shadow walks that kernel gave up on (a list of queue slots);
@@ -367,7 +376,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shadow_lean(const KernelAr
     const uint32_t total = listed ? A.s_counts[SC_TODO_SHADOW] : (pass == 0 ? split : A.s_counts[SC_SHADOW] - split);
     uint32_t *cursor = A.s_counts + (pass == 0 ? SC_SHADOW_FETCH : SC_SHADOW_FETCH2);
     Ray R;
-    LeanWalk W;
+    typename std::conditional<QUAD, QuadWalk, LeanWalk>::type W;
     int state = ST_FETCH;
     uint32_t r = 0, steps = 0;
     for (;;) {
@@ -393,8 +402,12 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shadow_lean(const KernelAr
         }
         if (!__ballot(state != ST_DONE)) break;
         if (state == ST_TRAVERSE) {
-            if (lean_walk<true>(W, R, false, A, 64, steps)) {
+            const int w = quad_walk<true>(W, R, false, A, 64, steps, stk);
+            if (w == WALK_DONE) {
                 A.s_occluded[r] = W.occluded ? 1 : 0;
+                state = ST_FETCH;
+            } else if (w == WALK_STACK_FULL) {
+                if (!evict_ray(A.s_sheavy, A.s_heavy_cap, A.s_counts + SC_SHEAVY, r, lane)) A.s_counts[SC_OVERFLOW] = 1;
                 state = ST_FETCH;
             } else if (steps >= A.step_budget) {
                 if (evict_ray(A.s_sheavy, A.s_heavy_cap, A.s_counts + SC_SHEAVY, r, lane)) state = ST_FETCH;

@@ -3,6 +3,9 @@ import os
 import sys
 
 import pytest
+# torch brings its own copy of the HIP runtime: when a test uses both torch.cuda and libcrt_hip.so in one process,
+# torch's copy has to be the first one loaded (the other order leaves torch with "No HIP GPUs are available")
+import torch  # noqa: F401
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
