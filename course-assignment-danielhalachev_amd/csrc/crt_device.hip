@@ -110,11 +110,11 @@ struct crt_ctx {
     hipEvent_t ev_fork[EV_RING] = {}, ev_s0[EV_RING] = {}, ev_s1[EV_RING] = {}, ev4[EV_RING] = {};
     float4 *d_hits = nullptr;         // their closest hits
     uint32_t heavy_cap = 0;
-    uint32_t step_budget = 1024;      // CRT_STEP_BUDGET: closest-hit walks are evicted to heavy_trace after this many steps (0 = never)
-    uint32_t shadow_budget = 4096;    // CRT_SHADOW_BUDGET: same for shadow walks (one big launch: only its tail matters)
-    uint32_t heavy_level_threshold = 0;  // CRT_HEAVY_LEVEL: levels with fewer rays go to heavy_trace whole
+    uint32_t step_budget = 512;       // CRT_STEP_BUDGET: closest-hit walks are evicted to heavy_trace after this many steps (0 = never)
+    uint32_t shadow_budget = 8192;    // CRT_SHADOW_BUDGET: same for shadow walks (one big launch: only its tail matters)
+    uint32_t heavy_level_threshold = 50000;  // CRT_HEAVY_LEVEL: levels with fewer rays go to heavy_trace whole
     bool lean_ok = true;              // 32-bit byte offsets reach every node and leaf entry
-    uint32_t use_quads = 7;           // CRT_QUAD: which lean kernels walk quad nodes (bit 0 levels, 1 shadow pass 0, 2 shadow pass 1)
+    uint32_t use_quads = 1;           // CRT_QUAD: which lean kernels walk quad nodes (bit 0 levels, 1 shadow pass 0, 2 shadow pass 1)
     uint32_t quad_stack_depth = 16;   // CRT_QUAD_STACK
     uint32_t n_quads = 0;
     uint32_t side_blocks_per_cu = 4;  // CRT_SIDE_BLOCKS: blocks per CU of the overlapped shadow pass

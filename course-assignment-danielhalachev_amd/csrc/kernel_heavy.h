@@ -19,12 +19,16 @@
 
 #include "kernel_common.h"
 #include "kernel_stream.h"
+#include "kernel_walk.h"
 
 struct HeavyState {   // all wave-uniform
     bool mhave;
     float mmin, mt;
     uint32_t mtri;
     uint32_t guard;   // remaining loop iterations for this ray: every loop of the walk is bounded by it
+    bool stop;        // shadow walks: an accepted hit within the light's distance ends the walk (kernel_walk.h: shadow_hit_occludes)
+    float light_dist;
+    __device__ __forceinline__ bool go() const { return guard != 0 && !stop; }
 };
 
 // Cross-lane helpers on the DPP / readlane paths (a ds_bpermute round trip per step is what the walk would
@@ -55,6 +59,7 @@ __device__ __forceinline__ float wave_min(float v) {
 }
 
 // One batch of up to 64 triangles (lane j tests list entry e when `valid`), lanes in list order.
+template <bool SHADOW>
 __device__ __forceinline__ void heavy_batch(const KernelArgs &A, const Ray &R, const bool primary, const bool valid,
                                             const size_t e, HeavyState &H) {
     const float4 a = A.ltris[4 * e + 0], b = A.ltris[4 * e + 1], c = A.ltris[4 * e + 2], d = A.ltris[4 * e + 3];
@@ -62,6 +67,11 @@ __device__ __forceinline__ void heavy_batch(const KernelArgs &A, const Ray &R, c
     const bool acc = valid && triangle_test(R, primary, a, b, c, d.x, t);
     const unsigned long long am = __ballot(acc);
     if (!am) return;
+    if (SHADOW) {
+        const bool occ = acc && t < INFINITY &&
+                         shadow_hit_occludes(R, R.ox + R.dx * t, R.oy + R.dy * t, R.oz + R.dz * t, H.light_dist);
+        if (__ballot(occ)) { H.stop = true; return; }
+    }
     if (!H.mhave) {  // `closest = intersections[0]`: the first accepted hit in list order, whatever its distance
         const int first = __ffsll((long long)am) - 1;
         H.mhave = true;
@@ -82,29 +92,30 @@ __device__ __forceinline__ void heavy_batch(const KernelArgs &A, const Ray &R, c
 // The triangles of all leaves of one 64-leaf chunk whose box the ray passes (`hit` lanes: leaf = lane,
 // list [begin, begin+count)), concatenated in leaf order and tested 64 at a time.  The concatenation is laid
 // over the lanes with wave-uniform arithmetic: `off` lanes of the batch under construction are taken.
+template <bool SHADOW>
 __device__ __forceinline__ void heavy_leaves(const KernelArgs &A, const Ray &R, const bool primary, const bool hit,
                                              const uint32_t begin, const uint32_t count, HeavyState &H, const uint32_t lane) {
     unsigned long long m = __ballot(hit);
     uint32_t off = 0, e = 0;
     bool valid = false;
-    while (m && H.guard) {
+    while (m && H.go()) {
         H.guard--;
         const int k = __ffsll((long long)m) - 1;
         m &= m - 1;
         uint32_t bg = lane_value(begin, k), cnt = lane_value(count, k);
-        while (cnt && H.guard) {  // a leaf longer than the free lanes continues in the next batch
+        while (cnt && H.go()) {  // a leaf longer than the free lanes continues in the next batch
             const uint32_t take = cnt < 64u - off ? cnt : 64u - off;
             if (lane >= off && lane < off + take) { e = bg + (lane - off); valid = true; }
             off += take; bg += take; cnt -= take;
             if (off == 64u) {
                 H.guard--;
-                heavy_batch(A, R, primary, valid, (size_t)e, H);
+                heavy_batch<SHADOW>(A, R, primary, valid, (size_t)e, H);
                 off = 0;
                 valid = false;
             }
         }
     }
-    if (off) heavy_batch(A, R, primary, valid, (size_t)e, H);
+    if (off && H.go()) heavy_batch<SHADOW>(A, R, primary, valid, (size_t)e, H);
 }
 
 struct ChunkBoxes { float4 b0, b1; bool valid; };
@@ -120,29 +131,30 @@ __device__ __forceinline__ ChunkBoxes heavy_chunk_load(const KernelArgs &A, cons
     return C;
 }
 
-template <int LEVEL>
+template <int LEVEL, bool SHADOW>
 __device__ __forceinline__ void heavy_chunk(const KernelArgs &A, const Ray &R, const bool primary, const HeavyMesh &M,
                                             const uint32_t chunk, const ChunkBoxes &C, HeavyState &H, const uint32_t lane) {
     const bool hit = C.valid && slab_test(R, C.b0.x, C.b0.y, C.b0.z, C.b1.x, C.b1.y, C.b1.z);
     if constexpr (LEVEL == 0) {
-        if (__ballot(hit)) heavy_leaves(A, R, primary, hit, __float_as_uint(C.b0.w), __float_as_uint(C.b1.w), H, lane);
+        if (__ballot(hit)) heavy_leaves<SHADOW>(A, R, primary, hit, __float_as_uint(C.b0.w), __float_as_uint(C.b1.w), H, lane);
     } else {
         unsigned long long m = __ballot(hit);
         if (!m) return;
         // the boxes of the next passing child chunk are requested before the current one is worked on
         ChunkBoxes next = heavy_chunk_load<LEVEL - 1>(A, M, chunk * 64u + (uint32_t)(__ffsll((long long)m) - 1), lane);
-        while (m && H.guard) {
+        while (m && H.go()) {
             H.guard--;
             const int k = __ffsll((long long)m) - 1;
             m &= m - 1;
             const ChunkBoxes cur = next;
             if (m) next = heavy_chunk_load<LEVEL - 1>(A, M, chunk * 64u + (uint32_t)(__ffsll((long long)m) - 1), lane);
-            heavy_chunk<LEVEL - 1>(A, R, primary, M, chunk * 64u + (uint32_t)k, cur, H, lane);
+            heavy_chunk<LEVEL - 1, SHADOW>(A, R, primary, M, chunk * 64u + (uint32_t)k, cur, H, lane);
         }
     }
 }
 
 // closest hit of the (wave-uniform) ray in one mesh
+template <bool SHADOW>
 __device__ __forceinline__ void heavy_mesh(const KernelArgs &A, const Ray &R, const bool primary, const uint32_t mesh,
                                            HeavyState &H, const uint32_t lane) {
     const HeavyMesh M = A.hmesh[mesh];
@@ -153,10 +165,10 @@ __device__ __forceinline__ void heavy_mesh(const KernelArgs &A, const Ray &R, co
     H.mt = 0;
     H.mtri = 0;
     switch (M.n_levels) {
-        case 1: heavy_chunk<0>(A, R, primary, M, 0, heavy_chunk_load<0>(A, M, 0, lane), H, lane); break;
-        case 2: heavy_chunk<1>(A, R, primary, M, 0, heavy_chunk_load<1>(A, M, 0, lane), H, lane); break;
-        case 3: heavy_chunk<2>(A, R, primary, M, 0, heavy_chunk_load<2>(A, M, 0, lane), H, lane); break;
-        case 4: heavy_chunk<3>(A, R, primary, M, 0, heavy_chunk_load<3>(A, M, 0, lane), H, lane); break;
+        case 1: heavy_chunk<0, SHADOW>(A, R, primary, M, 0, heavy_chunk_load<0>(A, M, 0, lane), H, lane); break;
+        case 2: heavy_chunk<1, SHADOW>(A, R, primary, M, 0, heavy_chunk_load<1>(A, M, 0, lane), H, lane); break;
+        case 3: heavy_chunk<2, SHADOW>(A, R, primary, M, 0, heavy_chunk_load<2>(A, M, 0, lane), H, lane); break;
+        case 4: heavy_chunk<3, SHADOW>(A, R, primary, M, 0, heavy_chunk_load<3>(A, M, 0, lane), H, lane); break;
         default: break;
     }
 }
@@ -172,7 +184,9 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const Ray &R, co
     uint32_t ti = A.top_root;
     HeavyState H;
     H.guard = 1u << 18;
-    while (ti != END && H.guard) {  // the top-level tree is tiny: walked node by node, uniformly
+    H.stop = false;
+    H.light_dist = light_dist;
+    while (ti != END && H.go()) {  // the top-level tree is tiny: walked node by node, uniformly
         H.guard--;
         const float4 q0 = A.nodes[2 * (size_t)ti], q1 = A.nodes[2 * (size_t)ti + 1];
         const uint32_t miss = __float_as_uint(q0.w), link = __float_as_uint(q1.w);
@@ -186,7 +200,8 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const Ray &R, co
             const crt_mesh m = A.meshes[mi];
             if (!(SHADOW && (m.flags & 1u))) {
                 if (A.debug & 32u) { H.mhave = false; } else
-                heavy_mesh(A, R, primary, mi, H, lane);
+                heavy_mesh<SHADOW>(A, R, primary, mi, H, lane);
+                if (SHADOW && H.stop) { occluded = true; break; }
                 if (H.mhave) {
                     if (SHADOW) {
                         const float px = R.ox + R.dx * H.mt, py = R.oy + R.dy * H.mt, pz = R.oz + R.dz * H.mt;
@@ -197,7 +212,7 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const Ray &R, co
                     }
                 }
             }
-            if ((ent & LAST) || !H.guard) break;
+            if ((ent & LAST) || !H.go()) break;
             H.guard--;
         }
         ti = miss;

@@ -13,6 +13,18 @@
 
 #include "kernel_common.h"
 
+// Early exit of a shadow walk, exact.  The reference walks every mesh to the end and then asks whether the
+// mesh's closest hit (smallest t, KDTree.cpp:75-86) lies within the light's distance
+// (AccelerationStructure.cpp:73-74: length(hitPoint - origin) <= distanceToLight), the answer being "any mesh
+// says yes".  Every step of that length -- d*t, o + (.), (.) - o, the squares, their sums, the square root --
+// is monotone non-decreasing in t >= 0 under round-to-nearest, so once ANY accepted hit with a finite t passes
+// the comparison, the mesh's final closest hit (t no larger, and finite, because a finite distance always
+// replaces a NaN/inf first entry) passes it too: the ray is occluded whatever the rest of the walk finds.
+// hx, hy, hz = o + d*t as the triangle test computed it (Ray.cpp:21), which is the hitPoint the reference stores.
+__device__ __forceinline__ bool shadow_hit_occludes(const Ray &R, float hx, float hy, float hz, float light_dist) {
+    return len3(hx - R.ox, hy - R.oy, hz - R.oz) <= light_dist;
+}
+
 struct LeanWalk {
     uint32_t n;        // next mesh-tree node (END: the current mesh is finished / none started)
     uint32_t e;        // next leaf entry of the current leaf (NONE: not inside a leaf)
@@ -72,6 +84,7 @@ __device__ __forceinline__ bool lean_walk(LeanWalk &W, const Ray &R, const bool 
             W.mmin = less ? t : W.mmin;
             W.mhave = W.mhave || ok;
             W.e = __float_as_uint(d.z) ? NONE : W.e + 1;
+            if (SHADOW && ok && t < INFINITY && shadow_hit_occludes(R, px, py, pz, W.light_dist)) { W.occluded = true; return true; }
         } else if (W.n != END) {
             // ---- one mesh-tree node (KDTree.cpp:53-74, BoundingBox.h:85-108), branch-free
             const float4 *N = reinterpret_cast<const float4 *>(nodes_b + (size_t)(uint32_t)(W.n << 5));
@@ -202,6 +215,7 @@ __device__ __forceinline__ int quad_walk(QuadWalk &W, const Ray &R, const bool p
             W.mhave = W.mhave || ok;
             next = __float_as_uint(d.z) != 0;
             W.e = next ? NONE : W.e + 1;
+            if (SHADOW && ok && t < INFINITY && shadow_hit_occludes(R, px, py, pz, W.light_dist)) { W.occluded = true; return WALK_DONE; }
         } else if (W.q != NONE) {
             // ---- one quad: four boxes (BoundingBox.h:85-108), the slots that pass go on the stack, last first
             if (W.sp + 4 > A.quad_stack_depth) return WALK_STACK_FULL;
