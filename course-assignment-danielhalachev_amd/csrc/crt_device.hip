@@ -116,6 +116,7 @@ struct crt_ctx {
     bool lean_ok = true;              // 32-bit byte offsets reach every node and leaf entry
     uint32_t use_quads = 1;           // CRT_QUAD: which lean kernels walk quad nodes (bit 0 levels, 1 shadow pass 0, 2 shadow pass 1)
     uint32_t quad_stack_depth = 16;   // CRT_QUAD_STACK
+    uint32_t prune = 0;               // CRT_PRUNE: distance pruning of closest-hit walks (kernel_common.h); bit 0 quad walk, bit 1 heavy_trace
     uint32_t n_quads = 0;
     uint32_t side_blocks_per_cu = 4;  // CRT_SIDE_BLOCKS: blocks per CU of the overlapped shadow pass
     uint32_t debug_skip = 0;          // CRT_DEBUG_SKIP: development only, skips heavy-path launches
@@ -240,6 +241,66 @@ static int validate_scene(const crt_scene_desc *s, std::string &err) {
     return CRT_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Loose boxes for distance pruning of closest-hit walks (kernel_walk.h: "pruning").
+// box(T) encloses every point p = o + d*t that Ray::intersectWithTriangle can ACCEPT for triangle T:
+// the inside test (Triangle.cpp:37-57) accepts p when, for each edge k, n . (e_k x (p - v_k)) >= -FLT_EPSILON,
+// i.e. when p's projection on the plane is at most FLT_EPSILON/|e_k| outside edge k; and p itself is within
+// rounding of the plane.  So box(T) = bounding box of the triangle whose edges are moved outwards by
+// d_k = 2*FLT_EPSILON/|e_k| + 1e-5*S (S = largest coordinate magnitude of the scene: the rounding of the test
+// itself is ~1e-6*S), grown by another 1e-5*S for the distance to the plane.  A triangle for which that
+// construction is ill-conditioned (zero edge, non-finite normal, edges almost parallel) gets the infinite box:
+// it is never pruned.
+static void triangle_loose_box(const crt_triangle &T, double S, float lo[3], float hi[3]) {
+    const double v[3][3] = {{T.v0[0], T.v0[1], T.v0[2]}, {T.v1[0], T.v1[1], T.v1[2]}, {T.v2[0], T.v2[1], T.v2[2]}};
+    const double n[3] = {T.nx, T.ny, T.nz};
+    auto infinite = [&]() { for (int a = 0; a < 3; a++) { lo[a] = -INFINITY; hi[a] = INFINITY; } };
+    const double nl = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    if (!(nl > 0.99 && nl < 1.01)) return infinite();
+    // the stored plane offset must be the triangle's own (Ray.cpp:17: D = -(v0 . n)), or p is not near the triangle
+    if (!(std::fabs((double)T.plane + (v[0][0] * n[0] + v[0][1] * n[1] + v[0][2] * n[2])) <= 1e-5 * (1.0 + S))) return infinite();
+    double e[3][3], el[3], m[3][3], c[3];  // edges, their lengths, inward in-plane normals, offsets: m_k . x >= c_k
+    for (int k = 0; k < 3; k++) {
+        const double *a = v[k], *b = v[(k + 1) % 3];
+        for (int i = 0; i < 3; i++) e[k][i] = b[i] - a[i];
+        el[k] = std::sqrt(e[k][0] * e[k][0] + e[k][1] * e[k][1] + e[k][2] * e[k][2]);
+        if (!(el[k] > 0.0) || !std::isfinite(el[k])) return infinite();
+        if (!(std::fabs(n[0] * e[k][0] + n[1] * e[k][1] + n[2] * e[k][2]) <= 1e-4 * el[k])) return infinite();  // n must be the edges' normal
+        // n x e_k, normalised
+        m[k][0] = (n[1] * e[k][2] - n[2] * e[k][1]) / (nl * el[k]);
+        m[k][1] = (n[2] * e[k][0] - n[0] * e[k][2]) / (nl * el[k]);
+        m[k][2] = (n[0] * e[k][1] - n[1] * e[k][0]) / (nl * el[k]);
+        const double d = 2.0 * (double)FLT_EPSILON / el[k] + 1e-5 * S;
+        c[k] = m[k][0] * a[0] + m[k][1] * a[1] + m[k][2] * a[2] - d;
+    }
+    double blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int k = 0; k < 3; k++) {
+        // corner k: where the moved edges k-1 and k meet.  x = v_k + s*e_{k-1}^ + u*e_k^ in the plane; solve the two
+        // line equations m_j . x = c_j (j = k-1, k) for (s, u).
+        const int j = (k + 2) % 3;
+        double ej[3], ek[3];
+        for (int i = 0; i < 3; i++) { ej[i] = e[j][i] / el[j]; ek[i] = e[k][i] / el[k]; }
+        auto dot = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+        // m_j . ej = 0 and m_k . ek = 0 (in-plane normals of their own edges):
+        //   m_j . x = m_j . v_k + u * (m_j . ek) = c_j      m_k . x = m_k . v_k + s * (m_k . ej) = c_k
+        const double ajk = dot(m[j], ek), akj = dot(m[k], ej);
+        if (!(std::fabs(ajk) > 1e-6) || !(std::fabs(akj) > 1e-6)) return infinite();  // a sliver: corners run away
+        const double u = (c[j] - dot(m[j], v[k])) / ajk, sdist = (c[k] - dot(m[k], v[k])) / akj;
+        for (int i = 0; i < 3; i++) {
+            const double x = v[k][i] + sdist * ej[i] + u * ek[i];
+            if (!std::isfinite(x)) return infinite();
+            blo[i] = std::min(blo[i], std::min(x, v[k][i]));
+            bhi[i] = std::max(bhi[i], std::max(x, v[k][i]));
+        }
+    }
+    const double grow = 2e-5 * S + 1e-30;
+    for (int i = 0; i < 3; i++) {
+        lo[i] = std::nextafterf((float)(blo[i] - grow), -INFINITY);
+        hi[i] = std::nextafterf((float)(bhi[i] + grow), INFINITY);
+    }
+}
+
 extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
     if (!out) return CRT_ERR_INVALID;
     *out = nullptr;
@@ -314,6 +375,57 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
         }
         if (upload(ctx, lt.data(), lt.size(), &A.ltris)) return fail(CRT_ERR_HIP);
     }
+    // loose boxes (see triangle_loose_box) of every mesh-tree node: a leaf's = union over its triangles, an inner
+    // node's = union over its children; nodes of one tree are in visit order, children after their parent
+    std::vector<float> nloose_lo((size_t)s->n_nodes * 3, INFINITY), nloose_hi((size_t)s->n_nodes * 3, -INFINITY);
+    {
+        double S = 0.0;
+        for (uint64_t t = 0; t < s->n_triangles; t++) {
+            const crt_triangle &T = s->triangles[t];
+            for (int a = 0; a < 3; a++) {
+                const double m = std::max(std::fabs((double)T.v0[a]), std::max(std::fabs((double)T.v1[a]), std::fabs((double)T.v2[a])));
+                if (std::isfinite(m)) S = std::max(S, m);
+            }
+        }
+        A.scene_scale = (float)S;
+        std::vector<float> tlo((size_t)s->n_triangles * 3), thi((size_t)s->n_triangles * 3);
+        for (uint64_t t = 0; t < s->n_triangles; t++) triangle_loose_box(s->triangles[t], S, &tlo[3 * t], &thi[3 * t]);
+        std::vector<bool> is_top(s->n_nodes, false);  // top-level nodes hold meshes, not triangles: left empty
+        {
+            std::vector<uint32_t> stack{s->top_root};
+            while (!stack.empty()) {
+                const uint32_t i = stack.back();
+                stack.pop_back();
+                if (i >= s->n_nodes || is_top[i]) continue;
+                is_top[i] = true;
+                const crt_node &n = s->nodes[i];
+                if (is_leaf_link(n.link) || n.link == CRT_LINK_END) continue;
+                stack.push_back(n.link);
+                const uint32_t c2 = s->nodes[n.link].miss;
+                if (c2 != n.miss && c2 != CRT_LINK_END) stack.push_back(c2);
+            }
+        }
+        for (uint32_t i = s->n_nodes; i-- > 0;) {
+            if (is_top[i]) continue;
+            const crt_node &n = s->nodes[i];
+            float *lo = &nloose_lo[(size_t)i * 3], *hi = &nloose_hi[(size_t)i * 3];
+            auto join = [&](const float *l, const float *h) {
+                for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], l[a]); hi[a] = std::max(hi[a], h[a]); }
+            };
+            if (is_leaf_link(n.link)) {
+                uint64_t e = n.link & ~CRT_LINK_LEAF;
+                while (e < s->n_leaf_triangles) {
+                    const uint32_t ent = s->leaf_triangles[e++], tri = ent & ~CRT_ENTRY_LAST;
+                    join(&tlo[(size_t)tri * 3], &thi[(size_t)tri * 3]);
+                    if (ent & CRT_ENTRY_LAST) break;
+                }
+            } else if (n.link != CRT_LINK_END) {
+                const uint32_t c1 = n.link, c2 = s->nodes[c1].miss;
+                join(&nloose_lo[(size_t)c1 * 3], &nloose_hi[(size_t)c1 * 3]);
+                if (c2 != n.miss && c2 != CRT_LINK_END) join(&nloose_lo[(size_t)c2 * 3], &nloose_hi[(size_t)c2 * 3]);
+            }
+        }
+    }
     {
         // Leaf sequence of every mesh tree (kernel_heavy.h): the leaves' own boxes in visit order, then union
         // boxes of 64 entries per level until at most 64 remain.  With forward links the nodes of a mesh tree
@@ -322,7 +434,7 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
         roots.push_back(s->top_root);
         for (uint32_t m = 0; m < s->n_meshes; m++) roots.push_back(s->meshes[m].root);
         std::sort(roots.begin(), roots.end());
-        std::vector<float4> hbox;
+        std::vector<float4> hbox, hloose;  // hloose: the entries' loose boxes, same indexing
         std::vector<HeavyMesh> hm(s->n_meshes);
         for (uint32_t m = 0; m < s->n_meshes; m++) {
             HeavyMesh &H = hm[m];
@@ -330,7 +442,7 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
             const uint32_t root = s->meshes[m].root;
             auto it = std::upper_bound(roots.begin(), roots.end(), root);
             const uint32_t end = it == roots.end() ? s->n_nodes : *it;
-            std::vector<float4> level;  // 2 x float4 per entry
+            std::vector<float4> level, loose;  // 2 x float4 per entry
             for (uint32_t i = root; i < end; i++) {
                 const crt_node &n = s->nodes[i];
                 if (!is_leaf_link(n.link)) continue;
@@ -345,6 +457,8 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
                 memcpy(&cb, &count, 4);
                 level.push_back(make_float4(n.lo[0], n.lo[1], n.lo[2], bb));
                 level.push_back(make_float4(n.hi[0], n.hi[1], n.hi[2], cb));
+                loose.push_back(make_float4(nloose_lo[(size_t)i * 3], nloose_lo[(size_t)i * 3 + 1], nloose_lo[(size_t)i * 3 + 2], 0.0f));
+                loose.push_back(make_float4(nloose_hi[(size_t)i * 3], nloose_hi[(size_t)i * 3 + 1], nloose_hi[(size_t)i * 3 + 2], 0.0f));
             }
             uint32_t nl = 0;
             while (!level.empty() && nl < 4) {
@@ -352,26 +466,35 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
                 H.first[nl] = (uint32_t)(hbox.size() / 2);
                 H.count[nl] = cnt;
                 hbox.insert(hbox.end(), level.begin(), level.end());
+                hloose.insert(hloose.end(), loose.begin(), loose.end());
                 nl++;
                 if (cnt <= 64) break;
-                std::vector<float4> up;
+                std::vector<float4> up, up_loose;
                 for (uint32_t g = 0; g < cnt; g += 64) {
                     float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+                    float llo[3] = {INFINITY, INFINITY, INFINITY}, lhi[3] = {-INFINITY, -INFINITY, -INFINITY};
                     for (uint32_t k = g; k < cnt && k < g + 64; k++) {
                         const float4 &a = level[2 * k], &b = level[2 * k + 1];
                         lo[0] = a.x < lo[0] ? a.x : lo[0]; lo[1] = a.y < lo[1] ? a.y : lo[1]; lo[2] = a.z < lo[2] ? a.z : lo[2];
                         hi[0] = b.x > hi[0] ? b.x : hi[0]; hi[1] = b.y > hi[1] ? b.y : hi[1]; hi[2] = b.z > hi[2] ? b.z : hi[2];
+                        const float4 &la = loose[2 * k], &lb = loose[2 * k + 1];
+                        llo[0] = std::min(llo[0], la.x); llo[1] = std::min(llo[1], la.y); llo[2] = std::min(llo[2], la.z);
+                        lhi[0] = std::max(lhi[0], lb.x); lhi[1] = std::max(lhi[1], lb.y); lhi[2] = std::max(lhi[2], lb.z);
                     }
                     up.push_back(make_float4(lo[0], lo[1], lo[2], 0.0f));
                     up.push_back(make_float4(hi[0], hi[1], hi[2], 0.0f));
+                    up_loose.push_back(make_float4(llo[0], llo[1], llo[2], 0.0f));
+                    up_loose.push_back(make_float4(lhi[0], lhi[1], lhi[2], 0.0f));
                 }
                 level.swap(up);
+                loose.swap(up_loose);
             }
             // more than 64^4 leaves: leave n_levels = 0 for this mesh -> the heavy path is switched off below
             H.n_levels = (!level.empty() && H.count[nl ? nl - 1 : 0] <= 64) ? nl : 0;
             if (H.n_levels == 0 && !level.empty()) ctx->step_budget = 0;
         }
         if (upload(ctx, hbox.data(), hbox.size(), &A.hbox)) return fail(CRT_ERR_HIP);
+        if (upload(ctx, hloose.data(), hloose.size(), &A.hloose)) return fail(CRT_ERR_HIP);
         if (upload(ctx, hm.data(), hm.size(), &A.hmesh)) return fail(CRT_ERR_HIP);
     }
     {
@@ -383,6 +506,7 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
         struct Builder {
             const crt_scene_desc *s;
             std::vector<float4> &quads;
+            const std::vector<float> &loose_lo, &loose_hi;
             void children(uint32_t i, std::vector<uint32_t> &out) const {
                 const crt_node &n = s->nodes[i];
                 if (is_leaf_link(n.link) || n.link == CRT_LINK_END) return;
@@ -414,14 +538,17 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
                     slots.erase(slots.begin() + pick);
                     slots.insert(slots.begin() + pick, kids.begin(), kids.end());
                 }
-                const uint32_t q = (uint32_t)(quads.size() / 8);
-                quads.resize(quads.size() + 8, make_float4(0, 0, 0, 0));
-                float box[6][4];
+                const uint32_t q = (uint32_t)(quads.size() / 16);
+                quads.resize(quads.size() + 16, make_float4(0, 0, 0, 0));
+                float box[6][4], lbox[6][4];
                 uint32_t link[4] = {NONE, NONE, NONE, NONE};
-                for (int k = 0; k < 4; k++) for (int a = 0; a < 6; a++) box[a][k] = 0.0f;
+                for (int k = 0; k < 4; k++) for (int a = 0; a < 6; a++) { box[a][k] = 0.0f; lbox[a][k] = 0.0f; }
                 for (size_t k = 0; k < slots.size(); k++) {
                     const crt_node &n = s->nodes[slots[k]];
-                    for (int a = 0; a < 3; a++) { box[a][k] = n.lo[a]; box[3 + a][k] = n.hi[a]; }
+                    for (int a = 0; a < 3; a++) {
+                        box[a][k] = n.lo[a]; box[3 + a][k] = n.hi[a];
+                        lbox[a][k] = loose_lo[(size_t)slots[k] * 3 + a]; lbox[3 + a][k] = loose_hi[(size_t)slots[k] * 3 + a];
+                    }
                     if (is_leaf_link(n.link)) {
                         link[k] = n.link;  // LEAF + first entry
                     } else {
@@ -430,16 +557,17 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
                         link[k] = build(kids, depth + 1);
                     }
                 }
-                for (int a = 0; a < 6; a++) quads[(size_t)q * 8 + a] = make_float4(box[a][0], box[a][1], box[a][2], box[a][3]);
+                for (int a = 0; a < 6; a++) quads[(size_t)q * 16 + a] = make_float4(box[a][0], box[a][1], box[a][2], box[a][3]);
+                for (int a = 0; a < 6; a++) quads[(size_t)q * 16 + 8 + a] = make_float4(lbox[a][0], lbox[a][1], lbox[a][2], lbox[a][3]);
                 float lb[4];
                 memcpy(lb, link, 16);
-                quads[(size_t)q * 8 + 6] = make_float4(lb[0], lb[1], lb[2], lb[3]);
+                quads[(size_t)q * 16 + 6] = make_float4(lb[0], lb[1], lb[2], lb[3]);
                 return q;
             }
-        } builder{s, quads};
+        } builder{s, quads, nloose_lo, nloose_hi};
         for (uint32_t m = 0; m < s->n_meshes; m++) qroots[m] = builder.build(std::vector<uint32_t>{s->meshes[m].root});
-        ctx->n_quads = (uint32_t)(quads.size() / 8);
-        if (builder.too_deep || quads.size() / 8 >= (1u << 24)) ctx->use_quads = 0;
+        ctx->n_quads = (uint32_t)(quads.size() / 16);
+        if (builder.too_deep || quads.size() / 16 >= (1u << 24)) ctx->use_quads = 0;
         if (upload(ctx, quads.data(), quads.size(), &A.quads)) return fail(CRT_ERR_HIP);
         if (upload(ctx, qroots.data(), qroots.size(), &A.quad_roots)) return fail(CRT_ERR_HIP);
     }
@@ -525,6 +653,8 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
         ctx->lean_ok = s->n_nodes < (1u << 27) && s->n_leaf_triangles < (1ull << 26);
         const char *qd = getenv("CRT_QUAD");
         if (qd && ctx->use_quads) ctx->use_quads = (uint32_t)atoi(qd) & 7u;
+        const char *pr = getenv("CRT_PRUNE");
+        if (pr) ctx->prune = (uint32_t)atoi(pr) & 3u;
         const char *qs = getenv("CRT_QUAD_STACK");
         if (qs) ctx->quad_stack_depth = (uint32_t)atoi(qs);
         if (ctx->quad_stack_depth < 4) ctx->quad_stack_depth = 4;
@@ -735,6 +865,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         const bool lean = heavy && ctx->lean_ok && !(ctx->debug_skip & 256u);
         const uint32_t quad = lean ? ctx->use_quads : 0u;  // bit 0: the levels, bit 1: shadow pass 0, bit 2: shadow pass 1
         A.quad_stack_depth = ctx->quad_stack_depth;
+        A.prune = ctx->prune;
         const uint32_t qlds = ctx->quad_stack_depth * BLOCK * (uint32_t)sizeof(uint32_t);
         const uint32_t heavy_blocks = ctx->grid_blocks < 1024u ? ctx->grid_blocks : 1024u;
         const bool packets = lean && ctx->packet_budget != 0 && !(ctx->debug_skip & 512u);

@@ -95,11 +95,15 @@ struct KernelArgs {
     uint32_t *s_todo_tiles;       // work items whose primary packet walk was abandoned
     uint32_t *s_todo_shadow;      // shadow-queue slots whose packet walk was abandoned
     uint32_t debug;               // development switches
-    // quad nodes of the mesh trees (kernel_walk.h): 128 bytes each = {lo.x[4]} {lo.y[4]} {lo.z[4]} {hi.x[4]} {hi.y[4]} {hi.z[4]}
-    // {slot links: quad index | LEAF + first leaf entry | NONE} {unused}
+    // quad nodes of the mesh trees (kernel_walk.h): 256 bytes each = {lo.x[4]} {lo.y[4]} {lo.z[4]} {hi.x[4]} {hi.y[4]} {hi.z[4]}
+    // {slot links: quad index | LEAF + first leaf entry | NONE} {unused}, then the slots' LOOSE boxes in the same
+    // six-vector layout (crt_device.hip: triangle_loose_box) and two unused vectors
     const float4 *quads;
     const uint32_t *quad_roots;   // per mesh
     uint32_t quad_stack_depth;    // words of LDS stack per lane
+    const float4 *hloose;         // loose boxes of the hbox entries, same indexing
+    float scene_scale;            // largest coordinate magnitude of the scene's triangles
+    uint32_t prune;               // closest-hit walks skip subtrees whose loose box lies beyond the best hit so far
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -133,6 +137,35 @@ __device__ __forceinline__ void ray_prepare(Ray &R) {
     R.ix = 1.0f / R.dx;
     R.iy = 1.0f / R.dy;
     R.iz = 1.0f / R.dz;
+}
+
+// ---- distance pruning of closest-hit walks -------------------------------------------------------------
+// The reference walks every leaf whose box the ray passes, whatever it has found so far (KDTree.cpp:53-74).
+// Only a hit with a STRICTLY smaller distance ever replaces the best one (KDTree.cpp:81, :162), so a subtree
+// that cannot contain such a hit may be skipped without changing the result.  "Cannot" is decided on the
+// subtree's LOOSE box (crt_device.hip: triangle_loose_box), which contains every point o + d*t the triangle
+// test can accept for any of the subtree's triangles -- not on the kd cell, which triangles stick out of.
+// For an accepted hit, p_i = fl(o_i + fl(d_i*t)) lies in the loose box; on an axis with |d_i| >= 0.01 that
+// gives t >= (c_i - o_i)/d_i - 2u(|o_i| + |p_i|)/|d_i| with c_i the box face the ray meets first, and the
+// computed (c_i - o_i)*inv_i is within 4u of that quotient (u = 2^-24).  prune_bound() returns the largest
+// such bound minus a margin three orders of magnitude above those error terms; a subtree is skipped only when
+// that value is >= the best distance so far.  NaN and infinite distances never skip anything.
+struct Prune {
+    float margin;
+    uint32_t bits;  // 1,2,4: the axis is used (|d| >= 0.01); 8,16,32: d > 0 on that axis (the near face is `lo`)
+};
+__device__ __forceinline__ void prune_prepare(Prune &P, const Ray &R, float scene_scale) {
+    P.bits = (fabsf(R.dx) >= 0.01f ? 1u : 0u) | (fabsf(R.dy) >= 0.01f ? 2u : 0u) | (fabsf(R.dz) >= 0.01f ? 4u : 0u) |
+             (R.dx > 0 ? 8u : 0u) | (R.dy > 0 ? 16u : 0u) | (R.dz > 0 ? 32u : 0u);
+    P.margin = 1e-3f * fmaxf(fmaxf(scene_scale, fabsf(R.ox)), fmaxf(fabsf(R.oy), fabsf(R.oz)));
+}
+// (cx, cy, cz): per axis the loose box's `lo` where d > 0, else its `hi`
+__device__ __forceinline__ float prune_bound(const Prune &P, const Ray &R, float cx, float cy, float cz) {
+    const float tx = (P.bits & 1u) ? (cx - R.ox) * R.ix : -INFINITY;
+    const float ty = (P.bits & 2u) ? (cy - R.oy) * R.iy : -INFINITY;
+    const float tz = (P.bits & 4u) ? (cz - R.oz) * R.iz : -INFINITY;
+    const float lb = fmaxf(fmaxf(tx, ty), tz);
+    return lb - (fabsf(lb) * 1e-4f + P.margin);
 }
 
 // BoundingBox::hasIntersection (BoundingBox.h:85-108).  The reference returns early per axis; t0 only

@@ -26,6 +26,8 @@ struct HeavyState {   // all wave-uniform
     float mmin, mt;
     uint32_t mtri;
     uint32_t guard;   // remaining loop iterations for this ray: every loop of the walk is bounded by it
+    float tmin_scene; // closest-hit walks: best distance over the meshes walked so far (distance pruning, kernel_common.h)
+    Prune prune;
     bool stop;        // shadow walks: an accepted hit within the light's distance ends the walk (kernel_walk.h: shadow_hit_occludes)
     float light_dist;
     __device__ __forceinline__ bool go() const { return guard != 0 && !stop; }
@@ -134,7 +136,17 @@ __device__ __forceinline__ ChunkBoxes heavy_chunk_load(const KernelArgs &A, cons
 template <int LEVEL, bool SHADOW>
 __device__ __forceinline__ void heavy_chunk(const KernelArgs &A, const Ray &R, const bool primary, const HeavyMesh &M,
                                             const uint32_t chunk, const ChunkBoxes &C, HeavyState &H, const uint32_t lane) {
-    const bool hit = C.valid && slab_test(R, C.b0.x, C.b0.y, C.b0.z, C.b1.x, C.b1.y, C.b1.z);
+    bool hit = C.valid && slab_test(R, C.b0.x, C.b0.y, C.b0.z, C.b1.x, C.b1.y, C.b1.z);
+    if (!SHADOW && (A.prune & 2u)) {
+        const float bound = fminf(H.tmin_scene, H.mmin);  // wave-uniform
+        if (bound < INFINITY && __ballot(hit)) {
+            const uint32_t idx = chunk * 64u + lane;
+            const size_t at = (size_t)M.first[LEVEL] + (C.valid ? idx : 0u);
+            const float4 l0 = A.hloose[2 * at], l1 = A.hloose[2 * at + 1];
+            const float cx = (H.prune.bits & 8u) ? l0.x : l1.x, cy = (H.prune.bits & 16u) ? l0.y : l1.y, cz = (H.prune.bits & 32u) ? l0.z : l1.z;
+            hit = hit && !(prune_bound(H.prune, R, cx, cy, cz) >= bound);
+        }
+    }
     if constexpr (LEVEL == 0) {
         if (__ballot(hit)) heavy_leaves<SHADOW>(A, R, primary, hit, __float_as_uint(C.b0.w), __float_as_uint(C.b1.w), H, lane);
     } else {
@@ -186,6 +198,8 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const Ray &R, co
     H.guard = 1u << 18;
     H.stop = false;
     H.light_dist = light_dist;
+    H.tmin_scene = INFINITY;
+    if (!SHADOW) prune_prepare(H.prune, R, A.scene_scale);
     while (ti != END && H.go()) {  // the top-level tree is tiny: walked node by node, uniformly
         H.guard--;
         const float4 q0 = A.nodes[2 * (size_t)ti], q1 = A.nodes[2 * (size_t)ti + 1];
@@ -208,7 +222,7 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const Ray &R, co
                         if (len3(px - R.ox, py - R.oy, pz - R.oz) <= light_dist) occluded = true;
                     } else {
                         if (!have) { have = true; bt = H.mt; btri = H.mtri; bmesh = mi; }
-                        if (H.mt < tmin) { tmin = H.mt; bt = H.mt; btri = H.mtri; bmesh = mi; }
+                        if (H.mt < tmin) { tmin = H.mt; bt = H.mt; btri = H.mtri; bmesh = mi; H.tmin_scene = tmin; }
                     }
                 }
             }

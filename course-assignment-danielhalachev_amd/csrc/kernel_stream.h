@@ -341,6 +341,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_lean(const KernelArg
                     if (R.parmask != 0) { A.s_counts[SC_OVERFLOW] = 1; continue; }  // cannot walk it here: let the fallback redo the frame
                 }
                 lean_begin(W, A.top_root);
+                if constexpr (QUAD) prune_prepare(W.prune, R, A.scene_scale);
                 steps = 0;
                 state = ST_TRAVERSE;
             }

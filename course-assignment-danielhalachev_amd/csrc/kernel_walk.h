@@ -164,6 +164,7 @@ struct QuadWalk {
     uint32_t btri, bmesh;
     bool have, occluded;
     float light_dist;
+    Prune prune;       // closest-hit walks (kernel_common.h: distance pruning)
 };
 
 __device__ __forceinline__ void lean_begin(QuadWalk &W, uint32_t top_root) {
@@ -219,13 +220,23 @@ __device__ __forceinline__ int quad_walk(QuadWalk &W, const Ray &R, const bool p
         } else if (W.q != NONE) {
             // ---- one quad: four boxes (BoundingBox.h:85-108), the slots that pass go on the stack, last first
             if (W.sp + 4 > A.quad_stack_depth) return WALK_STACK_FULL;
-            const float4 *Q = reinterpret_cast<const float4 *>(quads_b + (size_t)(uint32_t)(W.q << 7));
+            const float4 *Q = reinterpret_cast<const float4 *>(quads_b + (size_t)(uint32_t)(W.q << 8));
             const float4 lx = Q[0], ly = Q[1], lz = Q[2], hx = Q[3], hy = Q[4], hz = Q[5];
             const uint4 lk = reinterpret_cast<const uint4 *>(Q)[6];
-            const bool h0 = lk.x != NONE && slab_test_no_parallel(R, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x);
-            const bool h1 = lk.y != NONE && slab_test_no_parallel(R, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y);
-            const bool h2 = lk.z != NONE && slab_test_no_parallel(R, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z);
-            const bool h3 = lk.w != NONE && slab_test_no_parallel(R, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w);
+            bool h0 = lk.x != NONE && slab_test_no_parallel(R, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x);
+            bool h1 = lk.y != NONE && slab_test_no_parallel(R, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y);
+            bool h2 = lk.z != NONE && slab_test_no_parallel(R, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z);
+            bool h3 = lk.w != NONE && slab_test_no_parallel(R, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w);
+            if (!SHADOW && (A.prune & 1u)) {
+                const float bound = fminf(W.tmin, W.mmin);  // only a strictly smaller distance changes anything
+                if (bound < INFINITY) {
+                    const float4 cx = Q[(W.prune.bits & 8u) ? 8 : 11], cy = Q[(W.prune.bits & 16u) ? 9 : 12], cz = Q[(W.prune.bits & 32u) ? 10 : 13];
+                    h0 = h0 && !(prune_bound(W.prune, R, cx.x, cy.x, cz.x) >= bound);
+                    h1 = h1 && !(prune_bound(W.prune, R, cx.y, cy.y, cz.y) >= bound);
+                    h2 = h2 && !(prune_bound(W.prune, R, cx.z, cy.z, cz.z) >= bound);
+                    h3 = h3 && !(prune_bound(W.prune, R, cx.w, cy.w, cz.w) >= bound);
+                }
+            }
             // push(x): the old top goes to LDS, x becomes the top
 #define CRT_QPUSH(x)                                                   \
     do {                                                               \

@@ -61,6 +61,11 @@ def test_ppm_file_matches_reference_bytes(pkg, scenes, tmp_path):
     {"CRT_PACKET_BUDGET": "60", "CRT_STEP_BUDGET": "64"},              # level 0 by packets, most walks abandoned to the stream
     {"CRT_PACKET_BUDGET": "100000"},                                   # level 0 by packets, nothing abandoned
     {"CRT_SIDE_BLOCKS": "0"},                                          # no side stream
+    {"CRT_QUAD": "7", "CRT_HEAVY_LEVEL": "0"},                         # quad-node walk in every lean kernel
+    {"CRT_QUAD": "7", "CRT_QUAD_STACK": "4", "CRT_HEAVY_LEVEL": "0"},  # ... with a stack so short that walks overflow into heavy_trace
+    {"CRT_QUAD": "0", "CRT_HEAVY_LEVEL": "0"},                         # binary lean walk (no pruning there)
+    {"CRT_PRUNE": "0"},                                                # closest-hit walks without distance pruning
+    {"CRT_STEP_BUDGET": "100000", "CRT_SHADOW_BUDGET": "100000", "CRT_HEAVY_LEVEL": "0"},  # nothing evicted: lean kernels alone
 ])
 @pytest.mark.parametrize("name", ["hw11", "hw12", "hw14"])
 def test_every_kernel_path_gives_the_same_frame(pkg, scenes, oracle, name, env, tmp_path, monkeypatch):
@@ -205,3 +210,35 @@ def test_full_size_sample_against_oracle(full_hw14, oracle, scenes):
             org, d = o.camera_ray(row, col)
             buf[row, col] = o.shoot(org, d, ray_type=0, depth=0, max_depth=8)
             assert np.array_equal(buf[row, col].view(np.uint32), got[row, col].view(np.uint32)), (row, col)
+
+
+def _random_camera(rng, scene_radius):
+    # a camera anywhere in (and around) the scene looking anywhere: rays that start inside meshes, graze boxes, run along axes
+    pos = rng.uniform(-scene_radius, scene_radius, 3).astype(np.float32)
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    rot = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                    [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                    [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], dtype=np.float32)
+    return pos, rot.reshape(9)
+
+
+@pytest.mark.parametrize("name", ["hw11", "hw14", "hw12"])
+def test_early_exits_change_nothing_from_random_viewpoints(pkg, scenes, name, tmp_path, monkeypatch):
+    """Distance pruning and the shadow early exit skip work the reference does; the frames must not move by a bit.
+    The counting build walks every ray to the end the reference's way (and is itself checked against the oracle
+    above), so it is the yardstick here, from viewpoints the fixed camera never shows."""
+    scene = scenes.make(name, width=192, height=108, detail=0.5)
+    folder = str(tmp_path)
+    tracer = make_tracer(pkg, scenes, scene, folder)
+    depth = scenes.CONFIGS[name][3]
+    rng = np.random.default_rng(1234)
+    for k in range(6):
+        pos, mat = _random_camera(rng, 2.5)
+        if k == 0:                                        # axis-aligned view from the origin: rays parallel to box faces
+            pos, mat = np.zeros(3, np.float32), np.eye(3, dtype=np.float32).reshape(9)
+        tracer.set_camera(pos, mat)
+        want = tracer.render(max_depth=depth, counters=True).copy()
+        got = tracer.render(max_depth=depth)
+        assert_same_floats(got, want, "%s view %d" % (name, k))
