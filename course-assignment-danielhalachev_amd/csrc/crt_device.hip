@@ -116,6 +116,7 @@ struct crt_ctx {
     bool lean_ok = true;              // 32-bit byte offsets reach every node and leaf entry
     uint32_t use_quads = 1;           // CRT_QUAD: which lean kernels walk quad nodes (bit 0 levels, 1 shadow pass 0, 2 shadow pass 1)
     uint32_t quad_stack_depth = 16;   // CRT_QUAD_STACK
+    uint32_t heavy_blocks = 4096;     // CRT_HEAVY_BLOCKS: grid of the wave-per-ray kernels (more blocks than fit: late ones balance the load)
     uint32_t prune = 0;               // CRT_PRUNE: distance pruning of closest-hit walks (kernel_common.h); bit 0 quad walk, bit 1 heavy_trace
     uint32_t n_quads = 0;
     uint32_t side_blocks_per_cu = 4;  // CRT_SIDE_BLOCKS: blocks per CU of the overlapped shadow pass
@@ -653,6 +654,8 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
         ctx->lean_ok = s->n_nodes < (1u << 27) && s->n_leaf_triangles < (1ull << 26);
         const char *qd = getenv("CRT_QUAD");
         if (qd && ctx->use_quads) ctx->use_quads = (uint32_t)atoi(qd) & 7u;
+        const char *hb = getenv("CRT_HEAVY_BLOCKS");
+        if (hb && atoi(hb) > 0) ctx->heavy_blocks = (uint32_t)atoi(hb);
         const char *pr = getenv("CRT_PRUNE");
         if (pr) ctx->prune = (uint32_t)atoi(pr) & 3u;
         const char *qs = getenv("CRT_QUAD_STACK");
@@ -867,7 +870,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         A.quad_stack_depth = ctx->quad_stack_depth;
         A.prune = ctx->prune;
         const uint32_t qlds = ctx->quad_stack_depth * BLOCK * (uint32_t)sizeof(uint32_t);
-        const uint32_t heavy_blocks = ctx->grid_blocks < 1024u ? ctx->grid_blocks : 1024u;
+        const uint32_t heavy_blocks = ctx->heavy_blocks;
         const bool packets = lean && ctx->packet_budget != 0 && !(ctx->debug_skip & 512u);
         if (packets) {
             // 0) recursion level 0 for every tile whose rays stay coherent: packets, scalar-load path

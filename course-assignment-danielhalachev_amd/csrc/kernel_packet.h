@@ -173,7 +173,6 @@ __global__ __launch_bounds__(BLOCK) void render_packets(const KernelArgs A) {
         uint32_t btri = 0, bmesh = 0;
         int budget = A.packet_budget ? (int)A.packet_budget : 0x7FFFFFFF;
         packet_walk<false, true, COUNT>(A, R, on, 0.0f, have, bt, btri, bmesh, occluded, cnt, budget);
-        if (budget < 0 && lane == 0) atomicAdd(A.s_counts + 400, 1u);  // experiment: aborted walks
 
         // ---- shootRay's dispatch on the material (RayTracer.cpp:431-450)
         float cx = A.bgx, cy = A.bgy, cz = A.bgz;
@@ -214,7 +213,6 @@ __global__ __launch_bounds__(BLOCK) void render_packets(const KernelArgs A) {
                 uint32_t stri, smesh;
                 int sbudget = A.packet_budget ? (int)A.packet_budget : 0x7FFFFFFF;
                 packet_walk<true, false, COUNT>(A, SR, diffuse, dist, shave, st, stri, smesh, socc, cnt, sbudget);
-                if (sbudget < 0 && lane == 0) atomicAdd(A.s_counts + 401, 1u);
                 if (diffuse && !socc) {
                     if (COUNT && base_is_bitmap) cnt[C_TEXEL]++;
                     accx += kfac * basex; accy += kfac * basey; accz += kfac * basez;
