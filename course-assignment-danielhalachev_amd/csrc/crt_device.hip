@@ -112,7 +112,7 @@ struct crt_ctx {
     uint32_t heavy_cap = 0;
     uint32_t step_budget = 512;       // CRT_STEP_BUDGET: closest-hit walks are evicted to heavy_trace after this many steps (0 = never)
     uint32_t shadow_budget = 8192;    // CRT_SHADOW_BUDGET: same for shadow walks (one big launch: only its tail matters)
-    uint32_t heavy_level_threshold = 50000;  // CRT_HEAVY_LEVEL: levels with fewer rays go to heavy_trace whole
+    uint32_t heavy_level_threshold = 100000;  // CRT_HEAVY_LEVEL: levels with fewer rays go to heavy_trace whole
     bool lean_ok = true;              // 32-bit byte offsets reach every node and leaf entry
     uint32_t use_quads = 1;           // CRT_QUAD: which lean kernels walk quad nodes (bit 0 levels, 1 shadow pass 0, 2 shadow pass 1)
     uint32_t quad_stack_depth = 16;   // CRT_QUAD_STACK

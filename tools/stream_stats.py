@@ -3,7 +3,10 @@ import importlib, sys, ctypes as C
 sys.path.insert(0, '.')
 pkg = importlib.import_module('course-assignment-danielhalachev_amd'); sc = pkg.scenes
 name = sys.argv[1] if len(sys.argv) > 1 else 'hw14'
-s = sc.make(name); hs = pkg.Scene(json_text=sc.to_json(s)); tr = pkg.Tracer(hs)
+import tempfile
+s = sc.make(name); folder = tempfile.mkdtemp() + '/'
+if s.get('textures'): sc.write_bitmaps(s, folder)
+hs = pkg.Scene(json_text=sc.to_json(s), folder=folder); tr = pkg.Tracer(hs)
 depth = sc.CONFIGS[name][3]
 for i in range(3):
     tr.render(max_depth=depth)
