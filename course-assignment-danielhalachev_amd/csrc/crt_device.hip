@@ -864,8 +864,8 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         const bool heavy = ctx->step_budget && A.nested_boxes && !count;
         A.step_budget = heavy ? ctx->step_budget : 0u;
         A.debug = ctx->debug_skip;
-        A.heavy_level_threshold = ctx->heavy_level_threshold;
         const bool lean = heavy && ctx->lean_ok && !(ctx->debug_skip & 256u);
+        A.heavy_level_threshold = lean ? ctx->heavy_level_threshold : 0u;
         const uint32_t quad = lean ? ctx->use_quads : 0u;  // bit 0: the levels, bit 1: shadow pass 0, bit 2: shadow pass 1
         A.quad_stack_depth = ctx->quad_stack_depth;
         A.prune = ctx->prune;

@@ -240,13 +240,15 @@ __device__ __forceinline__ float uniform_f(float v) { return __uint_as_float(__b
 __global__ __launch_bounds__(BLOCK) void heavy_trace_closest(const KernelArgs A, const uint32_t gen) {
     const uint32_t lane = threadIdx.x & 63u;
     if (A.s_counts[SC_OVERFLOW]) return;
-    uint32_t total = A.s_counts[SC_HEAVY + gen];
+    const uint32_t count = stream_level_count(A, gen);
+    const bool whole = stream_level_is_whole_heavy(A, gen, count);  // every ray of the level: entry k is ray k
+    uint32_t total = whole ? count : A.s_counts[SC_HEAVY + gen];
     if (total > A.s_heavy_cap) total = A.s_heavy_cap;
     const float4 *in_q = A.s_rayq[gen & 1u];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
     const uint32_t n_waves = gridDim.x * (BLOCK / 64);
     for (uint32_t k = wave; k < total; k += n_waves) {  // one evicted ray per wave and trip
-        const uint32_t r = A.s_heavy[k];
+        const uint32_t r = whole ? k : A.s_heavy[k];
         Ray R;
         bool primary = false;
         if (gen == 0) {

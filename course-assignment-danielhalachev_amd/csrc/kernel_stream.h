@@ -47,6 +47,10 @@ static_assert(SC_OVERFLOW == SC_OVERFLOW_WORD, "kernel_common.h SC_OVERFLOW_WORD
 __device__ __forceinline__ uint32_t stream_level_count(const KernelArgs &A, uint32_t g) {
     return g == 0 ? A.n_items * 64u : A.s_counts[SC_COUNT + g];
 }
+// Levels below the threshold skip the per-lane kernel: list entry k of the wave-per-ray kernel is ray k itself.
+__device__ __forceinline__ bool stream_level_is_whole_heavy(const KernelArgs &A, uint32_t g, uint32_t count) {
+    return g > 0 && count < A.heavy_level_threshold && count <= A.s_heavy_cap;  // s_hits holds s_heavy_cap records
+}
 __device__ __forceinline__ uint32_t stream_level_base(const KernelArgs &A, uint32_t g) {
     uint32_t base = 0;
     for (uint32_t k = 0; k < g; k++) base += stream_level_count(A, k);
@@ -306,8 +310,8 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_lean(const KernelArg
     // level 0 after stream_packets_gen0: only the tiles that kernel gave up on
     const bool todo = gen == 0 && A.use_packets;
     const uint32_t fetch_count = todo ? A.s_counts[SC_TODO_TILES] * 64u : count;
-    // a small level is all tail: hand every ray to the wave-per-ray kernel straight away
-    const bool all_heavy = gen > 0 && count < A.heavy_level_threshold;
+    // a small level is all tail: heavy_trace_closest walks every ray of it (it applies the same rule)
+    if (stream_level_is_whole_heavy(A, gen, count)) return;
 
     Ray R;
     typename std::conditional<QUAD, QuadWalk, LeanWalk>::type W;
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_lean(const KernelArg
                     normalize3(R.dx, R.dy, R.dz);  // shootRay entry (RayTracer.cpp:420)
                     ray_prepare(R);
                 }
-                if (all_heavy || R.parmask != 0) {
+                if (R.parmask != 0) {
                     if (evict_ray(A.s_heavy, A.s_heavy_cap, A.s_counts + SC_HEAVY + gen, r, lane)) continue;
                     if (R.parmask != 0) { A.s_counts[SC_OVERFLOW] = 1; continue; }  // cannot walk it here: let the fallback redo the frame
                 }
@@ -485,16 +489,17 @@ template <bool COUNT>
 __global__ __launch_bounds__(BLOCK) void stream_shade_evicted(const KernelArgs A, const uint32_t gen) {
     const uint32_t lane = threadIdx.x & 63u;
     if (A.s_counts[SC_OVERFLOW]) return;
-    uint32_t total = A.s_counts[SC_HEAVY + gen];
-    if (total > A.s_heavy_cap) total = A.s_heavy_cap;
     const uint32_t count = stream_level_count(A, gen);
+    const bool whole = stream_level_is_whole_heavy(A, gen, count);
+    uint32_t total = whole ? count : A.s_counts[SC_HEAVY + gen];
+    if (total > A.s_heavy_cap) total = A.s_heavy_cap;
     const uint32_t node_base = stream_level_base(A, gen);
     const uint32_t child_base = node_base + count;
     const float4 *in_q = A.s_rayq[gen & 1u];
     uint32_t cnt[C_N];
     if (COUNT) for (int k = 0; k < C_N; k++) cnt[k] = 0;
     for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < total; k += gridDim.x * BLOCK) {
-        const uint32_t r = A.s_heavy[k];
+        const uint32_t r = whole ? k : A.s_heavy[k];
         Ray R;
         if (gen == 0) {
             const WorkItem wi = A.items[r >> 6];
