@@ -116,6 +116,7 @@ struct crt_ctx {
     bool lean_ok = true;              // 32-bit byte offsets reach every node and leaf entry
     uint32_t use_quads = 1;           // CRT_QUAD: which lean kernels walk quad nodes (bit 0 levels, 1 shadow pass 0, 2 shadow pass 1)
     uint32_t quad_stack_depth = 16;   // CRT_QUAD_STACK
+    uint32_t pass1_budget = 0;        // CRT_PASS1_BUDGET: cap of the budget of the second shadow pass (0: the step budget)
     uint32_t heavy_blocks = 4096;     // CRT_HEAVY_BLOCKS: grid of the wave-per-ray kernels (more blocks than fit: late ones balance the load)
     uint32_t prune = 0;               // CRT_PRUNE: distance pruning of closest-hit walks (kernel_common.h); bit 0 quad walk, bit 1 heavy_trace
     uint32_t n_quads = 0;
@@ -654,6 +655,8 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
         ctx->lean_ok = s->n_nodes < (1u << 27) && s->n_leaf_triangles < (1ull << 26);
         const char *qd = getenv("CRT_QUAD");
         if (qd && ctx->use_quads) ctx->use_quads = (uint32_t)atoi(qd) & 7u;
+        const char *p1 = getenv("CRT_PASS1_BUDGET");
+        if (p1) ctx->pass1_budget = (uint32_t)strtoul(p1, nullptr, 10);
         const char *hb = getenv("CRT_HEAVY_BLOCKS");
         if (hb && atoi(hb) > 0) ctx->heavy_blocks = (uint32_t)atoi(hb);
         const char *pr = getenv("CRT_PRUNE");
@@ -881,8 +884,22 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         }
         KernelArgs S = A;  // argument block of the shadow passes
         S.counters = ctx->d_counters + C_N;
-        S.step_budget = heavy ? ctx->shadow_budget : 0u;
+        {
+            // Pass 0 is one persistent launch: it ends when its longest walk ends, so the budget after which a walk is
+            // handed to heavy_trace_shadow should be about the steps one lane gets through in the whole launch --
+            // rays per lane x ~270 steps per ray (measured average on the benchmark scenes) -- and no more than the cap
+            // (CRT_SHADOW_BUDGET).  A rank that renders 1/8 of the tiles gets 1/8 of the budget.
+            const uint64_t lanes = (uint64_t)ctx->num_cus * (ctx->side_blocks_per_cu ? ctx->side_blocks_per_cu : 8u) * BLOCK;
+            const uint64_t est = (uint64_t)n_items * 64u * (ctx->n_lights ? ctx->n_lights : 1u) * 270u / (lanes ? lanes : 1u);
+            uint32_t budget = est > ctx->shadow_budget ? ctx->shadow_budget : (uint32_t)est;
+            if (budget < ctx->step_budget) budget = ctx->step_budget < ctx->shadow_budget ? ctx->step_budget : ctx->shadow_budget;
+            S.step_budget = heavy ? budget : 0u;
+        }
+        // the same reasoning for level 0 (one launch over all primary rays, ~150 steps per ray)
+        const uint64_t est0 = (uint64_t)n_items * 64u * 150u / ((uint64_t)lane_blocks * BLOCK);
+        const uint32_t budget0 = est0 >= ctx->step_budget ? ctx->step_budget : (est0 < 64u ? 64u : (uint32_t)est0);
         for (uint32_t g = 0; g <= o->max_depth; g++) {
+            A.step_budget = heavy ? (g == 0 ? budget0 : ctx->step_budget) : 0u;
             if (count) launch(stream_trace_shade<true>, lane_blocks, stream, A, g);
             else if (lean && (quad & 1u)) launch_lds(stream_trace_shade_lean<true>, lane_blocks, qlds, stream, A, g);
             else if (lean) launch(stream_trace_shade_lean<false>, lane_blocks, stream, A, g);
@@ -919,7 +936,13 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         // 2b) the shadow rays of the deeper levels, then the evicted shadow walks of both passes
         CRT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_s1[slot], 0));
         S.counters = ctx->d_counters + 2 * C_N;
-        S.step_budget = heavy ? ctx->step_budget : 0u;  // few rays: all tail, so the short budget of the levels
+        {
+            // few rays, all tail: the short budget of the levels, or less when this launch is small (the deeper levels
+            // queue about a quarter of a shadow ray per pixel on the benchmark scenes)
+            const uint64_t est1 = (uint64_t)n_items * 16u * 270u / ((uint64_t)lane_blocks * BLOCK);
+            const uint32_t env1 = ctx->pass1_budget ? ctx->pass1_budget : ctx->step_budget;
+            S.step_budget = heavy ? (est1 >= env1 ? env1 : (est1 < 64u ? 64u : (uint32_t)est1)) : 0u;
+        }
         if (count) launch(stream_trace_shadow<true>, lane_blocks, stream, S, 1u);
         else if (lean && (quad & 4u)) launch_lds(stream_trace_shadow_lean<1, true>, lane_blocks, qlds, stream, S);
         else if (lean) launch(stream_trace_shadow_lean<1, false>, lane_blocks, stream, S);

@@ -71,7 +71,7 @@ struct KernelArgs {
     uint32_t *deferred;           // capacity n_items*64
     uint32_t *deferred_count;
     uint32_t use_deferred;        // lane kernel: 0 = walk all n_items*64 pixels, 1 = walk the deferred list
-    uint32_t *tile_counter;       // packet kernel: next unassigned work item
+    uint32_t *tile_counter;       // (unused since render_packets deals tiles out statically)
     uint32_t nested_boxes;        // every inner node's child boxes lie inside its own box (checked by crt_create)
     // ray-stream buffers (kernel_stream.h)
     float4 *s_rayq[2];            // closest-hit ray queues of alternating recursion levels, 2 x float4 per ray

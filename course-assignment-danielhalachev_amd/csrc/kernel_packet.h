@@ -150,11 +150,10 @@ __global__ __launch_bounds__(BLOCK) void render_packets(const KernelArgs A) {
     uint32_t cnt[C_N], saved[C_N];
     if (COUNT) for (int k = 0; k < C_N; k++) cnt[k] = 0;
 
-    for (;;) {
-        uint32_t item = 0;
-        if (lane == 0) item = atomicAdd(A.tile_counter, 1u);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= A.n_items) break;
+    // static round-robin over the tiles (no atomic fetch + break on a wave-uniform value here: DESIGN.md "compiler notes")
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
+    const uint32_t n_waves = gridDim.x * (BLOCK / 64);
+    for (uint32_t item = wave; item < A.n_items; item += n_waves) {
         const WorkItem wi = A.items[item];
         const uint32_t px = (wi.tile % A.tiles_x) * TILE + (lane & 7u);
         const uint32_t py = (wi.tile / A.tiles_x) * TILE + (lane >> 3);
