@@ -107,7 +107,7 @@ struct crt_ctx {
     uint32_t *d_todo_tiles = nullptr, *d_todo_shadow = nullptr;  // what stream_packets_gen0 gave up on
     uint32_t packet_budget = 0;       // CRT_PACKET_BUDGET: level 0 by packets, a walk abandoned after this many wave-level visits (0 = off, default: measured slower overall)
     hipStream_t side = nullptr;       // shadow pass 0 overlaps the deeper recursion levels on this stream
-    hipEvent_t ev_fork[EV_RING] = {}, ev_s0[EV_RING] = {}, ev_s1[EV_RING] = {}, ev4[EV_RING] = {};
+    hipEvent_t ev_fork[EV_RING] = {}, ev_s0[EV_RING] = {}, ev_s1[EV_RING] = {}, ev_s2[EV_RING] = {}, ev4[EV_RING] = {};
     float4 *d_hits = nullptr;         // their closest hits
     uint32_t heavy_cap = 0;
     uint32_t step_budget = 512;       // CRT_STEP_BUDGET: closest-hit walks are evicted to heavy_trace after this many steps (0 = never)
@@ -348,6 +348,7 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
         CK(hipEventCreate(&ctx->ev_fork[i]));
         CK(hipEventCreate(&ctx->ev_s0[i]));
         CK(hipEventCreate(&ctx->ev_s1[i]));
+        CK(hipEventCreate(&ctx->ev_s2[i]));
     }
 
     ctx->width = s->width;
@@ -714,6 +715,7 @@ extern "C" void crt_destroy(crt_ctx *ctx) {
         if (ctx->ev_fork[i]) (void)hipEventDestroy(ctx->ev_fork[i]);
         if (ctx->ev_s0[i]) (void)hipEventDestroy(ctx->ev_s0[i]);
         if (ctx->ev_s1[i]) (void)hipEventDestroy(ctx->ev_s1[i]);
+        if (ctx->ev_s2[i]) (void)hipEventDestroy(ctx->ev_s2[i]);
     }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
@@ -880,7 +882,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
             A.use_packets = 1;
             const uint32_t need = (n_items + BLOCK / 64 - 1) / (BLOCK / 64);
             launch(stream_packets_gen0, need < ctx->grid_blocks ? need : ctx->grid_blocks, stream, A);
-            hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, stream, A);
+            hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, stream, A, (uint32_t)SC_SHADOW_SPLIT, (uint32_t)SC_SHADOW);
         }
         KernelArgs S = A;  // argument block of the shadow passes
         S.counters = ctx->d_counters + C_N;
@@ -908,7 +910,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
                 if (!(ctx->debug_skip & 1u)) launch(heavy_trace_closest, heavy_blocks, stream, A, g);
                 if (!(ctx->debug_skip & 2u)) launch(stream_shade_evicted<false>, 256u, stream, A, g);
             }
-            if (g == 0 && !packets) hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, stream, A);
+            if (g == 0 && !packets) hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, stream, A, (uint32_t)SC_SHADOW_SPLIT, (uint32_t)SC_SHADOW);
             if (g == 0 && ctx->side_blocks_per_cu) {
                 // 2a) the shadow rays level 0 queued (the bulk of them) start now, beside the deeper levels
                 CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork[slot], stream));
@@ -920,7 +922,12 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
                 else if (lean && (quad & 2u)) launch_lds(stream_trace_shadow_lean<0, true>, side_blocks, qlds, ctx->side, S);
                 else if (lean) launch(stream_trace_shadow_lean<0, false>, side_blocks, ctx->side, S);
                 else launch(stream_trace_shadow<false>, side_blocks, ctx->side, S, 0u);
+                // the walks it gave up follow at once, still beside the levels; the mark comes before the event the
+                // caller's stream waits for, so nothing the later pass appends is below it
+                if (heavy && !count) hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, ctx->side, S, (uint32_t)SC_SHEAVY_SPLIT, (uint32_t)SC_SHEAVY);
                 CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s1[slot], ctx->side));
+                if (heavy && !count && !(ctx->debug_skip & 4u)) launch(heavy_trace_shadow, heavy_blocks, ctx->side, S, 0u);
+                CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s2[slot], ctx->side));
             }
         }
         CRT_HIP_CHECK(ctx, hipGetLastError());
@@ -947,7 +954,8 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         else if (lean && (quad & 4u)) launch_lds(stream_trace_shadow_lean<1, true>, lane_blocks, qlds, stream, S);
         else if (lean) launch(stream_trace_shadow_lean<1, false>, lane_blocks, stream, S);
         else launch(stream_trace_shadow<false>, lane_blocks, stream, S, 1u);
-        if (heavy && !(ctx->debug_skip & 4u)) launch(heavy_trace_shadow, heavy_blocks, stream, S);
+        if (ctx->side_blocks_per_cu) CRT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_s2[slot], 0));
+        if (heavy && !(ctx->debug_skip & 4u)) launch(heavy_trace_shadow, heavy_blocks, stream, S, 1u);
         CRT_HIP_CHECK(ctx, hipGetLastError());
         if (timed) CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev2[slot], stream));
         A.counters = ctx->d_counters + 2 * C_N;
@@ -1125,6 +1133,12 @@ extern "C" int crt_unpack_tiles_device(crt_ctx *ctx, const float *d_packed_all, 
     if (!ctx || !d_packed_all || !d_frame || n_parts == 0) return CRT_ERR_INVALID;
     CRT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const uint32_t n_tiles = ctx->tiles_x * ctx->tiles_y;
+    // part p holds tiles p, p + n_parts, ...: the stride must cover the largest part, or the kernel would read past it
+    const uint64_t tiles_per_part = ((uint64_t)n_tiles + n_parts - 1) / n_parts;
+    if (part_stride_floats < tiles_per_part * 64 * 3) {
+        ctx->error = "crt_unpack_tiles_device: part_stride_floats is smaller than one part's tiles (ceil(tiles / n_parts) * 192 floats)";
+        return CRT_ERR_INVALID;
+    }
     const uint64_t threads = (uint64_t)n_tiles * 64;
     hipLaunchKernelGGL(unpack_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_packed_all,
                        n_parts, part_stride_floats, d_frame, ctx->width, ctx->height, ctx->tiles_x, n_tiles);

@@ -275,14 +275,19 @@ __global__ __launch_bounds__(BLOCK) void heavy_trace_closest(const KernelArgs A,
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void heavy_trace_shadow(const KernelArgs A) {
+// part 0: the walks shadow pass 0 gave up (list entries below the SC_SHEAVY_SPLIT mark), on the side stream right
+// after that pass; part 1: the rest, after the last pass.
+__global__ __launch_bounds__(BLOCK) void heavy_trace_shadow(const KernelArgs A, const uint32_t part) {
     const uint32_t lane = threadIdx.x & 63u;
     if (A.s_counts[SC_OVERFLOW]) return;
-    uint32_t total = A.s_counts[SC_SHEAVY];
+    uint32_t total = A.s_counts[SC_SHEAVY], split = A.s_counts[SC_SHEAVY_SPLIT];
     if (total > A.s_heavy_cap) total = A.s_heavy_cap;
+    if (split > total) split = total;
+    const uint32_t first = part == 0 ? 0u : split;
+    if (part == 0) total = split;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
     const uint32_t n_waves = gridDim.x * (BLOCK / 64);
-    for (uint32_t k = wave; k < total; k += n_waves) {
+    for (uint32_t k = first + wave; k < total; k += n_waves) {
         const uint32_t r = A.s_sheavy[k];
         const float4 q0 = A.s_shadowq[2 * (size_t)r], q1 = A.s_shadowq[2 * (size_t)r + 1];
         Ray R;

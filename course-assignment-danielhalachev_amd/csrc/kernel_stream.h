@@ -40,7 +40,7 @@ constexpr int MAX_GENERATIONS = 64;
 enum : int { SC_COUNT = 0, SC_FETCH = MAX_GENERATIONS, SC_HEAVY = 2 * MAX_GENERATIONS, SC_HEAVY_FETCH = 3 * MAX_GENERATIONS,
              SC_EVICT_FETCH = 4 * MAX_GENERATIONS, SC_SHADOW = 5 * MAX_GENERATIONS, SC_SHADOW_FETCH, SC_OVERFLOW, SC_SHEAVY,
              SC_SHEAVY_FETCH, SC_GUARD, SC_SHADOW_SPLIT, SC_SHADOW_FETCH2,
-             SC_TODO_TILES, SC_TODO_SHADOW, SC_TILE_FETCH, SC_WORDS };
+             SC_TODO_TILES, SC_TODO_SHADOW, SC_TILE_FETCH, SC_SHEAVY_SPLIT, SC_WORDS };
 
 static_assert(SC_OVERFLOW == SC_OVERFLOW_WORD, "kernel_common.h SC_OVERFLOW_WORD must match");
 
@@ -530,8 +530,8 @@ __global__ __launch_bounds__(BLOCK) void stream_shade_evicted(const KernelArgs A
 // The shadow queue is traced in two passes so that the first can overlap the deeper recursion levels:
 // pass 0 = the rays queued by level 0 (indices below the split mark), on a side stream as soon as level 0 is
 // done; pass 1 = the rest, after the last level.
-__global__ void stream_mark_split(const KernelArgs A) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) A.s_counts[SC_SHADOW_SPLIT] = A.s_counts[SC_SHADOW];
+__global__ void stream_mark_split(const KernelArgs A, const uint32_t dst_word, const uint32_t src_word) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) A.s_counts[dst_word] = A.s_counts[src_word];
 }
 
 template <bool COUNT>

@@ -29,3 +29,22 @@ def test_device_pow5_matches_libm(pkg):
     want = libm_pow5(x)
     bad = (got.view(np.uint32) != want.view(np.uint32)) & ~(np.isnan(got) & np.isnan(want))
     assert not bad.any(), "x=%r device %r libm %r (%d mismatches)" % (x[bad][0], got[bad][0], want[bad][0], int(bad.sum()))
+
+
+def test_abi_rejects_inconsistent_arguments(pkg, scenes):
+    """The C ABI answers a malformed call with an error code and a message, never with a launch."""
+    import torch
+    scene = scenes.make("hw08", width=64, height=48, detail=0.2)
+    tracer = pkg.Tracer(pkg.Scene(json_text=scenes.to_json(scene)))
+    frame = torch.zeros(64 * 48 * 3, dtype=torch.float32, device="cuda:0")
+    packed = torch.zeros(48 * 192, dtype=torch.float32, device="cuda:0")   # 8 x 6 tiles
+    # a stride that cannot hold one part's tiles (the kernel would read past the buffer)
+    with pytest.raises(pkg.CrtError) as e:
+        tracer.unpack_tiles_device(packed.data_ptr(), 1, 47 * 192, frame.data_ptr())
+    assert "part_stride_floats" in str(e.value)
+    with pytest.raises(pkg.CrtError):
+        tracer.unpack_tiles_device(packed.data_ptr(), 0, 48 * 192, frame.data_ptr())
+    with pytest.raises(pkg.CrtError):
+        tracer.render(options=pkg.Options(3, 1e-4, 1e-4, 1e-4, 1, 0))      # use_gi = 1: GI is outside this path
+    tracer.unpack_tiles_device(packed.data_ptr(), 1, 48 * 192, frame.data_ptr())   # the consistent call goes through
+    torch.cuda.synchronize()
