@@ -241,6 +241,9 @@ def main():
                          "note": "algorithmic bytes = the reference's tests for these rays (counting build); the production "
                                  "kernel's exact early exit skips part of them, see DESIGN.md section 4",
                          "algorithmic_bytes_per_launch": int(b_alg), "counters": dom_counters,
+                         "recursion_levels": {"kernels": "9 x (stream_trace_shade_lean<true> + heavy_trace_closest + stream_shade_evicted)",
+                                              "algorithmic_bytes": int(b_pk), "kernels_ms": round(pk_ms, 4),
+                                              "achieved": round(b_pk / (pk_ms * 1e-3) / 1e9, 2), "counters": pk_counters},
                          "whole_frame": {"algorithmic_bytes": int(b_all), "kernels_ms": round(avg_kernel_ms, 4),
                                          "achieved": round(b_all / (avg_kernel_ms * 1e-3) / 1e9, 2),
                                          "counters": counters}},
