@@ -212,6 +212,26 @@ def test_full_size_sample_against_oracle(full_hw14, oracle, scenes):
             assert np.array_equal(buf[row, col].view(np.uint32), got[row, col].view(np.uint32)), (row, col)
 
 
+@pytest.mark.parametrize("name", ["hw08", "hw11", "hw12"])
+def test_full_size_configs_against_oracle_samples_and_counting_build(pkg, scenes, oracle, name, tmp_path):
+    """BASELINE.json's other configurations at their full sizes (HW12: 3840x2160 with its bitmap texture): the production
+    kernels must give the counting build's frame bit for bit over the WHOLE frame, and the oracle's colour on a grid of
+    sample pixels (the oracle is too slow for 8 Mpixels inside a test)."""
+    scene = scenes.make(name)
+    depth = scenes.CONFIGS[name][3]
+    tracer = make_tracer(pkg, scenes, scene, str(tmp_path))
+    got = tracer.render(max_depth=depth).copy()
+    ref = tracer.render(max_depth=depth, counters=True)                   # every ray walked the reference's way
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    o = oracle.OracleScene(scenes.to_blob(scene))
+    H, W = got.shape[:2]
+    for row in range(H // 16, H, H // 8):
+        for col in range(W // 64, W, W // 32):
+            org, d = o.camera_ray(row, col)
+            want = o.shoot(org, d, ray_type=0, depth=0, max_depth=depth)
+            assert np.array_equal(want.view(np.uint32), got[row, col].view(np.uint32)), (name, row, col)
+
+
 def _random_camera(rng, scene_radius):
     # a camera anywhere in (and around) the scene looking anywhere: rays that start inside meshes, graze boxes, run along axes
     pos = rng.uniform(-scene_radius, scene_radius, 3).astype(np.float32)
