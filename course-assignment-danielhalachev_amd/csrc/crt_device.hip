@@ -5,18 +5,35 @@
 // 127-192; src/AccelerationStructure.cpp:56-94; include/tracer/BoundingBox.h:85-108;
 // src/Ray.cpp:9-31; src/Triangle.cpp:37-73; src/Texture.cpp:14-72; src/Color.cpp:12-16).
 //
-// Design (see DESIGN.md for the measurements behind it):
-//  * two kernels: render_packets walks the tree ONCE per 8x8 tile for its 64 coherent rays (primary
-//    rays, then one shared walk per light for the tile's shadow rays) with wave-uniform scalar loads of
-//    nodes and triangles; render_lanes (one independent ray per lane, lanes refilled from a global
-//    pixel counter) takes the pixels whose primary hit is reflective/refractive, where rays scatter;
-//  * the reference's stack DFS has a FIXED visit order and no distance pruning, so the tree is
-//    flattened into hit/miss links (crt_node) and walked without any stack;
-//  * the binary reflect/refract recursion is an explicit per-lane frame stack, evaluated in the
-//    reference's post-order so that every float is combined in the same order;
-//  * arithmetic is IEEE binary32 with no contraction (-ffp-contract=off), correctly rounded
-//    divide and sqrt, std::min/std::max semantics written out, so results are bit-identical to
-//    the x86-64 reference build.
+// Design (DESIGN.md has the measurements behind it):
+//  * default path (kernel_stream.h): the reference's recursion unrolled BY RECURSION LEVEL.  Level g is one
+//    launch of a per-lane walk kernel (kernel_walk.h: quad nodes for the levels, binary threaded nodes for the
+//    shadow passes) whose lanes are refilled from a queue; it writes ray-tree nodes, child rays for level g+1
+//    and shadow rays.  Walks that outlast a step budget, and whole small levels, go to a wave-per-ray kernel
+//    (kernel_heavy.h).  The shadow rays of level 0 -- the bulk of the frame -- run on a side stream beside the
+//    deeper levels.  stream_resolve evaluates every pixel's ray tree in the reference's post-order, so that
+//    every float is combined in the same order;
+//  * the reference's stack DFS has a FIXED visit order and no distance pruning, so the trees are flattened into
+//    hit/miss links (crt_node) and walked without a stack; the quad and leaf-sequence forms rest on the boxes
+//    being nested, which crt_create verifies;
+//  * fallbacks, all bit-exact and all tested: render_lanes (kernel_lane.h: the full recursion per lane on an
+//    explicit frame stack; also redoes a frame whose queues overflowed) and render_packets (kernel_packet.h:
+//    one wave per 8x8 tile, scalar loads);
+//  * arithmetic is IEEE binary32 with no contraction (-ffp-contract=off), correctly rounded divide and sqrt,
+//    std::min/std::max semantics written out, so results are bit-identical to the x86-64 reference build.
+//
+// Tuning variables read by crt_create (none is needed; defaults are what bench.py measures):
+//   CRT_MODE=stream|packets|lanes   kernel family (default stream)
+//   CRT_STEP_BUDGET (512)           steps after which a closest-hit walk goes to heavy_trace_closest; 0 = faithful kernels only
+//   CRT_SHADOW_BUDGET (8192)        cap of the same for shadow pass 0 (the launch scales it down with its size)
+//   CRT_PASS1_BUDGET (= step)       cap for the second shadow pass
+//   CRT_HEAVY_LEVEL (100000)        recursion levels with fewer rays skip the per-lane kernel
+//   CRT_HEAVY_BLOCKS (4096)         grid of the wave-per-ray kernels
+//   CRT_SIDE_BLOCKS (4)             workgroups per CU of shadow pass 0 on the side stream; 0 = no side stream
+//   CRT_QUAD (1) / CRT_QUAD_STACK (16)  which lean kernels walk quad nodes (bit 0 levels, 1 shadow pass 0, 2 pass 1); LDS words per lane
+//   CRT_PRUNE (0)                   exact distance pruning of closest-hit walks (bit 0 quad walk, bit 1 heavy_trace)
+//   CRT_PACKET_BUDGET (0)           level 0 by packets first, giving a tile up after this many wave-level visits
+//   CRT_DEBUG_SKIP                  path selection for tests: 256 = no lean kernels (faithful walk + heavy_trace), 512 = no packets
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -121,7 +138,7 @@ struct crt_ctx {
     uint32_t prune = 0;               // CRT_PRUNE: distance pruning of closest-hit walks (kernel_common.h); bit 0 quad walk, bit 1 heavy_trace
     uint32_t n_quads = 0;
     uint32_t side_blocks_per_cu = 4;  // CRT_SIDE_BLOCKS: blocks per CU of the overlapped shadow pass
-    uint32_t debug_skip = 0;          // CRT_DEBUG_SKIP: development only, skips heavy-path launches
+    uint32_t debug_skip = 0;          // CRT_DEBUG_SKIP: path selection for tests (256: no lean kernels, 512: no packets)
     uint64_t stream_items = 0;        // work items the stream buffers are sized for
     uint64_t overflows = 0;           // frames redone by the fallback (diagnostic)
     uint32_t n_lights = 0;
@@ -907,8 +924,8 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
             else if (lean) launch(stream_trace_shade_lean<false>, lane_blocks, stream, A, g);
             else launch(stream_trace_shade<false>, lane_blocks, stream, A, g);
             if (heavy) {
-                if (!(ctx->debug_skip & 1u)) launch(heavy_trace_closest, heavy_blocks, stream, A, g);
-                if (!(ctx->debug_skip & 2u)) launch(stream_shade_evicted<false>, 256u, stream, A, g);
+                launch(heavy_trace_closest, heavy_blocks, stream, A, g);
+                launch(stream_shade_evicted<false>, 256u, stream, A, g);
             }
             if (g == 0 && !packets) hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, stream, A, (uint32_t)SC_SHADOW_SPLIT, (uint32_t)SC_SHADOW);
             if (g == 0 && ctx->side_blocks_per_cu) {
@@ -926,7 +943,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
                 // caller's stream waits for, so nothing the later pass appends is below it
                 if (heavy && !count) hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, ctx->side, S, (uint32_t)SC_SHEAVY_SPLIT, (uint32_t)SC_SHEAVY);
                 CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s1[slot], ctx->side));
-                if (heavy && !count && !(ctx->debug_skip & 4u)) launch(heavy_trace_shadow, heavy_blocks, ctx->side, S, 0u);
+                if (heavy && !count) launch(heavy_trace_shadow, heavy_blocks, ctx->side, S, 0u);
                 CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s2[slot], ctx->side));
             }
         }
@@ -955,7 +972,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         else if (lean) launch(stream_trace_shadow_lean<1, false>, lane_blocks, stream, S);
         else launch(stream_trace_shadow<false>, lane_blocks, stream, S, 1u);
         if (ctx->side_blocks_per_cu) CRT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_s2[slot], 0));
-        if (heavy && !(ctx->debug_skip & 4u)) launch(heavy_trace_shadow, heavy_blocks, stream, S, 1u);
+        if (heavy) launch(heavy_trace_shadow, heavy_blocks, stream, S, 1u);
         CRT_HIP_CHECK(ctx, hipGetLastError());
         if (timed) CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev2[slot], stream));
         A.counters = ctx->d_counters + 2 * C_N;

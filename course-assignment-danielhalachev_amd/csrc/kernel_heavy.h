@@ -213,7 +213,6 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const Ray &R, co
             const uint32_t mi = ent & ~LAST;
             const crt_mesh m = A.meshes[mi];
             if (!(SHADOW && (m.flags & 1u))) {
-                if (A.debug & 32u) { H.mhave = false; } else
                 heavy_mesh<SHADOW>(A, R, primary, mi, H, lane);
                 if (SHADOW && H.stop) { occluded = true; break; }
                 if (H.mhave) {
@@ -270,7 +269,7 @@ __global__ __launch_bounds__(BLOCK) void heavy_trace_closest(const KernelArgs A,
         bool have = false, occluded = false;
         float bt = 0;
         uint32_t btri = 0, bmesh = 0;
-        if (!(A.debug & 16u)) heavy_walk<false>(A, R, primary, 0.0f, have, bt, btri, bmesh, occluded, lane);
+        heavy_walk<false>(A, R, primary, 0.0f, have, bt, btri, bmesh, occluded, lane);
         if (lane == 0) A.s_hits[k] = make_float4(bt, __uint_as_float(btri), __uint_as_float(bmesh), __uint_as_float(have ? 1u : 0u));
     }
 }

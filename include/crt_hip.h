@@ -217,6 +217,13 @@ int crt_device_count(void);
 /* Test hook: out[i] = the device build of the restated glibc powf(x[i], 5) (the Fresnel term, RayTracer.cpp:407). */
 int crt_test_pow5(int device, const float *x, float *out, uint64_t n);
 
+/* Diagnostics for the development tools under tools/ (no counterpart in the reference; not needed to render):
+ * the ray-stream pass's queue counters of the last frame (rays per recursion level, walks handed to the
+ * wave-per-ray kernels, ...: the SC_* layout of csrc/kernel_stream.h, at most 512 words), and the packet kernel's
+ * wave-level visit counts {nodes, triangles, walks} of the last counted render. */
+int crt_debug_stream_counts(crt_ctx *ctx, uint32_t *out_words, uint32_t max_words);
+int crt_debug_packet_counters(crt_ctx *ctx, uint64_t out[3]);
+
 #ifdef __cplusplus
 }
 #endif
