@@ -32,6 +32,7 @@
 //   CRT_SIDE_BLOCKS (4)             workgroups per CU of shadow pass 0 on the side stream; 0 = no side stream
 //   CRT_QUAD (1) / CRT_QUAD_STACK (16)  which lean kernels walk quad nodes (bit 0 levels, 1 shadow pass 0, 2 pass 1); LDS words per lane
 //   CRT_PRUNE (0)                   exact distance pruning of closest-hit walks (bit 0 quad walk, bit 1 heavy_trace)
+//   CRT_FIXED0 (1)                  level 0's shadow rays in fixed tile-ordered slots (0: queued like the deeper levels')
 //   CRT_PACKET_BUDGET (0)           level 0 by packets first, giving a tile up after this many wave-level visits
 //   CRT_DEBUG_SKIP                  path selection for tests: 256 = no lean kernels (faithful walk + heavy_trace), 512 = no packets
 #include <hip/hip_runtime.h>
@@ -133,6 +134,7 @@ struct crt_ctx {
     bool lean_ok = true;              // 32-bit byte offsets reach every node and leaf entry
     uint32_t use_quads = 1;           // CRT_QUAD: which lean kernels walk quad nodes (bit 0 levels, 1 shadow pass 0, 2 shadow pass 1)
     uint32_t quad_stack_depth = 16;   // CRT_QUAD_STACK
+    uint32_t fixed0 = 1;              // CRT_FIXED0
     uint32_t pass1_budget = 0;        // CRT_PASS1_BUDGET: cap of the budget of the second shadow pass (0: the step budget)
     uint32_t heavy_blocks = 4096;     // CRT_HEAVY_BLOCKS: grid of the wave-per-ray kernels (more blocks than fit: late ones balance the load)
     uint32_t prune = 0;               // CRT_PRUNE: distance pruning of closest-hit walks (kernel_common.h); bit 0 quad walk, bit 1 heavy_trace
@@ -673,6 +675,8 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
         ctx->lean_ok = s->n_nodes < (1u << 27) && s->n_leaf_triangles < (1ull << 26);
         const char *qd = getenv("CRT_QUAD");
         if (qd && ctx->use_quads) ctx->use_quads = (uint32_t)atoi(qd) & 7u;
+        const char *f0 = getenv("CRT_FIXED0");
+        if (f0) ctx->fixed0 = (uint32_t)atoi(f0);
         const char *p1 = getenv("CRT_PASS1_BUDGET");
         if (p1) ctx->pass1_budget = (uint32_t)strtoul(p1, nullptr, 10);
         const char *hb = getenv("CRT_HEAVY_BLOCKS");
@@ -891,6 +895,14 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         const uint32_t quad = lean ? ctx->use_quads : 0u;  // bit 0: the levels, bit 1: shadow pass 0, bit 2: shadow pass 1
         A.quad_stack_depth = ctx->quad_stack_depth;
         A.prune = ctx->prune;
+        A.fixed0 = 0;
+        if (ctx->fixed0) {  // level 0 owns the first n_items * 64 * n_lights slots of the shadow queue; the deeper levels append
+            const uint64_t n0 = (uint64_t)n_items * 64u * ctx->n_lights;
+            if (n0 <= A.s_shadow_cap) {
+                A.fixed0 = 1;
+                CRT_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->d_scounts + SC_SHADOW), (int)(uint32_t)n0, 1, stream));
+            }
+        }
         const uint32_t qlds = ctx->quad_stack_depth * BLOCK * (uint32_t)sizeof(uint32_t);
         const uint32_t heavy_blocks = ctx->heavy_blocks;
         const bool packets = lean && ctx->packet_budget != 0 && !(ctx->debug_skip & 512u);

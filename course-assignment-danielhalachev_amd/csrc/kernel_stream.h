@@ -67,6 +67,31 @@ __device__ __forceinline__ uint32_t wave_fetch(uint32_t *cursor, uint32_t lane) 
     return base + (uint32_t)rank;
 }
 
+// wave-aggregated append of this lane's ray id to an eviction list; false when the list is full
+__device__ __forceinline__ bool evict_ray(uint32_t *list, uint32_t cap, uint32_t *count, uint32_t r, uint32_t lane) {
+    const unsigned long long em = __ballot(1);
+    uint32_t base = 0;
+    if ((em & ((1ull << lane) - 1ull)) == 0) base = atomicAdd(count, (uint32_t)__popcll(em));
+    base = __shfl(base, __ffsll((long long)em) - 1);
+    const uint32_t slot = base + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
+    if (slot >= cap) return false;
+    list[slot] = r;
+    return true;
+}
+
+// Level 0 does not queue its shadow rays, it has fixed slots for them: pixel r = 64*item + sub of light li owns slot
+// (item * n_lights + li) * 64 + sub, so that 64 consecutive slots are one 8x8 tile's rays towards one light -- rays that
+// visit the same nodes at the same time, which is what the vector L1 serves cheaply -- and no atomic is needed.  A pixel
+// without a diffuse hit marks its slots unused (distance word all ones: no computed distance has that pattern).
+constexpr uint32_t SHADOW_SLOT_UNUSED = 0xFFFFFFFFu;
+__device__ __forceinline__ uint32_t level0_shadow_slot(const KernelArgs &A, uint32_t r) { return (r >> 6) * A.n_lights * 64u + (r & 63u); }
+__device__ __forceinline__ void level0_release_shadow_slots(const KernelArgs &A, uint32_t r) {
+    if (!A.fixed0) return;
+    const size_t first = level0_shadow_slot(A, r);
+    for (uint32_t li = 0; li < A.n_lights; li++)
+        A.s_shadowq[2 * (first + (size_t)li * 64u)] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(SHADOW_SLOT_UNUSED));
+}
+
 // shootRay's dispatch on the closest hit (RayTracer.cpp:431-450) for ray `r` of level `gen`: writes the ray-tree
 // node, appends the child rays of level gen+1 and the shadow rays.  Called by every lane whose walk has just
 // ended (any subset of the wave); allocations are aggregated over those lanes.
@@ -93,11 +118,17 @@ __device__ __forceinline__ void shade_and_emit(const KernelArgs &A, const uint32
                 texture_color<COUNT>(A, A.textures[S.M.texture], btri, S.u, S.v, 1.0f - S.u - S.v, N.cx, N.cy, N.cz, bitmap);
             else { N.cx = S.M.ax; N.cy = S.M.ay; N.cz = S.M.az; }
             const unsigned long long mask = __ballot(1);
-            const uint32_t cntd = (uint32_t)__popcll(mask);
-            const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            uint32_t cntd = (uint32_t)__popcll(mask);
+            uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
             uint32_t base = 0;
-            if (rank == 0) base = atomicAdd(A.s_counts + SC_SHADOW, cntd * A.n_lights);
-            base = __shfl(base, __ffsll((long long)mask) - 1);
+            if (gen == 0 && A.fixed0) {
+                base = (r >> 6) * A.n_lights * 64u;  // level0_shadow_slot(r) = base + rank, one light apart = 64 slots
+                rank = r & 63u;
+                cntd = 64u;
+            } else {
+                if (rank == 0) base = atomicAdd(A.s_counts + SC_SHADOW, cntd * A.n_lights);
+                base = __shfl(base, __ffsll((long long)mask) - 1);
+            }
             if ((uint64_t)base + (uint64_t)cntd * A.n_lights > A.s_shadow_cap) {
                 A.s_counts[SC_OVERFLOW] = 1;
                 N.cx = N.cy = N.cz = 0;  // the frame is redone by the fallback path
@@ -114,6 +145,11 @@ __device__ __forceinline__ void shade_and_emit(const KernelArgs &A, const uint32
                     const size_t slot = (size_t)base + (size_t)li * cntd + rank;
                     A.s_shadowq[2 * slot] = make_float4(SR.ox, SR.oy, SR.oz, dist);
                     A.s_shadowq[2 * slot + 1] = make_float4(SR.dx, SR.dy, SR.dz, kfac);
+                    // after stream_packets_gen0, shadow pass 0 only walks the listed slots: a tile that kernel gave up
+                    // is shaded here by the per-lane kernel, which lists what it emits
+                    if (gen == 0 && A.fixed0 && A.use_packets && !out_diffuse &&
+                        !evict_ray(A.s_todo_shadow, A.s_shadow_cap, A.s_counts + SC_TODO_SHADOW, (uint32_t)slot, lane))
+                        A.s_counts[SC_OVERFLOW] = 1;
                 }
             }
         } else if (S.M.type == CRT_MAT_REFLECTIVE || S.M.type == CRT_MAT_REFRACTIVE) {
@@ -185,6 +221,7 @@ __device__ __forceinline__ void shade_and_emit(const KernelArgs &A, const uint32
         }
         // any other material type (Constant): background, RayTracer.cpp:443-446
     }
+    if (gen == 0 && (N.kind & TN_KIND_MASK) != TN_DIFFUSE) level0_release_shadow_slots(A, r);
     float4 *dst = A.s_nodes + 2 * ((size_t)node_base + r);
     dst[0] = make_float4(N.cx, N.cy, N.cz, __uint_as_float(N.kind));
     dst[1] = make_float4(__uint_as_float(N.a), __uint_as_float(N.b), N.f, 0.0f);
@@ -221,6 +258,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade(const KernelArgs A, 
                     const uint32_t py = (wi.tile / A.tiles_x) * TILE + (sub >> 3);
                     if (!((wi.mask >> sub) & 1ull) || px >= A.width || py >= A.height) {
                         reinterpret_cast<uint32_t *>(A.s_nodes + 2 * (size_t)r)[3] = TN_SKIP;
+                        level0_release_shadow_slots(A, r);
                         continue;
                     }
                     primary_ray(A, px, py, R);
@@ -282,18 +320,6 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade(const KernelArgs A, 
     }
 }
 
-// wave-aggregated append of this lane's ray id to an eviction list; false when the list is full
-__device__ __forceinline__ bool evict_ray(uint32_t *list, uint32_t cap, uint32_t *count, uint32_t r, uint32_t lane) {
-    const unsigned long long em = __ballot(1);
-    uint32_t base = 0;
-    if ((em & ((1ull << lane) - 1ull)) == 0) base = atomicAdd(count, (uint32_t)__popcll(em));
-    base = __shfl(base, __ffsll((long long)em) - 1);
-    const uint32_t slot = base + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
-    if (slot >= cap) return false;
-    list[slot] = r;
-    return true;
-}
-
 // stream_trace_shade with the lean walk (kernel_walk.h): the non-counting build when heavy_trace is available.
 // Rays with a parallel axis and walks longer than step_budget go to heavy_trace_closest.
 template <bool QUAD>
@@ -330,6 +356,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_lean(const KernelArg
                     const uint32_t py = (wi.tile / A.tiles_x) * TILE + (sub >> 3);
                     if (!((wi.mask >> sub) & 1ull) || px >= A.width || py >= A.height) {
                         reinterpret_cast<uint32_t *>(A.s_nodes + 2 * (size_t)r)[3] = TN_SKIP;
+                        level0_release_shadow_slots(A, r);
                         continue;
                     }
                     primary_ray(A, px, py, R);
@@ -391,6 +418,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shadow_lean(const KernelAr
                 if (r >= total) { state = ST_DONE; break; }
                 r = listed ? A.s_todo_shadow[r] : r + first;
                 const float4 q0 = A.s_shadowq[2 * (size_t)r], q1 = A.s_shadowq[2 * (size_t)r + 1];
+                if (__float_as_uint(q0.w) == SHADOW_SLOT_UNUSED) continue;  // a level-0 pixel without a diffuse hit
                 R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
                 R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;  // already normalised once; shadow rays skip shootRay (RayTracer.cpp:313-317)
                 ray_prepare(R);
@@ -456,7 +484,7 @@ __global__ __launch_bounds__(BLOCK) void stream_packets_gen0(const KernelArgs A)
             bool diffuse = false;
             uint32_t first = 0, stride = 0;
             if (on) shade_and_emit<false>(A, 0u, r, 0u, count, R, have, bt, btri, bmesh, nullptr, lane, &diffuse, &first, &stride);
-            else reinterpret_cast<uint32_t *>(A.s_nodes + 2 * (size_t)r)[3] = TN_SKIP;
+            else { reinterpret_cast<uint32_t *>(A.s_nodes + 2 * (size_t)r)[3] = TN_SKIP; level0_release_shadow_slots(A, r); }
             if (__ballot(diffuse)) {
                 for (uint32_t li = 0; li < A.n_lights; li++) {
                     const size_t slot = (size_t)first + (size_t)li * stride;
@@ -557,13 +585,15 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shadow(const KernelArgs A,
                 else {
                     r += first;
                     const float4 q0 = A.s_shadowq[2 * (size_t)r], q1 = A.s_shadowq[2 * (size_t)r + 1];
-                    R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
-                    R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;  // already normalised once; shadow rays skip shootRay (RayTracer.cpp:313-317)
-                    ray_prepare(R);
-                    L.rtype = RAY_SHADOW;
-                    traversal_begin(L, A.top_root);
-                    L.light_dist = q0.w;
-                    state = ST_TRAVERSE;
+                    if (__float_as_uint(q0.w) != SHADOW_SLOT_UNUSED) {  // (unused: the lane fetches again next trip)
+                        R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
+                        R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;  // already normalised once; shadow rays skip shootRay (RayTracer.cpp:313-317)
+                        ray_prepare(R);
+                        L.rtype = RAY_SHADOW;
+                        traversal_begin(L, A.top_root);
+                        L.light_dist = q0.w;
+                        state = ST_TRAVERSE;
+                    }
                 }
             }
         }
