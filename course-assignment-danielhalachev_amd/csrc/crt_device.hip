@@ -32,6 +32,7 @@
 //   CRT_SIDE_BLOCKS (4)             workgroups per CU of shadow pass 0 on the side stream; 0 = no side stream
 //   CRT_QUAD (1) / CRT_QUAD_STACK (16)  which lean kernels walk quad nodes (bit 0 levels, 1 shadow pass 0, 2 pass 1); LDS words per lane
 //   CRT_PRUNE (0)                   exact distance pruning of closest-hit walks (bit 0 quad walk, bit 1 heavy_trace)
+//   CRT_BUNDLE (16)                 shadow pass 0 refills a wave when at most this many of its lanes still walk (64: lane by lane)
 //   CRT_FIXED0 (1)                  level 0's shadow rays in fixed tile-ordered slots (0: queued like the deeper levels')
 //   CRT_PACKET_BUDGET (0)           level 0 by packets first, giving a tile up after this many wave-level visits
 //   CRT_DEBUG_SKIP                  path selection for tests: 256 = no lean kernels (faithful walk + heavy_trace), 512 = no packets
@@ -135,6 +136,7 @@ struct crt_ctx {
     uint32_t use_quads = 1;           // CRT_QUAD: which lean kernels walk quad nodes (bit 0 levels, 1 shadow pass 0, 2 shadow pass 1)
     uint32_t quad_stack_depth = 16;   // CRT_QUAD_STACK
     uint32_t fixed0 = 1;              // CRT_FIXED0
+    uint32_t bundle = 16;             // CRT_BUNDLE (shadow pass 0)
     uint32_t pass1_budget = 0;        // CRT_PASS1_BUDGET: cap of the budget of the second shadow pass (0: the step budget)
     uint32_t heavy_blocks = 4096;     // CRT_HEAVY_BLOCKS: grid of the wave-per-ray kernels (more blocks than fit: late ones balance the load)
     uint32_t prune = 0;               // CRT_PRUNE: distance pruning of closest-hit walks (kernel_common.h); bit 0 quad walk, bit 1 heavy_trace
@@ -675,6 +677,8 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
         ctx->lean_ok = s->n_nodes < (1u << 27) && s->n_leaf_triangles < (1ull << 26);
         const char *qd = getenv("CRT_QUAD");
         if (qd && ctx->use_quads) ctx->use_quads = (uint32_t)atoi(qd) & 7u;
+        const char *bd = getenv("CRT_BUNDLE");
+        if (bd) ctx->bundle = (uint32_t)strtoul(bd, nullptr, 10);
         const char *f0 = getenv("CRT_FIXED0");
         if (f0) ctx->fixed0 = (uint32_t)atoi(f0);
         const char *p1 = getenv("CRT_PASS1_BUDGET");
@@ -895,6 +899,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         const uint32_t quad = lean ? ctx->use_quads : 0u;  // bit 0: the levels, bit 1: shadow pass 0, bit 2: shadow pass 1
         A.quad_stack_depth = ctx->quad_stack_depth;
         A.prune = ctx->prune;
+        A.bundle = 64;
         A.fixed0 = 0;
         if (ctx->fixed0) {  // level 0 owns the first n_items * 64 * n_lights slots of the shadow queue; the deeper levels append
             const uint64_t n0 = (uint64_t)n_items * 64u * ctx->n_lights;
@@ -915,6 +920,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         }
         KernelArgs S = A;  // argument block of the shadow passes
         S.counters = ctx->d_counters + C_N;
+        S.bundle = ctx->bundle;
         {
             // Pass 0 is one persistent launch: it ends when its longest walk ends, so the budget after which a walk is
             // handed to heavy_trace_shadow should be about the steps one lane gets through in the whole launch --
@@ -972,6 +978,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         // 2b) the shadow rays of the deeper levels, then the evicted shadow walks of both passes
         CRT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_s1[slot], 0));
         S.counters = ctx->d_counters + 2 * C_N;
+        S.bundle = 64;
         {
             // few rays, all tail: the short budget of the levels, or less when this launch is small (the deeper levels
             // queue about a quarter of a shadow ray per pixel on the benchmark scenes)

@@ -412,7 +412,10 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shadow_lean(const KernelAr
     int state = ST_FETCH;
     uint32_t r = 0, steps = 0;
     for (;;) {
-        if (__ballot(state == ST_FETCH)) {
+        // Refill: free lanes wait until no more than `bundle` lanes of the wave are still walking, then all of them fetch at
+        // once -- consecutive slots, i.e. (pass 0) neighbouring pixels' rays towards one light, which stay together in the
+        // tree.  bundle >= 64: every lane fetches as soon as it is free.
+        if (__ballot(state == ST_FETCH) && (A.bundle >= 64u || (uint32_t)__popcll(__ballot(state == ST_TRAVERSE)) <= A.bundle)) {
             while (state == ST_FETCH) {
                 r = wave_fetch(cursor, lane);
                 if (r >= total) { state = ST_DONE; break; }
