@@ -194,6 +194,7 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const Ray &R, co
     occluded = false;
     float tmin = INFINITY;
     uint32_t ti = A.top_root;
+    unsigned long long seen = 0;
     HeavyState H;
     H.guard = 1u << 18;
     H.stop = false;
@@ -212,7 +213,7 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const Ray &R, co
             const uint32_t ent = A.leaf_meshes[e++];
             const uint32_t mi = ent & ~LAST;
             const crt_mesh m = A.meshes[mi];
-            if (!(SHADOW && (m.flags & 1u))) {
+            if (!(SHADOW && (m.flags & 1u)) && !mesh_walk_is_repeat(seen, mi)) {  // (kernel_walk.h: every mesh once per ray)
                 heavy_mesh<SHADOW>(A, R, primary, mi, H, lane);
                 if (SHADOW && H.stop) { occluded = true; break; }
                 if (H.mhave) {

@@ -25,6 +25,22 @@ __device__ __forceinline__ bool shadow_hit_occludes(const Ray &R, float hx, floa
     return len3(hx - R.ox, hy - R.oy, hz - R.oz) <= light_dist;
 }
 
+// A mesh that overlaps several top-level leaves is listed in each of them, and the reference walks its tree again for
+// every listed occurrence the ray reaches (KDTree.cpp:138-145, AccelerationStructure.cpp:62-77) -- on the benchmark scene
+// two thirds of all box and triangle tests are such repeats.  A repeat finds the same hit as the first walk, and that hit
+// can no longer change anything: the scene-level rule only takes a strictly smaller distance (KDTree.cpp:162; the first
+// walk's own distance is not smaller than itself, and the running minimum only decreases), and a shadow ray's verdict is
+// an OR over the walks.  So the production kernels walk every mesh once per ray, at its first occurrence in visit order,
+// which is also where the reference first collects its hit.  (Meshes 64 and up are simply walked again; the counting
+// build repeats everything, as its counters are the reference's.)
+__device__ __forceinline__ bool mesh_walk_is_repeat(unsigned long long &seen, uint32_t mesh) {
+    if (mesh >= 64u) return false;
+    const unsigned long long bit = 1ull << mesh;
+    const bool repeat = (seen & bit) != 0;
+    seen |= bit;
+    return repeat;
+}
+
 struct LeanWalk {
     uint32_t n;        // next mesh-tree node (END: the current mesh is finished / none started)
     uint32_t e;        // next leaf entry of the current leaf (NONE: not inside a leaf)
@@ -38,12 +54,14 @@ struct LeanWalk {
     uint32_t btri, bmesh;
     bool have, occluded;
     float light_dist;
+    unsigned long long seen;  // meshes 0..63 already walked for this ray (mesh_walk_is_repeat)
 };
 
 __device__ __forceinline__ void lean_begin(LeanWalk &W, uint32_t top_root) {
     W.n = END; W.e = NONE; W.tnode = top_root; W.tleaf = NONE; W.mesh = NONE;
     W.mhave = false; W.mmin = INFINITY; W.mt = 0; W.mtri = 0;
     W.have = false; W.occluded = false; W.tmin = INFINITY; W.bt = 0; W.btri = 0; W.bmesh = 0;
+    W.seen = 0;
 }
 
 // Runs up to `iterations` steps of the walk for this lane.  Returns true when the ray's walk is complete.
@@ -113,7 +131,7 @@ __device__ __forceinline__ bool lean_walk(LeanWalk &W, const Ray &R, const bool 
                 const uint32_t mi = ent & ~LAST;
                 W.tleaf = (ent & LAST) ? NONE : W.tleaf + 1;
                 const crt_mesh m = A.meshes[mi];
-                if (!(SHADOW && (m.flags & 1u))) {
+                if (!(SHADOW && (m.flags & 1u)) && !mesh_walk_is_repeat(W.seen, mi)) {
                     W.mesh = mi;
                     W.n = m.root;
                     W.mhave = false;
@@ -165,12 +183,14 @@ struct QuadWalk {
     bool have, occluded;
     float light_dist;
     Prune prune;       // closest-hit walks (kernel_common.h: distance pruning)
+    unsigned long long seen;  // meshes 0..63 already walked for this ray (mesh_walk_is_repeat)
 };
 
 __device__ __forceinline__ void lean_begin(QuadWalk &W, uint32_t top_root) {
     W.q = NONE; W.e = NONE; W.sp = 0; W.top = NONE; W.tnode = top_root; W.tleaf = NONE; W.mesh = NONE;
     W.mhave = false; W.mmin = INFINITY; W.mt = 0; W.mtri = 0;
     W.have = false; W.occluded = false; W.tmin = INFINITY; W.bt = 0; W.btri = 0; W.bmesh = 0;
+    W.seen = 0;
 }
 
 enum : int { WALK_MORE = 0, WALK_DONE = 1, WALK_STACK_FULL = 2 };
@@ -270,7 +290,7 @@ __device__ __forceinline__ int quad_walk(QuadWalk &W, const Ray &R, const bool p
                 const uint32_t mi = ent & ~LAST;
                 W.tleaf = (ent & LAST) ? NONE : W.tleaf + 1;
                 const crt_mesh m = A.meshes[mi];
-                if (!(SHADOW && (m.flags & 1u))) {
+                if (!(SHADOW && (m.flags & 1u)) && !mesh_walk_is_repeat(W.seen, mi)) {
                     W.mesh = mi;
                     W.q = A.quad_roots[mi];
                     W.mhave = false;
