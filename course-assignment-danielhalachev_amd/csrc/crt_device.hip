@@ -24,8 +24,8 @@
 //
 // Tuning variables read by crt_create (none is needed; defaults are what bench.py measures):
 //   CRT_MODE=stream|packets|lanes   kernel family (default stream)
-//   CRT_STEP_BUDGET (512)           steps after which a closest-hit walk goes to heavy_trace_closest; 0 = faithful kernels only
-//   CRT_SHADOW_BUDGET (8192)        cap of the same for shadow pass 0 (the launch scales it down with its size)
+//   CRT_STEP_BUDGET (256)           steps after which a closest-hit walk goes to heavy_trace_closest; 0 = faithful kernels only
+//   CRT_SHADOW_BUDGET (4096)        cap of the same for shadow pass 0 (the launch scales it down with its size)
 //   CRT_PASS1_BUDGET (= step)       cap for the second shadow pass
 //   CRT_HEAVY_LEVEL (100000)        recursion levels with fewer rays skip the per-lane kernel
 //   CRT_HEAVY_BLOCKS (4096)         grid of the wave-per-ray kernels
@@ -129,8 +129,8 @@ struct crt_ctx {
     hipEvent_t ev_fork[EV_RING] = {}, ev_s0[EV_RING] = {}, ev_s1[EV_RING] = {}, ev_s2[EV_RING] = {}, ev4[EV_RING] = {};
     float4 *d_hits = nullptr;         // their closest hits
     uint32_t heavy_cap = 0;
-    uint32_t step_budget = 512;       // CRT_STEP_BUDGET: closest-hit walks are evicted to heavy_trace after this many steps (0 = never)
-    uint32_t shadow_budget = 8192;    // CRT_SHADOW_BUDGET: same for shadow walks (one big launch: only its tail matters)
+    uint32_t step_budget = 256;       // CRT_STEP_BUDGET: closest-hit walks are evicted to heavy_trace after this many steps (0 = never)
+    uint32_t shadow_budget = 4096;    // CRT_SHADOW_BUDGET: same for shadow walks (one big launch: only its tail matters)
     uint32_t heavy_level_threshold = 100000;  // CRT_HEAVY_LEVEL: levels with fewer rays go to heavy_trace whole
     bool lean_ok = true;              // 32-bit byte offsets reach every node and leaf entry
     uint32_t use_quads = 1;           // CRT_QUAD: which lean kernels walk quad nodes (bit 0 levels, 1 shadow pass 0, 2 shadow pass 1)
@@ -924,16 +924,16 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         {
             // Pass 0 is one persistent launch: it ends when its longest walk ends, so the budget after which a walk is
             // handed to heavy_trace_shadow should be about the steps one lane gets through in the whole launch --
-            // rays per lane x ~270 steps per ray (measured average on the benchmark scenes) -- and no more than the cap
+            // rays per lane x ~130 steps per ray (measured average on the benchmark scenes) -- and no more than the cap
             // (CRT_SHADOW_BUDGET).  A rank that renders 1/8 of the tiles gets 1/8 of the budget.
             const uint64_t lanes = (uint64_t)ctx->num_cus * (ctx->side_blocks_per_cu ? ctx->side_blocks_per_cu : 8u) * BLOCK;
-            const uint64_t est = (uint64_t)n_items * 64u * (ctx->n_lights ? ctx->n_lights : 1u) * 270u / (lanes ? lanes : 1u);
+            const uint64_t est = (uint64_t)n_items * 64u * (ctx->n_lights ? ctx->n_lights : 1u) * 130u / (lanes ? lanes : 1u);
             uint32_t budget = est > ctx->shadow_budget ? ctx->shadow_budget : (uint32_t)est;
             if (budget < ctx->step_budget) budget = ctx->step_budget < ctx->shadow_budget ? ctx->step_budget : ctx->shadow_budget;
             S.step_budget = heavy ? budget : 0u;
         }
-        // the same reasoning for level 0 (one launch over all primary rays, ~150 steps per ray)
-        const uint64_t est0 = (uint64_t)n_items * 64u * 150u / ((uint64_t)lane_blocks * BLOCK);
+        // the same reasoning for level 0 (one launch over all primary rays, ~70 steps per ray)
+        const uint64_t est0 = (uint64_t)n_items * 64u * 70u / ((uint64_t)lane_blocks * BLOCK);
         const uint32_t budget0 = est0 >= ctx->step_budget ? ctx->step_budget : (est0 < 64u ? 64u : (uint32_t)est0);
         for (uint32_t g = 0; g <= o->max_depth; g++) {
             A.step_budget = heavy ? (g == 0 ? budget0 : ctx->step_budget) : 0u;
@@ -982,7 +982,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         {
             // few rays, all tail: the short budget of the levels, or less when this launch is small (the deeper levels
             // queue about a quarter of a shadow ray per pixel on the benchmark scenes)
-            const uint64_t est1 = (uint64_t)n_items * 16u * 270u / ((uint64_t)lane_blocks * BLOCK);
+            const uint64_t est1 = (uint64_t)n_items * 16u * 130u / ((uint64_t)lane_blocks * BLOCK);
             const uint32_t env1 = ctx->pass1_budget ? ctx->pass1_budget : ctx->step_budget;
             S.step_budget = heavy ? (est1 >= env1 ? env1 : (est1 < 64u ? 64u : (uint32_t)est1)) : 0u;
         }
