@@ -100,7 +100,7 @@ class Stats(C.Structure):
 DEVICE_SYMBOLS = ["crt_create", "crt_set_camera", "crt_render", "crt_render_tiles_device", "crt_packed_tile_count",
                   "crt_unpack_tiles_device", "crt_quantize_device", "crt_read_quantized", "crt_kernel_elapsed_ms", "crt_kernel_times_ms",
                   "crt_get_stats", "crt_get_kernel_counters", "crt_synchronize", "crt_destroy", "crt_last_error", "crt_device_count", "crt_test_pow5",
-                  "crt_debug_stream_counts", "crt_debug_packet_counters"]
+                  "crt_debug_stream_counts", "crt_debug_packet_counters", "crt_get_executed_counters"]
 HOST_SYMBOLS = ["crt_host_scene_parse_file", "crt_host_scene_parse_text", "crt_host_scene_free", "crt_host_scene_desc",
                 "crt_host_scene_settings", "crt_host_scene_camera", "crt_host_scene_mesh_count",
                 "crt_host_tree_node_count", "crt_host_tree_index_total", "crt_host_tree_dump", "crt_host_mesh_sizes",
@@ -182,7 +182,8 @@ def _p(a):
 
 
 def make_options(max_depth=5, shadow_bias=1e-4, reflection_bias=1e-4, refraction_bias=1e-4, counters=False):
-    return Options(max_depth, shadow_bias, reflection_bias, refraction_bias, 0, 1 if counters else 0)
+    # counters: False / True (the counting build, reference semantics) / 2 (production kernels tallying executed tests)
+    return Options(max_depth, shadow_bias, reflection_bias, refraction_bias, 0, int(counters))
 
 
 def _host_check(rc):
@@ -328,6 +329,12 @@ class Tracer:
         s = Stats()
         lib().crt_get_stats(self.ctx, C.byref(s))
         return s
+
+    def executed_counters(self):
+        """{box_tests, tri_tests} the production kernels executed in the last render made with counters=2."""
+        a = (C.c_uint64 * 2)()
+        self._check(lib().crt_get_executed_counters(self.ctx, a))
+        return {"box_tests": int(a[0]), "tri_tests": int(a[1])}
 
     def kernel_counters(self):
         """(packet-kernel counters, lane-kernel counters) of the last counted render, as dicts."""

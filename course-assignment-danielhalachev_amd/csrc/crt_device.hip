@@ -120,6 +120,8 @@ struct crt_ctx {
     uint8_t *d_occluded = nullptr;
     float4 *d_nodes = nullptr;
     uint32_t *d_scounts = nullptr;
+    unsigned long long *d_exec = nullptr;           // executed-test tallies of a collect_counters == 2 render
+    unsigned long long exec_counters[4] = {0, 0, 0, 0};
     uint32_t *h_overflow = nullptr;   // pinned copy of the stream pass's overflow word
     uint32_t *d_heavy = nullptr;      // evicted ray ids
     uint32_t *d_sheavy = nullptr;     // evicted shadow ray ids
@@ -696,6 +698,8 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
         const char *sb = getenv("CRT_SHADOW_BUDGET");
         if (sb) ctx->shadow_budget = (uint32_t)strtoul(sb, nullptr, 10);
     }
+    CK(hipMalloc((void **)&ctx->d_exec, 4 * sizeof(unsigned long long)));
+    CK(hipMemset(ctx->d_exec, 0, 4 * sizeof(unsigned long long)));
     CK(hipMalloc((void **)&ctx->d_scounts, 512 * sizeof(uint32_t)));
     CK(hipMemset(ctx->d_scounts, 0, 512 * sizeof(uint32_t)));
     CK(hipHostMalloc((void **)&ctx->h_overflow, sizeof(uint32_t)));
@@ -723,6 +727,7 @@ extern "C" void crt_destroy(crt_ctx *ctx) {
     if (ctx->d_occluded) (void)hipFree(ctx->d_occluded);
     if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
     if (ctx->d_scounts) (void)hipFree(ctx->d_scounts);
+    if (ctx->d_exec) (void)hipFree(ctx->d_exec);
     if (ctx->d_heavy) (void)hipFree(ctx->d_heavy);
     if (ctx->d_sheavy) (void)hipFree(ctx->d_sheavy);
     if (ctx->d_todo_tiles) (void)hipFree(ctx->d_todo_tiles);
@@ -877,7 +882,8 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
     A.use_deferred = 0;
     A.packet_budget = ctx->packet_budget;
     A.use_packets = 0;
-    const bool count = o->collect_counters != 0;
+    const bool count = o->collect_counters == 1;       // the counting build: every ray walked the reference's way
+    const bool exec_count = o->collect_counters == 2;  // the production kernels, tallying the tests they execute
     CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_sync, 0, 4 * sizeof(uint32_t), stream));
     if (count) CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_counters, 0, 3 * C_N * sizeof(unsigned long long), stream));
     if (n_items == 0) return CRT_OK;
@@ -899,6 +905,9 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         const uint32_t quad = lean ? ctx->use_quads : 0u;  // bit 0: the levels, bit 1: shadow pass 0, bit 2: shadow pass 1
         A.quad_stack_depth = ctx->quad_stack_depth;
         A.prune = ctx->prune;
+        A.exec_count = exec_count ? 1u : 0u;
+        A.exec_counters = ctx->d_exec;
+        if (exec_count) CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_exec, 0, 4 * sizeof(unsigned long long), stream));
         A.bundle = 64;
         A.fixed0 = 0;
         if (ctx->fixed0) {  // level 0 owns the first n_items * 64 * n_lights slots of the shadow queue; the deeper levels append
@@ -1035,8 +1044,10 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
 
 static int fetch_counters(crt_ctx *ctx, const crt_options *o, uint64_t pixels) {
     ctx->stats.pixels = pixels;
-    ctx->stats.counters_valid = o->collect_counters ? 1 : 0;
-    if (o->collect_counters) {
+    ctx->stats.counters_valid = o->collect_counters == 1 ? 1 : 0;
+    if (o->collect_counters == 2)
+        CRT_HIP_CHECK(ctx, hipMemcpy(ctx->exec_counters, ctx->d_exec, sizeof(ctx->exec_counters), hipMemcpyDeviceToHost));
+    if (o->collect_counters == 1) {
         unsigned long long c2[3 * C_N], c[C_N];
         CRT_HIP_CHECK(ctx, hipMemcpy(c2, ctx->d_counters, sizeof(c2), hipMemcpyDeviceToHost));
         for (int k = 0; k < C_N; k++) {
@@ -1242,6 +1253,13 @@ extern "C" int crt_kernel_times_ms(crt_ctx *ctx, double *out_phase_ms, uint32_t 
 extern "C" int crt_get_kernel_counters(crt_ctx *ctx, uint64_t packets[9], uint64_t lanes[9]) {
     if (!ctx || !packets || !lanes) return CRT_ERR_INVALID;
     for (int k = 0; k < C_PUBLIC; k++) { packets[k] = ctx->packet_counters[k]; lanes[k] = ctx->lane_counters[k]; }
+    return CRT_OK;
+}
+
+extern "C" int crt_get_executed_counters(crt_ctx *ctx, uint64_t out[2]) {
+    if (!ctx || !out) return CRT_ERR_INVALID;
+    out[0] = ctx->exec_counters[0];
+    out[1] = ctx->exec_counters[1];
     return CRT_OK;
 }
 

@@ -101,6 +101,10 @@ struct KernelArgs {
     const float4 *quads;
     const uint32_t *quad_roots;   // per mesh
     uint32_t quad_stack_depth;    // words of LDS stack per lane
+    // crt_options::collect_counters == 2: the production kernels tally the box and triangle tests they EXECUTE (the exact
+    // shortcuts make that fewer than the reference's, which the counting build tallies): {box tests, triangle tests}
+    unsigned long long *exec_counters;
+    uint32_t exec_count;
     uint32_t bundle;              // shadow passes: refill a wave when at most this many of its lanes are still walking (>= 64: at once)
     uint32_t fixed0;              // level 0's shadow rays go to fixed, tile-ordered slots (kernel_stream.h: level0_shadow_slot)
     const float4 *hloose;         // loose boxes of the hbox entries, same indexing

@@ -30,6 +30,7 @@ struct HeavyState {   // all wave-uniform
     Prune prune;
     bool stop;        // shadow walks: an accepted hit within the light's distance ends the walk (kernel_walk.h: shadow_hit_occludes)
     float light_dist;
+    uint32_t nbox, ntri;  // tests executed for this ray (KernelArgs::exec_count)
     __device__ __forceinline__ bool go() const { return guard != 0 && !stop; }
 };
 
@@ -66,6 +67,7 @@ __device__ __forceinline__ void heavy_batch(const KernelArgs &A, const Ray &R, c
                                             const size_t e, HeavyState &H) {
     const float4 a = A.ltris[4 * e + 0], b = A.ltris[4 * e + 1], c = A.ltris[4 * e + 2], d = A.ltris[4 * e + 3];
     float t = 0;
+    if (A.exec_count) H.ntri += (uint32_t)__popcll(__ballot(valid));
     const bool acc = valid && triangle_test(R, primary, a, b, c, d.x, t);
     const unsigned long long am = __ballot(acc);
     if (!am) return;
@@ -136,6 +138,7 @@ __device__ __forceinline__ ChunkBoxes heavy_chunk_load(const KernelArgs &A, cons
 template <int LEVEL, bool SHADOW>
 __device__ __forceinline__ void heavy_chunk(const KernelArgs &A, const Ray &R, const bool primary, const HeavyMesh &M,
                                             const uint32_t chunk, const ChunkBoxes &C, HeavyState &H, const uint32_t lane) {
+    if (A.exec_count) H.nbox += (uint32_t)__popcll(__ballot(C.valid));
     bool hit = C.valid && slab_test(R, C.b0.x, C.b0.y, C.b0.z, C.b1.x, C.b1.y, C.b1.z);
     if (!SHADOW && (A.prune & 2u)) {
         const float bound = fminf(H.tmin_scene, H.mmin);  // wave-uniform
@@ -199,6 +202,7 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const Ray &R, co
     H.guard = 1u << 18;
     H.stop = false;
     H.light_dist = light_dist;
+    H.nbox = 0; H.ntri = 0;
     H.tmin_scene = INFINITY;
     if (!SHADOW) prune_prepare(H.prune, R, A.scene_scale);
     while (ti != END && H.go()) {  // the top-level tree is tiny: walked node by node, uniformly
@@ -206,6 +210,7 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const Ray &R, co
         const float4 q0 = A.nodes[2 * (size_t)ti], q1 = A.nodes[2 * (size_t)ti + 1];
         const uint32_t miss = __float_as_uint(q0.w), link = __float_as_uint(q1.w);
         const bool hit = slab_test(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
+        H.nbox++;
         if (!hit) { ti = miss; continue; }
         if (!is_leaf_link(link)) { ti = link; continue; }
         uint32_t e = link & ~LEAF;
@@ -232,6 +237,7 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const Ray &R, co
         ti = miss;
     }
     if (!H.guard && lane == 0) { A.s_counts[SC_GUARD] = 1; A.s_counts[SC_OVERFLOW] = 1; }  // bound hit: let the fallback redo the frame
+    if (A.exec_count && lane == 0) { atomicAdd(&A.exec_counters[0], (unsigned long long)H.nbox); atomicAdd(&A.exec_counters[1], (unsigned long long)H.ntri); }
 }
 
 __device__ __forceinline__ float uniform_f(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }

@@ -341,6 +341,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_lean(const KernelArg
 
     Ray R;
     typename std::conditional<QUAD, QuadWalk, LeanWalk>::type W;
+    W.nbox = 0; W.ntri = 0;
     int state = ST_FETCH;
     uint32_t r = 0, steps = 0;
     for (;;) {
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_lean(const KernelArg
             }
         }
     }
+    exec_counters_flush(A, W.nbox, W.ntri, lane);
 }
 
 template <uint32_t pass, bool QUAD>  // `pass` is a template parameter so that the two passes are two kernels in a profile
@@ -409,6 +411,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shadow_lean(const KernelAr
     uint32_t *cursor = A.s_counts + (pass == 0 ? SC_SHADOW_FETCH : SC_SHADOW_FETCH2);
     Ray R;
     typename std::conditional<QUAD, QuadWalk, LeanWalk>::type W;
+    W.nbox = 0; W.ntri = 0;
     int state = ST_FETCH;
     uint32_t r = 0, steps = 0;
     for (;;) {
@@ -451,6 +454,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shadow_lean(const KernelAr
             }
         }
     }
+    exec_counters_flush(A, W.nbox, W.ntri, lane);
 }
 
 // Recursion level 0 by PACKETS (kernel_packet.h): one wave per 8x8 tile walks the tree once for the tile's 64

@@ -55,6 +55,7 @@ struct LeanWalk {
     bool have, occluded;
     float light_dist;
     unsigned long long seen;  // meshes 0..63 already walked for this ray (mesh_walk_is_repeat)
+    uint32_t nbox, ntri;      // tests executed by this lane since the kernel started (KernelArgs::exec_count; not reset per ray)
 };
 
 __device__ __forceinline__ void lean_begin(LeanWalk &W, uint32_t top_root) {
@@ -76,6 +77,7 @@ __device__ __forceinline__ bool lean_walk(LeanWalk &W, const Ray &R, const bool 
             // ---- one triangle of the current leaf (Ray.cpp:9-31, Triangle.cpp:37-57), branch-free
             const float4 *T = reinterpret_cast<const float4 *>(ltris_b + (size_t)(uint32_t)(W.e << 6));
             const float4 a = T[0], b = T[1], c = T[2], d = T[3];
+            if (A.exec_count) W.ntri++;
             const float nx = a.w, ny = b.w, nz = c.w;
             const float nd = dot3(R.dx, R.dy, R.dz, nx, ny, nz);
             const float t = -(dot3(nx, ny, nz, R.ox, R.oy, R.oz) + d.x) / nd;
@@ -107,6 +109,7 @@ __device__ __forceinline__ bool lean_walk(LeanWalk &W, const Ray &R, const bool 
             // ---- one mesh-tree node (KDTree.cpp:53-74, BoundingBox.h:85-108), branch-free
             const float4 *N = reinterpret_cast<const float4 *>(nodes_b + (size_t)(uint32_t)(W.n << 5));
             const float4 q0 = N[0], q1 = N[1];
+            if (A.exec_count) W.nbox++;
             const uint32_t miss = __float_as_uint(q0.w), link = __float_as_uint(q1.w);
             const bool hit = slab_test_no_parallel(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
             const bool leaf = is_leaf_link(link);
@@ -140,6 +143,7 @@ __device__ __forceinline__ bool lean_walk(LeanWalk &W, const Ray &R, const bool 
             } else if (W.tnode != END) {
                 const float4 *N = reinterpret_cast<const float4 *>(nodes_b + (size_t)(uint32_t)(W.tnode << 5));
                 const float4 q0 = N[0], q1 = N[1];
+                if (A.exec_count) W.nbox++;
                 const uint32_t miss = __float_as_uint(q0.w), link = __float_as_uint(q1.w);
                 const bool hit = slab_test_no_parallel(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
                 const bool leaf = is_leaf_link(link);
@@ -184,6 +188,7 @@ struct QuadWalk {
     float light_dist;
     Prune prune;       // closest-hit walks (kernel_common.h: distance pruning)
     unsigned long long seen;  // meshes 0..63 already walked for this ray (mesh_walk_is_repeat)
+    uint32_t nbox, ntri;      // tests executed by this lane since the kernel started (KernelArgs::exec_count; not reset per ray)
 };
 
 __device__ __forceinline__ void lean_begin(QuadWalk &W, uint32_t top_root) {
@@ -210,6 +215,7 @@ __device__ __forceinline__ int quad_walk(QuadWalk &W, const Ray &R, const bool p
             // ---- one triangle of the current leaf (Ray.cpp:9-31, Triangle.cpp:37-57), branch-free
             const float4 *T = reinterpret_cast<const float4 *>(ltris_b + (size_t)(uint32_t)(W.e << 6));
             const float4 a = T[0], b = T[1], c = T[2], d = T[3];
+            if (A.exec_count) W.ntri++;
             const float nx = a.w, ny = b.w, nz = c.w;
             const float nd = dot3(R.dx, R.dy, R.dz, nx, ny, nz);
             const float t = -(dot3(nx, ny, nz, R.ox, R.oy, R.oz) + d.x) / nd;
@@ -243,6 +249,7 @@ __device__ __forceinline__ int quad_walk(QuadWalk &W, const Ray &R, const bool p
             const float4 *Q = reinterpret_cast<const float4 *>(quads_b + (size_t)(uint32_t)(W.q << 8));
             const float4 lx = Q[0], ly = Q[1], lz = Q[2], hx = Q[3], hy = Q[4], hz = Q[5];
             const uint4 lk = reinterpret_cast<const uint4 *>(Q)[6];
+            if (A.exec_count) W.nbox += (lk.x != NONE) + (lk.y != NONE) + (lk.z != NONE) + (lk.w != NONE);
             bool h0 = lk.x != NONE && slab_test_no_parallel(R, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x);
             bool h1 = lk.y != NONE && slab_test_no_parallel(R, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y);
             bool h2 = lk.z != NONE && slab_test_no_parallel(R, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z);
@@ -299,6 +306,7 @@ __device__ __forceinline__ int quad_walk(QuadWalk &W, const Ray &R, const bool p
             } else if (W.tnode != END) {
                 const float4 *N = reinterpret_cast<const float4 *>(nodes_b + (size_t)(uint32_t)(W.tnode << 5));
                 const float4 q0 = N[0], q1 = N[1];
+                if (A.exec_count) W.nbox++;
                 const uint32_t miss = __float_as_uint(q0.w), link = __float_as_uint(q1.w);
                 const bool hit = slab_test_no_parallel(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
                 const bool leaf = is_leaf_link(link);
@@ -329,4 +337,12 @@ template <bool SHADOW>
 __device__ __forceinline__ int quad_walk(LeanWalk &W, const Ray &R, const bool primary, const KernelArgs &A, int iterations,
                                          uint32_t &steps, uint32_t *) {
     return lean_walk<SHADOW>(W, R, primary, A, iterations, steps) ? WALK_DONE : WALK_MORE;
+}
+
+// End of a kernel: the lanes' executed-test tallies go to KernelArgs::exec_counters (collect_counters == 2 only).
+__device__ __forceinline__ void exec_counters_flush(const KernelArgs &A, uint32_t nbox, uint32_t ntri, uint32_t lane) {
+    if (!A.exec_count) return;
+    unsigned long long b = nbox, t = ntri;
+    for (int off = 32; off > 0; off >>= 1) { b += __shfl_down(b, off); t += __shfl_down(t, off); }
+    if (lane == 0) { atomicAdd(&A.exec_counters[0], b); atomicAdd(&A.exec_counters[1], t); }
 }

@@ -117,7 +117,7 @@ crt_stats RayTracer::stats() const {
   return s;
 }
 
-int RayTracer::renderFlat(const std::string &pathToImage, const RenderOptions &ro, float *outRGB, bool counters) {
+int RayTracer::renderFlat(const std::string &pathToImage, const RenderOptions &ro, float *outRGB, unsigned int counters) {
   const unsigned int W = scene.sceneSettings.image.width, H = scene.sceneSettings.image.height;
   crt_options o{};
   o.max_depth = ro.MAX_DEPTH;
@@ -125,7 +125,7 @@ int RayTracer::renderFlat(const std::string &pathToImage, const RenderOptions &r
   o.reflection_bias = ro.REFLECTION_BIAS;
   o.refraction_bias = ro.REFRACTION_BIAS;
   o.use_gi = ro.USE_GI ? 1u : 0u;
-  o.collect_counters = counters ? 1u : 0u;
+  o.collect_counters = counters;  // 0, 1 (counting build) or 2 (production kernels with tallies), see crt_hip.h
   const Matrix3 &m = camera.getRotationMatrix();
   const float pos[3] = {camera.getPosition().x, camera.getPosition().y, camera.getPosition().z};
   int rc = crt_set_camera(ctx, pos, &m.m[0][0]);

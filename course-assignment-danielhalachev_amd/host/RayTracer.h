@@ -78,7 +78,7 @@ class RayTracer {
   void exportPPM(const std::string &pathToImage, const std::vector<std::vector<Color>> &colorBuffer);
 
   // flat access for callers that do not want the vector-of-vectors copy
-  int renderFlat(const std::string &pathToImage, const RenderOptions &renderOptions, float *outRGB, bool counters = false);
+  int renderFlat(const std::string &pathToImage, const RenderOptions &renderOptions, float *outRGB, unsigned int counters = 0);
   crt_ctx *context() const { return ctx; }
   const FlatScene &flatScene() const { return flat; }
   const AccelerationStructure &acceleration() const { return accelerationStructure; }

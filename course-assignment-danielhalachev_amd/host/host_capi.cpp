@@ -185,7 +185,7 @@ extern "C" int crt_host_tracer_render(crt_host_tracer *t, const char *ppm_path, 
   return guarded([&]() {
     crt::RenderOptions ro((crt::RenderOptimization)optimization, o->max_depth, o->use_gi != 0, 2, 1, o->shadow_bias,
                           o->reflection_bias, o->refraction_bias);
-    int rc = t->tracer->renderFlat(ppm_path ? ppm_path : "", ro, out_rgb, o->collect_counters != 0);
+    int rc = t->tracer->renderFlat(ppm_path ? ppm_path : "", ro, out_rgb, o->collect_counters);
     if (rc) g_error = crt_last_error(t->tracer->context());
     return rc;
   });

@@ -130,7 +130,8 @@ typedef struct crt_options {
     float reflection_bias;   /* REFLECTION_BIAS */
     float refraction_bias;   /* REFRACTION_BIAS */
     uint32_t use_gi;         /* must be 0 */
-    uint32_t collect_counters; /* != 0: run the counting build of the kernel (slower) */
+    uint32_t collect_counters; /* 1: run the counting build (every ray walked the reference's way; fills crt_stats);
+                                * 2: run the production kernels and tally the tests they execute (crt_get_executed_counters) */
 } crt_options;
 
 /* A pixel rectangle = the reference's unit of work, RayTracer::renderRectangle(row, col, w, h)
@@ -213,6 +214,11 @@ void crt_destroy(crt_ctx *ctx);
 /* last error text of a context (or of the last failed crt_create when ctx == NULL) */
 const char *crt_last_error(const crt_ctx *ctx);
 int crt_device_count(void);
+
+/* After a render with collect_counters == 2 on the default (ray-stream) path: out = {box tests, triangle tests} the
+ * production kernels executed.  Fewer than crt_stats' box_tests / tri_tests, which are the reference's: the kernels leave
+ * out work that cannot change the result (shadow early exit, one walk per mesh and ray). */
+int crt_get_executed_counters(crt_ctx *ctx, uint64_t out[2]);
 
 /* Test hook: out[i] = the device build of the restated glibc powf(x[i], 5) (the Fresnel term, RayTracer.cpp:407). */
 int crt_test_pow5(int device, const float *x, float *out, uint64_t n);

@@ -262,3 +262,20 @@ def test_early_exits_change_nothing_from_random_viewpoints(pkg, scenes, name, tm
         want = tracer.render(max_depth=depth, counters=True).copy()
         got = tracer.render(max_depth=depth)
         assert_same_floats(got, want, "%s view %d" % (name, k))
+
+
+@pytest.mark.parametrize("name", ["hw11", "hw14"])
+def test_executed_work_is_a_subset_of_the_reference_work(pkg, scenes, name):
+    """collect_counters == 2 runs the production kernels with tallies of the tests they execute: the frame is the same,
+    and the triangle tally is no larger than the reference's count (the counting build's)."""
+    scene, depth, _ = small_case(scenes, name)
+    tracer = make_tracer(pkg, scenes, scene)
+    plain = tracer.render(max_depth=depth).copy()
+    counted = tracer.render(max_depth=depth, counters=True).copy()
+    ref = tracer.stats().counters()
+    tallied = tracer.render(max_depth=depth, counters=2)
+    ex = tracer.executed_counters()
+    assert_same_floats(tallied, plain, name + " (tallying run)")
+    assert_same_floats(counted, plain, name + " (counting build)")
+    assert 0 < ex["tri_tests"] <= ref["tri_tests"]       # triangles: only leaves the reference visits too, each mesh once
+    assert 0 < ex["box_tests"] <= 8 * ref["box_tests"]   # boxes: the wide kernels test 4 / 64 at a time, so not necessarily fewer
