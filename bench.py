@@ -245,6 +245,11 @@ def main():
                          "note": "algorithmic bytes = the reference's tests for these rays (counting build); the production "
                                  "kernel's exact early exit skips part of them, see DESIGN.md section 4",
                          "algorithmic_bytes_per_launch": int(b_alg), "counters": dom_counters,
+                         "executed_by_dominant_kernel": {
+                             "box_tests": executed["shadow_pass0_box_tests"], "tri_tests": executed["shadow_pass0_tri_tests"],
+                             "bytes": int(32 * executed["shadow_pass0_box_tests"] + 52 * executed["shadow_pass0_tri_tests"]),
+                             "achieved": round((32 * executed["shadow_pass0_box_tests"] + 52 * executed["shadow_pass0_tri_tests"]) / (dom_ms * 1e-3) / 1e9, 2),
+                             "frac": round((32 * executed["shadow_pass0_box_tests"] + 52 * executed["shadow_pass0_tri_tests"]) / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
                          "executed": {"note": "whole frame, production kernels: the tests actually executed (exact shortcuts leave out "
                                               "repeated walks of a mesh and the rest of a shadow walk once it is decided)",
                                       "box_tests": executed["box_tests"], "tri_tests": executed["tri_tests"],

@@ -332,9 +332,9 @@ class Tracer:
 
     def executed_counters(self):
         """{box_tests, tri_tests} the production kernels executed in the last render made with counters=2."""
-        a = (C.c_uint64 * 2)()
+        a = (C.c_uint64 * 4)()
         self._check(lib().crt_get_executed_counters(self.ctx, a))
-        return {"box_tests": int(a[0]), "tri_tests": int(a[1])}
+        return {"box_tests": int(a[0]), "tri_tests": int(a[1]), "shadow_pass0_box_tests": int(a[2]), "shadow_pass0_tri_tests": int(a[3])}
 
     def kernel_counters(self):
         """(packet-kernel counters, lane-kernel counters) of the last counted render, as dicts."""

@@ -930,6 +930,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         KernelArgs S = A;  // argument block of the shadow passes
         S.counters = ctx->d_counters + C_N;
         S.bundle = ctx->bundle;
+        S.exec_counters = ctx->d_exec + 2;  // shadow pass 0 tallies on its own
         {
             // Pass 0 is one persistent launch: it ends when its longest walk ends, so the budget after which a walk is
             // handed to heavy_trace_shadow should be about the steps one lane gets through in the whole launch --
@@ -988,6 +989,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         CRT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_s1[slot], 0));
         S.counters = ctx->d_counters + 2 * C_N;
         S.bundle = 64;
+        S.exec_counters = ctx->d_exec;
         {
             // few rays, all tail: the short budget of the levels, or less when this launch is small (the deeper levels
             // queue about a quarter of a shadow ray per pixel on the benchmark scenes)
@@ -1256,10 +1258,12 @@ extern "C" int crt_get_kernel_counters(crt_ctx *ctx, uint64_t packets[9], uint64
     return CRT_OK;
 }
 
-extern "C" int crt_get_executed_counters(crt_ctx *ctx, uint64_t out[2]) {
+extern "C" int crt_get_executed_counters(crt_ctx *ctx, uint64_t out[4]) {
     if (!ctx || !out) return CRT_ERR_INVALID;
-    out[0] = ctx->exec_counters[0];
-    out[1] = ctx->exec_counters[1];
+    out[0] = ctx->exec_counters[0] + ctx->exec_counters[2];  // the whole render
+    out[1] = ctx->exec_counters[1] + ctx->exec_counters[3];
+    out[2] = ctx->exec_counters[2];                          // of which shadow pass 0 (stream_trace_shadow_lean<0>)
+    out[3] = ctx->exec_counters[3];
     return CRT_OK;
 }
 

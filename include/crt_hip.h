@@ -216,9 +216,9 @@ const char *crt_last_error(const crt_ctx *ctx);
 int crt_device_count(void);
 
 /* After a render with collect_counters == 2 on the default (ray-stream) path: out = {box tests, triangle tests} the
- * production kernels executed.  Fewer than crt_stats' box_tests / tri_tests, which are the reference's: the kernels leave
+ * production kernels executed in the whole render, then the same two for shadow pass 0 alone (the largest kernel).  Fewer than crt_stats' box_tests / tri_tests, which are the reference's: the kernels leave
  * out work that cannot change the result (shadow early exit, one walk per mesh and ray). */
-int crt_get_executed_counters(crt_ctx *ctx, uint64_t out[2]);
+int crt_get_executed_counters(crt_ctx *ctx, uint64_t out[4]);
 
 /* Test hook: out[i] = the device build of the restated glibc powf(x[i], 5) (the Fresnel term, RayTracer.cpp:407). */
 int crt_test_pow5(int device, const float *x, float *out, uint64_t n);
