@@ -145,6 +145,22 @@ __device__ __forceinline__ void ray_prepare(Ray &R) {
     R.iz = 1.0f / R.dz;
 }
 
+// A mesh that overlaps several top-level leaves is listed in each of them, and the reference walks its tree again for
+// every listed occurrence the ray reaches (KDTree.cpp:138-145, AccelerationStructure.cpp:62-77) -- on the benchmark scene
+// two thirds of all box and triangle tests are such repeats.  A repeat finds the same hit as the first walk, and that hit
+// can no longer change anything: the scene-level rule only takes a strictly smaller distance (KDTree.cpp:162; the first
+// walk's own distance is not smaller than itself, and the running minimum only decreases), and a shadow ray's verdict is
+// an OR over the walks.  So the production kernels walk every mesh once per ray, at its first occurrence in visit order,
+// which is also where the reference first collects its hit.  (Meshes 64 and up are simply walked again; the counting
+// build repeats everything, as its counters are the reference's.)
+__device__ __forceinline__ bool mesh_walk_is_repeat(unsigned long long &seen, uint32_t mesh) {
+    if (mesh >= 64u) return false;
+    const unsigned long long bit = 1ull << mesh;
+    const bool repeat = (seen & bit) != 0;
+    seen |= bit;
+    return repeat;
+}
+
 // ---- distance pruning of closest-hit walks -------------------------------------------------------------
 // The reference walks every leaf whose box the ray passes, whatever it has found so far (KDTree.cpp:53-74).
 // Only a hit with a STRICTLY smaller distance ever replaces the best one (KDTree.cpp:81, :162), so a subtree

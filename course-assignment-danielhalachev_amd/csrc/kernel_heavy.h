@@ -218,7 +218,7 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const Ray &R, co
             const uint32_t ent = A.leaf_meshes[e++];
             const uint32_t mi = ent & ~LAST;
             const crt_mesh m = A.meshes[mi];
-            if (!(SHADOW && (m.flags & 1u)) && !mesh_walk_is_repeat(seen, mi)) {  // (kernel_walk.h: every mesh once per ray)
+            if (!(SHADOW && (m.flags & 1u)) && !mesh_walk_is_repeat(seen, mi)) {  // (kernel_common.h: every mesh once per ray)
                 heavy_mesh<SHADOW>(A, R, primary, mi, H, lane);
                 if (SHADOW && H.stop) { occluded = true; break; }
                 if (H.mhave) {

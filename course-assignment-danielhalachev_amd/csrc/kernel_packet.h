@@ -55,13 +55,15 @@ __device__ __forceinline__ void packet_walk_impl(const KernelArgs &A, const Ray 
     occluded = false;
     if (COUNT && (threadIdx.x & 63u) == 0) cnt[C_WAVE_WALKS]++;
     float tmin = INFINITY;
+    unsigned long long seen = 0;    // per lane: meshes already walked for this ray (kernel_common.h: mesh_walk_is_repeat)
     uint32_t tres = on ? 0u : END;  // TRACK: the lane takes part in the top-level walk from node index `tres` on
     uint32_t ti = A.top_root;
     while (ti != END && budget >= 0) {
         const v8f q = load_node(nodes, ti);
         const uint32_t miss = __float_as_uint(q[3]), link = __float_as_uint(q[7]);
         if (COUNT && (threadIdx.x & 63u) == 0) cnt[C_WAVE_NODES]++;
-        const bool act = TRACK ? (ti >= tres) : on;
+        // (production build: a shadow ray that is already occluded has its answer -- an OR over the meshes -- and sits out)
+        const bool act = (TRACK ? (ti >= tres) : on) && !(SHADOW && !COUNT && occluded);
         const bool hit = act && slab(q);
         if (COUNT && act) cnt[C_BOX]++;
         if (TRACK && act && !hit) tres = miss;
@@ -73,7 +75,8 @@ __device__ __forceinline__ void packet_walk_impl(const KernelArgs &A, const Ray 
             const uint32_t mi = ent & ~LAST;
             const uint32_t mroot = meshes[4 * (size_t)mi], mflags = meshes[4 * (size_t)mi + 2];
             if (COUNT && hit) cnt[C_LEAFIDX]++;
-            const bool mon = hit && !(SHADOW && (mflags & 1u));  // shadow rays skip refractive meshes
+            bool mon = hit && !(SHADOW && (mflags & 1u));  // shadow rays skip refractive meshes
+            if (!COUNT && mon && mesh_walk_is_repeat(seen, mi)) mon = false;  // production build: every mesh once per ray
             if (__ballot(mon)) {
                 // ---- one mesh tree (KDTree.cpp:48-87), closest hit per lane with the reference's tie rule
                 bool mhave = false;

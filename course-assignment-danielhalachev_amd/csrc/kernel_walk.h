@@ -25,22 +25,6 @@ __device__ __forceinline__ bool shadow_hit_occludes(const Ray &R, float hx, floa
     return len3(hx - R.ox, hy - R.oy, hz - R.oz) <= light_dist;
 }
 
-// A mesh that overlaps several top-level leaves is listed in each of them, and the reference walks its tree again for
-// every listed occurrence the ray reaches (KDTree.cpp:138-145, AccelerationStructure.cpp:62-77) -- on the benchmark scene
-// two thirds of all box and triangle tests are such repeats.  A repeat finds the same hit as the first walk, and that hit
-// can no longer change anything: the scene-level rule only takes a strictly smaller distance (KDTree.cpp:162; the first
-// walk's own distance is not smaller than itself, and the running minimum only decreases), and a shadow ray's verdict is
-// an OR over the walks.  So the production kernels walk every mesh once per ray, at its first occurrence in visit order,
-// which is also where the reference first collects its hit.  (Meshes 64 and up are simply walked again; the counting
-// build repeats everything, as its counters are the reference's.)
-__device__ __forceinline__ bool mesh_walk_is_repeat(unsigned long long &seen, uint32_t mesh) {
-    if (mesh >= 64u) return false;
-    const unsigned long long bit = 1ull << mesh;
-    const bool repeat = (seen & bit) != 0;
-    seen |= bit;
-    return repeat;
-}
-
 struct LeanWalk {
     uint32_t n;        // next mesh-tree node (END: the current mesh is finished / none started)
     uint32_t e;        // next leaf entry of the current leaf (NONE: not inside a leaf)
