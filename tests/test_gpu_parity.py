@@ -279,3 +279,24 @@ def test_executed_work_is_a_subset_of_the_reference_work(pkg, scenes, name):
     assert_same_floats(counted, plain, name + " (counting build)")
     assert 0 < ex["tri_tests"] <= ref["tri_tests"]       # triangles: only leaves the reference visits too, each mesh once
     assert 0 < ex["box_tests"] <= 8 * ref["box_tests"]   # boxes: the wide kernels test 4 / 64 at a time, so not necessarily fewer
+
+
+def test_more_meshes_than_the_seen_mask_holds(pkg, scenes, oracle):
+    """72 objects: the one-walk-per-mesh shortcut keeps a 64-bit mask per ray, meshes 64.. are simply walked at every listed
+    occurrence like the reference does; the top-level tree is several levels deep and lists meshes in many leaves."""
+    base = scenes.make("hw11", width=96, height=64, detail=0.15)
+    rng = np.random.default_rng(7)
+    objects = list(base["objects"])
+    n_mat = len(base["materials"])
+    while len(objects) < 72:                                               # small tetrahedra scattered through the room
+        c = rng.uniform([-1.6, -0.8, -5.5], [1.6, 1.2, -2.0]).astype(np.float32)
+        v = (c + rng.uniform(-0.25, 0.25, (4, 3))).astype(np.float32)
+        objects.append({"material_index": int(rng.integers(0, n_mat)), "vertices": v,
+                        "triangles": np.array([[0, 1, 2], [0, 3, 1], [1, 3, 2], [2, 3, 0]], dtype=np.uint32)})
+    scene = dict(base, objects=objects)
+    tracer = make_tracer(pkg, scenes, scene)
+    want, counters = oracle.OracleScene(scenes.to_blob(scene)).render(4)
+    got = tracer.render(max_depth=4, counters=True)
+    assert tracer.stats().counters() == counters
+    assert_same_floats(got, want, "72 meshes (counting build)")
+    assert_same_floats(tracer.render(max_depth=4), want, "72 meshes (production kernels)")
