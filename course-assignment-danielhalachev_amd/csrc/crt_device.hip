@@ -401,6 +401,7 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
         }
         if (upload(ctx, lt.data(), lt.size(), &A.ltris)) return fail(CRT_ERR_HIP);
     }
+    std::vector<HeavyMesh> hmesh_host;  // filled with the leaf sequences below, read again for the single-leaf mesh table
     // loose boxes (see triangle_loose_box) of every mesh-tree node: a leaf's = union over its triangles, an inner
     // node's = union over its children; nodes of one tree are in visit order, children after their parent
     std::vector<float> nloose_lo((size_t)s->n_nodes * 3, INFINITY), nloose_hi((size_t)s->n_nodes * 3, -INFINITY);
@@ -461,7 +462,8 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
         for (uint32_t m = 0; m < s->n_meshes; m++) roots.push_back(s->meshes[m].root);
         std::sort(roots.begin(), roots.end());
         std::vector<float4> hbox, hloose;  // hloose: the entries' loose boxes, same indexing
-        std::vector<HeavyMesh> hm(s->n_meshes);
+        std::vector<HeavyMesh> &hm = hmesh_host;
+        hm.assign(s->n_meshes, HeavyMesh{});
         for (uint32_t m = 0; m < s->n_meshes; m++) {
             HeavyMesh &H = hm[m];
             memset(&H, 0, sizeof(H));
@@ -602,7 +604,30 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
     if (s->vertex_uvs) {
         if (upload(ctx, s->vertex_uvs, (size_t)s->n_vertices * 3, &A.vuvs)) return fail(CRT_ERR_HIP);
     } else A.vuvs = nullptr;
-    if (upload(ctx, s->meshes, (size_t)s->n_meshes, &A.meshes)) return fail(CRT_ERR_HIP);
+    {
+        // the meshes' device copy marks single-leaf meshes (kernel_heavy.h: TinyResults): at most 64 of them, at most 512 triangles in all
+        std::vector<crt_mesh> dm(s->meshes, s->meshes + s->n_meshes);
+        std::vector<uint32_t> tiny_at, tiny_flags;
+        uint64_t tiny_tris = 0;
+        const bool use_tiny = !(getenv("CRT_TINY") && atoi(getenv("CRT_TINY")) == 0);
+        for (uint32_t m = 0; m < s->n_meshes; m++) {
+            dm[m].pad = 0;
+            const crt_node &root = s->nodes[s->meshes[m].root];
+            const HeavyMesh &H = hmesh_host[m];
+            if (!use_tiny || !is_leaf_link(root.link) || H.n_levels != 1 || H.count[0] != 1 || tiny_at.size() >= 64) continue;
+            uint32_t cnt = 0;
+            for (uint64_t e = root.link & ~CRT_LINK_LEAF; e < s->n_leaf_triangles; e++) { cnt++; if (s->leaf_triangles[e] & CRT_ENTRY_LAST) break; }
+            if (tiny_tris + cnt > 512) continue;
+            tiny_tris += cnt;
+            dm[m].pad = (uint32_t)tiny_at.size() + 1u;
+            tiny_at.push_back(H.first[0]);
+            tiny_flags.push_back(s->meshes[m].flags);
+        }
+        A.tiny_count = (uint32_t)tiny_at.size();
+        if (upload(ctx, tiny_at.data(), tiny_at.size(), &A.tiny_at)) return fail(CRT_ERR_HIP);
+        if (upload(ctx, tiny_flags.data(), tiny_flags.size(), &A.tiny_flags)) return fail(CRT_ERR_HIP);
+        if (upload(ctx, dm.data(), dm.size(), &A.meshes)) return fail(CRT_ERR_HIP);
+    }
     {
         std::vector<DMaterial> mats(s->n_materials);
         for (uint32_t i = 0; i < s->n_materials; i++) {

@@ -106,6 +106,11 @@ struct KernelArgs {
     unsigned long long *exec_counters;
     uint32_t exec_count;
     uint32_t bundle;              // shadow passes: refill a wave when at most this many of its lanes are still walking (>= 64: at once)
+    // single-leaf meshes (walls, floors: a root that is a leaf): the wave-per-ray kernels test them all in one step at the
+    // start of a ray (kernel_heavy.h: TinyResults).  tiny_at[k] = the mesh's entry in hbox, tiny_flags[k] = crt_mesh::flags;
+    // the device copy of crt_mesh::pad holds k + 1 for such a mesh, 0 for the others.
+    const uint32_t *tiny_at, *tiny_flags;
+    uint32_t tiny_count;
     uint32_t fixed0;              // level 0's shadow rays go to fixed, tile-ordered slots (kernel_stream.h: level0_shadow_slot)
     const float4 *hloose;         // loose boxes of the hbox entries, same indexing
     float scene_scale;            // largest coordinate magnitude of the scene's triangles

@@ -168,6 +168,90 @@ __device__ __forceinline__ void heavy_chunk(const KernelArgs &A, const Ray &R, c
     }
 }
 
+// ---- single-leaf meshes, all at once ----------------------------------------------------------------------------------
+// A room's walls and floor are meshes whose tree is one leaf.  Walked one after the other each costs the ray two dependent
+// loads (its box, its triangles) -- a third of the dependent steps of a typical walk.  Their results do not depend on WHEN
+// they are computed, only the order in which the scene-level rule sees them does: so at the start of a ray lane k tests the
+// box of single-leaf mesh k (KernelArgs::tiny_at), the triangles of those that pass are tested in one or two batches, and the
+// per-mesh results wait in lane k's registers until the top-level walk reaches mesh k, in the reference's order.
+struct TinyResults {  // per lane k < tiny_count: the closest hit in single-leaf mesh k (mesh-level rule, KDTree.cpp:75-86)
+    bool have;
+    float mmin, mt;
+    uint32_t mtri;
+};
+
+template <bool SHADOW>
+__device__ __forceinline__ void heavy_tiny_batch(const KernelArgs &A, const Ray &R, const bool primary, const bool valid, const size_t e,
+                                                 const uint32_t tag, unsigned long long tags, TinyResults &T, HeavyState &H, const uint32_t lane) {
+    const float4 a = A.ltris[4 * e + 0], b = A.ltris[4 * e + 1], c = A.ltris[4 * e + 2], d = A.ltris[4 * e + 3];
+    float t = 0;
+    if (A.exec_count) H.ntri += (uint32_t)__popcll(__ballot(valid));
+    const bool acc = valid && triangle_test(R, primary, a, b, c, d.x, t);
+    if (!__ballot(acc)) return;
+    while (tags) {  // the meshes that have triangles in this batch, one masked reduction each (registers only)
+        const int g = __ffsll((long long)tags) - 1;
+        tags &= tags - 1;
+        const bool mine = acc && tag == (uint32_t)g;
+        const unsigned long long am = __ballot(mine);
+        if (!am) continue;
+        bool have = __builtin_amdgcn_readlane((int)T.have, g) != 0;
+        float mmin = lane_value(T.mmin, g), mt = lane_value(T.mt, g);
+        uint32_t mtri = lane_value(T.mtri, g);
+        if (!have) {  // `closest = intersections[0]`
+            const int first = __ffsll((long long)am) - 1;
+            have = true;
+            mt = lane_value(t, first);
+            mtri = lane_value(__float_as_uint(d.y), first);
+        }
+        const float key = (mine && t < INFINITY) ? t : INFINITY;
+        const float mn = wave_min(key);
+        if (mn < mmin) {
+            const int w = __ffsll((long long)__ballot(mine && key == mn)) - 1;
+            mmin = mn;
+            mt = lane_value(t, w);
+            mtri = lane_value(__float_as_uint(d.y), w);
+        }
+        if (lane == (uint32_t)g) { T.have = have; T.mmin = mmin; T.mt = mt; T.mtri = mtri; }
+    }
+}
+
+template <bool SHADOW>
+__device__ __forceinline__ void heavy_tiny_meshes(const KernelArgs &A, const Ray &R, const bool primary, TinyResults &T, HeavyState &H,
+                                                  const uint32_t lane) {
+    T.have = false; T.mmin = INFINITY; T.mt = 0; T.mtri = 0;
+    if (A.tiny_count == 0) return;
+    const bool valid = lane < A.tiny_count;
+    const size_t at = valid ? A.tiny_at[lane] : A.tiny_at[0];
+    const uint32_t flags = valid ? A.tiny_flags[lane] : 0u;
+    const float4 b0 = A.hbox[2 * at], b1 = A.hbox[2 * at + 1];
+    if (A.exec_count) H.nbox += A.tiny_count;
+    const bool hit = valid && !(SHADOW && (flags & 1u)) && slab_test(R, b0.x, b0.y, b0.z, b1.x, b1.y, b1.z);
+    unsigned long long m = __ballot(hit);
+    if (!m) return;
+    const uint32_t begin = __float_as_uint(b0.w), count = __float_as_uint(b1.w);
+    uint32_t off = 0, e = 0, tag = 0;
+    bool tvalid = false;
+    unsigned long long tags = 0;
+    while (m && H.guard) {
+        H.guard--;
+        const int k = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        uint32_t bg = lane_value(begin, k), cnt = lane_value(count, k);
+        while (cnt && H.guard) {
+            const uint32_t take = cnt < 64u - off ? cnt : 64u - off;
+            if (lane >= off && lane < off + take) { e = bg + (lane - off); tag = (uint32_t)k; tvalid = true; }
+            tags |= 1ull << k;
+            off += take; bg += take; cnt -= take;
+            if (off == 64u) {
+                H.guard--;
+                heavy_tiny_batch<SHADOW>(A, R, primary, tvalid, (size_t)e, tag, tags, T, H, lane);
+                off = 0; tvalid = false; tags = 0;
+            }
+        }
+    }
+    if (off) heavy_tiny_batch<SHADOW>(A, R, primary, tvalid, (size_t)e, tag, tags, T, H, lane);
+}
+
 // closest hit of the (wave-uniform) ray in one mesh
 template <bool SHADOW>
 __device__ __forceinline__ void heavy_mesh(const KernelArgs &A, const Ray &R, const bool primary, const uint32_t mesh,
@@ -205,6 +289,8 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const Ray &R, co
     H.nbox = 0; H.ntri = 0;
     H.tmin_scene = INFINITY;
     if (!SHADOW) prune_prepare(H.prune, R, A.scene_scale);
+    TinyResults T;
+    heavy_tiny_meshes<SHADOW>(A, R, primary, T, H, lane);
     while (ti != END && H.go()) {  // the top-level tree is tiny: walked node by node, uniformly
         H.guard--;
         const float4 q0 = A.nodes[2 * (size_t)ti], q1 = A.nodes[2 * (size_t)ti + 1];
@@ -219,7 +305,15 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const Ray &R, co
             const uint32_t mi = ent & ~LAST;
             const crt_mesh m = A.meshes[mi];
             if (!(SHADOW && (m.flags & 1u)) && !mesh_walk_is_repeat(seen, mi)) {  // (kernel_common.h: every mesh once per ray)
-                heavy_mesh<SHADOW>(A, R, primary, mi, H, lane);
+                if (m.pad) {  // a single-leaf mesh: its result has been waiting in lane pad - 1 since the start of the ray
+                    const int k = (int)m.pad - 1;
+                    H.mhave = __builtin_amdgcn_readlane((int)T.have, k) != 0;
+                    H.mt = lane_value(T.mt, k);
+                    H.mtri = lane_value(T.mtri, k);
+                    H.mmin = lane_value(T.mmin, k);
+                } else {
+                    heavy_mesh<SHADOW>(A, R, primary, mi, H, lane);
+                }
                 if (SHADOW && H.stop) { occluded = true; break; }
                 if (H.mhave) {
                     if (SHADOW) {
