@@ -109,6 +109,9 @@ struct KernelArgs {
     // single-leaf meshes (walls, floors: a root that is a leaf): the wave-per-ray kernels test them all in one step at the
     // start of a ray (kernel_heavy.h: TinyResults).  tiny_at[k] = the mesh's entry in hbox, tiny_flags[k] = crt_mesh::flags;
     // the device copy of crt_mesh::pad holds k + 1 for such a mesh, 0 for the others.
+    // the top-level tree held in registers by the wave-per-ray kernels (kernel_heavy.h: TopRegs) when it is small:
+    // its nodes are [top_first, top_first + top_count), top_count <= 64, and leaf_meshes / meshes have <= 64 entries
+    uint32_t top_fast, top_first, top_count, top_leaf_entries, top_meshes;
     const uint32_t *tiny_at, *tiny_flags;
     uint32_t tiny_count;
     uint32_t fixed0;              // level 0's shadow rays go to fixed, tile-ordered slots (kernel_stream.h: level0_shadow_slot)

@@ -155,14 +155,11 @@ __device__ __forceinline__ void heavy_chunk(const KernelArgs &A, const Ray &R, c
     } else {
         unsigned long long m = __ballot(hit);
         if (!m) return;
-        // the boxes of the next passing child chunk are requested before the current one is worked on
-        ChunkBoxes next = heavy_chunk_load<LEVEL - 1>(A, M, chunk * 64u + (uint32_t)(__ffsll((long long)m) - 1), lane);
         while (m && H.go()) {
             H.guard--;
             const int k = __ffsll((long long)m) - 1;
             m &= m - 1;
-            const ChunkBoxes cur = next;
-            if (m) next = heavy_chunk_load<LEVEL - 1>(A, M, chunk * 64u + (uint32_t)(__ffsll((long long)m) - 1), lane);
+            const ChunkBoxes cur = heavy_chunk_load<LEVEL - 1>(A, M, chunk * 64u + (uint32_t)k, lane);
             heavy_chunk<LEVEL - 1, SHADOW>(A, R, primary, M, chunk * 64u + (uint32_t)k, cur, H, lane);
         }
     }
@@ -272,9 +269,30 @@ __device__ __forceinline__ void heavy_mesh(const KernelArgs &A, const Ray &R, co
     }
 }
 
+// The top-level tree in registers.  Walked from memory it is ~40 dependent scalar loads per ray (nodes, leaf entries, mesh
+// records) -- measured: half of a ray's 100 us in this kernel -- for a few hundred bytes that do not depend on the ray.  When
+// crt_create finds it small enough (KernelArgs::top_fast) every wave loads it once: lane i keeps top-level node i, lane j
+// leaf entry j, lane m the flags / pad of mesh m; a ray then tests all the nodes' boxes in one instruction and the walk
+// reads links and entries with v_readlane.
+struct TopRegs {
+    float4 q0, q1;           // lane i: node top_first + i  {lo, miss} {hi, link}
+    uint32_t entry;          // lane j: leaf_meshes[j]
+    uint32_t mflags, mpad;   // lane m: meshes[m].flags, meshes[m].pad
+};
+__device__ __forceinline__ TopRegs heavy_top_load(const KernelArgs &A, const uint32_t lane) {
+    TopRegs TR;
+    TR.q0 = make_float4(0, 0, 0, 0); TR.q1 = TR.q0; TR.entry = 0; TR.mflags = 0; TR.mpad = 0;
+    if (A.top_fast) {
+        if (lane < A.top_count) { TR.q0 = A.nodes[2 * (size_t)(A.top_first + lane)]; TR.q1 = A.nodes[2 * (size_t)(A.top_first + lane) + 1]; }
+        if (lane < A.top_leaf_entries) TR.entry = A.leaf_meshes[lane];
+        if (lane < A.top_meshes) { const crt_mesh m = A.meshes[lane]; TR.mflags = m.flags; TR.mpad = m.pad; }
+    }
+    return TR;
+}
+
 // The two-level walk for one ray per wave.  SHADOW: AccelerationStructure.cpp:56-94, else KDTree.cpp:127-167.
 template <bool SHADOW>
-__device__ __forceinline__ void heavy_walk(const KernelArgs &A, const Ray &R, const bool primary, const float light_dist,
+__device__ __forceinline__ void heavy_walk(const KernelArgs &A, const TopRegs &TR, const Ray &R, const bool primary, const float light_dist,
                                            bool &have, float &bt, uint32_t &btri, uint32_t &bmesh, bool &occluded,
                                            const uint32_t lane) {
     have = false;
@@ -291,19 +309,34 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const Ray &R, co
     if (!SHADOW) prune_prepare(H.prune, R, A.scene_scale);
     TinyResults T;
     heavy_tiny_meshes<SHADOW>(A, R, primary, T, H, lane);
+    const bool fast = A.top_fast != 0;
+    // all top-level boxes against this ray at once (the same test, node by node, as the loop below would make)
+    const unsigned long long top_hits = fast ? __ballot(lane < A.top_count && slab_test(R, TR.q0.x, TR.q0.y, TR.q0.z, TR.q1.x, TR.q1.y, TR.q1.z)) : 0ull;
     while (ti != END && H.go()) {  // the top-level tree is tiny: walked node by node, uniformly
         H.guard--;
-        const float4 q0 = A.nodes[2 * (size_t)ti], q1 = A.nodes[2 * (size_t)ti + 1];
-        const uint32_t miss = __float_as_uint(q0.w), link = __float_as_uint(q1.w);
-        const bool hit = slab_test(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
+        uint32_t miss, link;
+        bool hit;
+        if (fast) {
+            const int i = (int)(ti - A.top_first);
+            miss = lane_value(__float_as_uint(TR.q0.w), i);
+            link = lane_value(__float_as_uint(TR.q1.w), i);
+            hit = ((top_hits >> i) & 1ull) != 0;
+        } else {
+            const float4 q0 = A.nodes[2 * (size_t)ti], q1 = A.nodes[2 * (size_t)ti + 1];
+            miss = __float_as_uint(q0.w); link = __float_as_uint(q1.w);
+            hit = slab_test(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
+        }
         H.nbox++;
         if (!hit) { ti = miss; continue; }
         if (!is_leaf_link(link)) { ti = link; continue; }
         uint32_t e = link & ~LEAF;
         for (;;) {
-            const uint32_t ent = A.leaf_meshes[e++];
+            const uint32_t ent = fast ? lane_value(TR.entry, (int)e) : A.leaf_meshes[e];
+            e++;
             const uint32_t mi = ent & ~LAST;
-            const crt_mesh m = A.meshes[mi];
+            crt_mesh m;
+            if (fast) { m.flags = lane_value(TR.mflags, (int)mi); m.pad = lane_value(TR.mpad, (int)mi); m.root = 0; m.material = 0; }
+            else m = A.meshes[mi];
             if (!(SHADOW && (m.flags & 1u)) && !mesh_walk_is_repeat(seen, mi)) {  // (kernel_common.h: every mesh once per ray)
                 if (m.pad) {  // a single-leaf mesh: its result has been waiting in lane pad - 1 since the start of the ray
                     const int k = (int)m.pad - 1;
@@ -347,6 +380,8 @@ __global__ __launch_bounds__(BLOCK) void heavy_trace_closest(const KernelArgs A,
     const float4 *in_q = A.s_rayq[gen & 1u];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
     const uint32_t n_waves = gridDim.x * (BLOCK / 64);
+    if (wave >= total) return;
+    const TopRegs TR = heavy_top_load(A, lane);
     for (uint32_t k = wave; k < total; k += n_waves) {  // one evicted ray per wave and trip
         const uint32_t r = whole ? k : A.s_heavy[k];
         Ray R;
@@ -370,7 +405,7 @@ __global__ __launch_bounds__(BLOCK) void heavy_trace_closest(const KernelArgs A,
         bool have = false, occluded = false;
         float bt = 0;
         uint32_t btri = 0, bmesh = 0;
-        heavy_walk<false>(A, R, primary, 0.0f, have, bt, btri, bmesh, occluded, lane);
+        heavy_walk<false>(A, TR, R, primary, 0.0f, have, bt, btri, bmesh, occluded, lane);
         if (lane == 0) A.s_hits[k] = make_float4(bt, __uint_as_float(btri), __uint_as_float(bmesh), __uint_as_float(have ? 1u : 0u));
     }
 }
@@ -387,6 +422,8 @@ __global__ __launch_bounds__(BLOCK) void heavy_trace_shadow(const KernelArgs A, 
     if (part == 0) total = split;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
     const uint32_t n_waves = gridDim.x * (BLOCK / 64);
+    if (first + wave >= total) return;
+    const TopRegs TR = heavy_top_load(A, lane);
     for (uint32_t k = first + wave; k < total; k += n_waves) {
         const uint32_t r = A.s_sheavy[k];
         const float4 q0 = A.s_shadowq[2 * (size_t)r], q1 = A.s_shadowq[2 * (size_t)r + 1];
@@ -399,7 +436,7 @@ __global__ __launch_bounds__(BLOCK) void heavy_trace_shadow(const KernelArgs A, 
         bool have, occluded;
         float bt = 0;
         uint32_t btri = 0, bmesh = 0;
-        heavy_walk<true>(A, R, false, uniform_f(q0.w), have, bt, btri, bmesh, occluded, lane);
+        heavy_walk<true>(A, TR, R, false, uniform_f(q0.w), have, bt, btri, bmesh, occluded, lane);
         if (lane == 0) A.s_occluded[r] = occluded ? 1 : 0;
     }
 }
