@@ -437,7 +437,7 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
             for (uint32_t i = 0; i < s->n_nodes; i++)
                 if (is_top[i]) { lo = i < lo ? i : lo; hi = i > hi ? i : hi; cnt++; }
             const bool off = getenv("CRT_TOP_REGS") && atoi(getenv("CRT_TOP_REGS")) == 0;
-            A.top_fast = (!off && cnt > 0 && hi - lo + 1 == cnt && cnt <= 64u && s->n_leaf_meshes <= 64u && s->n_meshes <= 64u) ? 1u : 0u;
+            A.top_fast = (!off && cnt > 0 && hi - lo + 1 == cnt && cnt <= 64u && s->n_leaf_meshes <= 128u && s->n_meshes <= 64u) ? 1u : 0u;
             A.top_first = cnt ? lo : 0u;
             A.top_count = cnt;
             A.top_leaf_entries = s->n_leaf_meshes;

@@ -110,7 +110,7 @@ struct KernelArgs {
     // start of a ray (kernel_heavy.h: TinyResults).  tiny_at[k] = the mesh's entry in hbox, tiny_flags[k] = crt_mesh::flags;
     // the device copy of crt_mesh::pad holds k + 1 for such a mesh, 0 for the others.
     // the top-level tree held in registers by the wave-per-ray kernels (kernel_heavy.h: TopRegs) when it is small:
-    // its nodes are [top_first, top_first + top_count), top_count <= 64, and leaf_meshes / meshes have <= 64 entries
+    // its nodes are [top_first, top_first + top_count), top_count <= 64, leaf_meshes has <= 128 entries and there are <= 64 meshes
     uint32_t top_fast, top_first, top_count, top_leaf_entries, top_meshes;
     const uint32_t *tiny_at, *tiny_flags;
     uint32_t tiny_count;

@@ -276,15 +276,16 @@ __device__ __forceinline__ void heavy_mesh(const KernelArgs &A, const Ray &R, co
 // reads links and entries with v_readlane.
 struct TopRegs {
     float4 q0, q1;           // lane i: node top_first + i  {lo, miss} {hi, link}
-    uint32_t entry;          // lane j: leaf_meshes[j]
+    uint32_t entry, entry2;  // lane j: leaf_meshes[j], leaf_meshes[64 + j]
     uint32_t mflags, mpad;   // lane m: meshes[m].flags, meshes[m].pad
 };
 __device__ __forceinline__ TopRegs heavy_top_load(const KernelArgs &A, const uint32_t lane) {
     TopRegs TR;
-    TR.q0 = make_float4(0, 0, 0, 0); TR.q1 = TR.q0; TR.entry = 0; TR.mflags = 0; TR.mpad = 0;
+    TR.q0 = make_float4(0, 0, 0, 0); TR.q1 = TR.q0; TR.entry = 0; TR.entry2 = 0; TR.mflags = 0; TR.mpad = 0;
     if (A.top_fast) {
         if (lane < A.top_count) { TR.q0 = A.nodes[2 * (size_t)(A.top_first + lane)]; TR.q1 = A.nodes[2 * (size_t)(A.top_first + lane) + 1]; }
         if (lane < A.top_leaf_entries) TR.entry = A.leaf_meshes[lane];
+        if (64u + lane < A.top_leaf_entries) TR.entry2 = A.leaf_meshes[64u + lane];
         if (lane < A.top_meshes) { const crt_mesh m = A.meshes[lane]; TR.mflags = m.flags; TR.mpad = m.pad; }
     }
     return TR;
@@ -331,7 +332,7 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const TopRegs &T
         if (!is_leaf_link(link)) { ti = link; continue; }
         uint32_t e = link & ~LEAF;
         for (;;) {
-            const uint32_t ent = fast ? lane_value(TR.entry, (int)e) : A.leaf_meshes[e];
+            const uint32_t ent = !fast ? A.leaf_meshes[e] : (e < 64u ? lane_value(TR.entry, (int)e) : lane_value(TR.entry2, (int)(e - 64u)));
             e++;
             const uint32_t mi = ent & ~LAST;
             crt_mesh m;
