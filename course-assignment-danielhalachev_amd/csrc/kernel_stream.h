@@ -325,6 +325,8 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade(const KernelArgs A, 
 template <bool QUAD>
 __global__ __launch_bounds__(BLOCK) void stream_trace_shade_lean(const KernelArgs A, const uint32_t gen) {
     extern __shared__ uint32_t qstack[];  // QUAD: A.quad_stack_depth x BLOCK words
+    __shared__ TopLdsStorage top_storage;
+    const TopLds TL = top_lds_load(A, top_storage);  // (a barrier inside: before any return)
     uint32_t *const stk = qstack + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     if (A.s_counts[SC_OVERFLOW]) return;
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_lean(const KernelArg
         }
         if (!__ballot(state != ST_DONE)) break;
         if (state == ST_TRAVERSE) {
-            const int w = quad_walk<false>(W, R, primary, A, 64, steps, stk);
+            const int w = quad_walk<false>(W, R, primary, A, TL, 64, steps, stk);
             if (w == WALK_DONE) {
                 shade_and_emit<false>(A, gen, r, node_base, child_base, R, W.have, W.bt, W.btri, W.bmesh, nullptr, lane);
                 state = ST_FETCH;
@@ -399,6 +401,8 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_lean(const KernelArg
 template <uint32_t pass, bool QUAD>  // `pass` is a template parameter so that the two passes are two kernels in a profile
 __global__ __launch_bounds__(BLOCK) void stream_trace_shadow_lean(const KernelArgs A) {
     extern __shared__ uint32_t qstack[];  // QUAD: A.quad_stack_depth x BLOCK words
+    __shared__ TopLdsStorage top_storage;
+    const TopLds TL = top_lds_load(A, top_storage);  // (a barrier inside: before any return)
     uint32_t *const stk = qstack + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     if (A.s_counts[SC_OVERFLOW]) return;
@@ -441,7 +445,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shadow_lean(const KernelAr
         }
         if (!__ballot(state != ST_DONE)) break;
         if (state == ST_TRAVERSE) {
-            const int w = quad_walk<true>(W, R, false, A, 64, steps, stk);
+            const int w = quad_walk<true>(W, R, false, A, TL, 64, steps, stk);
             if (w == WALK_DONE) {
                 A.s_occluded[r] = W.occluded ? 1 : 0;
                 state = ST_FETCH;

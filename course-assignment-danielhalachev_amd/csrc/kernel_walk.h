@@ -25,6 +25,51 @@ __device__ __forceinline__ bool shadow_hit_occludes(const Ray &R, float hx, floa
     return len3(hx - R.ox, hy - R.oy, hz - R.oz) <= light_dist;
 }
 
+// The top-level tree for the per-lane walks, in LDS.  A ray spends about as many steps in the few dozen top-level nodes as in
+// the mesh trees (HW14: 17 of 31 box tests of a shadow ray), and every one of them is a divergent gather through the vector
+// L1 for a table of a kilobyte: when crt_create finds the table small (KernelArgs::top_fast) each workgroup copies it to LDS
+// and the walks read nodes, leaf entries and mesh records from there.
+typedef float lds_v4f __attribute__((ext_vector_type(4)));       // plain vector types: LDS pointers cannot bind to the float4 class
+typedef uint32_t lds_v4u __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) lds_v4f *lds_f4;
+typedef const __attribute__((address_space(3))) lds_v4u *lds_u4;
+typedef const __attribute__((address_space(3))) uint32_t *lds_u32;
+constexpr int TOP_LDS_NODES = 64, TOP_LDS_ENTRIES = 128, TOP_LDS_MESHES = 64;
+struct TopLdsStorage {
+    lds_v4f nodes[TOP_LDS_NODES * 2];
+    lds_v4u meshes[TOP_LDS_MESHES];    // {flags, tree root, quad root, -}
+    uint32_t entries[TOP_LDS_ENTRIES];
+};
+struct TopLds {
+    bool fast;        // the same for every thread of the launch
+    lds_f4 nodes;     // node i at nodes[2 * (i - first)]
+    lds_u4 meshes;
+    lds_u32 entries;
+    uint32_t first;
+};
+// Called by every thread of the workgroup before anything else (it holds a barrier).
+__device__ __forceinline__ TopLds top_lds_load(const KernelArgs &A, TopLdsStorage &S) {
+    TopLds T;
+    T.fast = A.top_fast != 0;
+    T.first = A.top_first;
+    T.nodes = (lds_f4)S.nodes;
+    T.meshes = (lds_u4)S.meshes;
+    T.entries = (lds_u32)S.entries;
+    if (T.fast) {
+        for (uint32_t i = threadIdx.x; i < A.top_count * 2u; i += blockDim.x) {
+            const float4 q = A.nodes[2 * (size_t)A.top_first + i];
+            S.nodes[i] = lds_v4f{q.x, q.y, q.z, q.w};
+        }
+        for (uint32_t i = threadIdx.x; i < A.top_leaf_entries; i += blockDim.x) S.entries[i] = A.leaf_meshes[i];
+        for (uint32_t i = threadIdx.x; i < A.top_meshes; i += blockDim.x) {
+            const crt_mesh m = A.meshes[i];
+            S.meshes[i] = lds_v4u{m.flags, m.root, A.quad_roots[i], 0u};
+        }
+        __syncthreads();
+    }
+    return T;
+}
+
 struct LeanWalk {
     uint32_t n;        // next mesh-tree node (END: the current mesh is finished / none started)
     uint32_t e;        // next leaf entry of the current leaf (NONE: not inside a leaf)
@@ -51,7 +96,7 @@ __device__ __forceinline__ void lean_begin(LeanWalk &W, uint32_t top_root) {
 
 // Runs up to `iterations` steps of the walk for this lane.  Returns true when the ray's walk is complete.
 template <bool SHADOW>
-__device__ __forceinline__ bool lean_walk(LeanWalk &W, const Ray &R, const bool primary, const KernelArgs &A,
+__device__ __forceinline__ bool lean_walk(LeanWalk &W, const Ray &R, const bool primary, const KernelArgs &A, const TopLds &TL,
                                           int iterations, uint32_t &steps) {
     const char *nodes_b = reinterpret_cast<const char *>(A.nodes);
     const char *ltris_b = reinterpret_cast<const char *>(A.ltris);
@@ -114,19 +159,28 @@ __device__ __forceinline__ bool lean_walk(LeanWalk &W, const Ray &R, const bool 
                 W.mesh = NONE;
             }
             if (W.tleaf != NONE) {
-                const uint32_t ent = A.leaf_meshes[W.tleaf];
+                const uint32_t ent = TL.fast ? TL.entries[W.tleaf] : A.leaf_meshes[W.tleaf];
                 const uint32_t mi = ent & ~LAST;
                 W.tleaf = (ent & LAST) ? NONE : W.tleaf + 1;
-                const crt_mesh m = A.meshes[mi];
-                if (!(SHADOW && (m.flags & 1u)) && !mesh_walk_is_repeat(W.seen, mi)) {
+                uint4 m;  // {flags, tree root, quad root}
+                if (TL.fast) { const lds_v4u v = TL.meshes[mi]; m = make_uint4(v[0], v[1], v[2], v[3]); }
+                else { const crt_mesh g = A.meshes[mi]; m = make_uint4(g.flags, g.root, 0u, 0u); }
+                if (!(SHADOW && (m.x & 1u)) && !mesh_walk_is_repeat(W.seen, mi)) {
                     W.mesh = mi;
-                    W.n = m.root;
+                    W.n = m.y;
                     W.mhave = false;
                     W.mmin = INFINITY;
                 }
             } else if (W.tnode != END) {
-                const float4 *N = reinterpret_cast<const float4 *>(nodes_b + (size_t)(uint32_t)(W.tnode << 5));
-                const float4 q0 = N[0], q1 = N[1];
+                float4 q0, q1;
+                if (TL.fast) {
+                    const lds_v4f a = TL.nodes[2 * (W.tnode - TL.first)], b = TL.nodes[2 * (W.tnode - TL.first) + 1];
+                    q0 = make_float4(a[0], a[1], a[2], a[3]); q1 = make_float4(b[0], b[1], b[2], b[3]);
+                }
+                else {
+                    const float4 *N = reinterpret_cast<const float4 *>(nodes_b + (size_t)(uint32_t)(W.tnode << 5));
+                    q0 = N[0]; q1 = N[1];
+                }
                 if (A.exec_count) W.nbox++;
                 const uint32_t miss = __float_as_uint(q0.w), link = __float_as_uint(q1.w);
                 const bool hit = slab_test_no_parallel(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
@@ -186,8 +240,8 @@ enum : int { WALK_MORE = 0, WALK_DONE = 1, WALK_STACK_FULL = 2 };
 
 // `stk`: this thread's column of the workgroup's stack array (element i at stk[i * BLOCK]).
 template <bool SHADOW>
-__device__ __forceinline__ int quad_walk(QuadWalk &W, const Ray &R, const bool primary, const KernelArgs &A, int iterations,
-                                         uint32_t &steps, uint32_t *stk) {
+__device__ __forceinline__ int quad_walk(QuadWalk &W, const Ray &R, const bool primary, const KernelArgs &A, const TopLds &TL,
+                                         int iterations, uint32_t &steps, uint32_t *stk) {
     const char *nodes_b = reinterpret_cast<const char *>(A.nodes);
     const char *quads_b = reinterpret_cast<const char *>(A.quads);
     const char *ltris_b = reinterpret_cast<const char *>(A.ltris);
@@ -277,19 +331,28 @@ __device__ __forceinline__ int quad_walk(QuadWalk &W, const Ray &R, const bool p
                 W.mesh = NONE;
             }
             if (W.tleaf != NONE) {
-                const uint32_t ent = A.leaf_meshes[W.tleaf];
+                const uint32_t ent = TL.fast ? TL.entries[W.tleaf] : A.leaf_meshes[W.tleaf];
                 const uint32_t mi = ent & ~LAST;
                 W.tleaf = (ent & LAST) ? NONE : W.tleaf + 1;
-                const crt_mesh m = A.meshes[mi];
-                if (!(SHADOW && (m.flags & 1u)) && !mesh_walk_is_repeat(W.seen, mi)) {
+                uint4 m;  // {flags, tree root, quad root}
+                if (TL.fast) { const lds_v4u v = TL.meshes[mi]; m = make_uint4(v[0], v[1], v[2], v[3]); }
+                else { m = make_uint4(A.meshes[mi].flags, 0u, A.quad_roots[mi], 0u); }
+                if (!(SHADOW && (m.x & 1u)) && !mesh_walk_is_repeat(W.seen, mi)) {
                     W.mesh = mi;
-                    W.q = A.quad_roots[mi];
+                    W.q = m.z;
                     W.mhave = false;
                     W.mmin = INFINITY;
                 }
             } else if (W.tnode != END) {
-                const float4 *N = reinterpret_cast<const float4 *>(nodes_b + (size_t)(uint32_t)(W.tnode << 5));
-                const float4 q0 = N[0], q1 = N[1];
+                float4 q0, q1;
+                if (TL.fast) {
+                    const lds_v4f a = TL.nodes[2 * (W.tnode - TL.first)], b = TL.nodes[2 * (W.tnode - TL.first) + 1];
+                    q0 = make_float4(a[0], a[1], a[2], a[3]); q1 = make_float4(b[0], b[1], b[2], b[3]);
+                }
+                else {
+                    const float4 *N = reinterpret_cast<const float4 *>(nodes_b + (size_t)(uint32_t)(W.tnode << 5));
+                    q0 = N[0]; q1 = N[1];
+                }
                 if (A.exec_count) W.nbox++;
                 const uint32_t miss = __float_as_uint(q0.w), link = __float_as_uint(q1.w);
                 const bool hit = slab_test_no_parallel(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
@@ -318,9 +381,9 @@ __device__ __forceinline__ int quad_walk(QuadWalk &W, const Ray &R, const bool p
 
 // the binary walk under the same interface
 template <bool SHADOW>
-__device__ __forceinline__ int quad_walk(LeanWalk &W, const Ray &R, const bool primary, const KernelArgs &A, int iterations,
-                                         uint32_t &steps, uint32_t *) {
-    return lean_walk<SHADOW>(W, R, primary, A, iterations, steps) ? WALK_DONE : WALK_MORE;
+__device__ __forceinline__ int quad_walk(LeanWalk &W, const Ray &R, const bool primary, const KernelArgs &A, const TopLds &TL,
+                                         int iterations, uint32_t &steps, uint32_t *) {
+    return lean_walk<SHADOW>(W, R, primary, A, TL, iterations, steps) ? WALK_DONE : WALK_MORE;
 }
 
 // End of a kernel: the lanes' executed-test tallies go to KernelArgs::exec_counters (collect_counters == 2 only).
