@@ -88,7 +88,7 @@ class Stats(C.Structure):
                 ("tri_tests", C.c_uint64), ("leaf_index_reads", C.c_uint64), ("shaded_hits", C.c_uint64),
                 ("light_evals", C.c_uint64), ("texel_fetches", C.c_uint64), ("primary_rays", C.c_uint64),
                 ("secondary_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("pixels", C.c_uint64),
-                ("counters_valid", C.c_uint32)]
+                ("counters_valid", C.c_uint32), ("fallback_frames", C.c_uint32)]
 
     def counters(self):
         return {k: int(getattr(self, k)) for k in ("box_tests", "tri_tests", "leaf_index_reads", "shaded_hits",
@@ -96,15 +96,47 @@ class Stats(C.Structure):
                                                    "shadow_rays")}
 
 
+MODE_STREAM, MODE_PACKETS, MODE_LANES = range(3)
+
+
+class Tuning(C.Structure):
+    """crt_tuning (include/crt_hip.h): kernel selection and sizing; no setting changes a pixel."""
+    _fields_ = [(n, C.c_uint32) for n in (
+        "size", "mode", "step_budget", "shadow_budget", "pass1_budget", "heavy_level", "heavy_blocks", "side_blocks",
+        "quad", "quad_stack", "prune", "bundle", "fixed0", "packet_budget", "path_mask", "top_in_registers",
+        "tiny_meshes", "node_cap", "ray_cap", "shadow_cap", "deep", "deep_blocks", "plan")] + [("reserved", C.c_uint32 * 5)]
+
+
+def make_tuning(**fields):
+    """Default tuning (crt_tuning_defaults) with the given fields replaced, e.g. make_tuning(mode=MODE_LANES)."""
+    t = Tuning()
+    lib().crt_tuning_defaults(C.byref(t))
+    for k, v in fields.items():
+        if k not in dict(Tuning._fields_) or k in ("size", "reserved"):
+            raise KeyError("crt_tuning has no field %r" % k)
+        setattr(t, k, int(v))
+    return t
+
+
+def tuning_from_string(text):
+    """'quad=0 heavy_level=0' -> make_tuning(quad=0, heavy_level=0); '' -> None.  Used by the development tools
+    (tools/*.py read it from their command line or from the CRT_TUNING variable); the library itself reads no
+    environment variables."""
+    text = (text or "").strip()
+    if not text:
+        return None
+    return make_tuning(**{k: int(v, 0) for k, v in (kv.split("=") for kv in text.split())})
+
+
 # every symbol include/crt_hip.h and include/crt_host.h declare
-DEVICE_SYMBOLS = ["crt_create", "crt_set_camera", "crt_render", "crt_render_tiles_device", "crt_packed_tile_count",
+DEVICE_SYMBOLS = ["crt_tuning_defaults", "crt_create_tuned", "crt_create", "crt_set_camera", "crt_render", "crt_render_tiles_device", "crt_packed_tile_count",
                   "crt_unpack_tiles_device", "crt_quantize_device", "crt_read_quantized", "crt_kernel_elapsed_ms", "crt_kernel_times_ms",
                   "crt_get_stats", "crt_get_kernel_counters", "crt_synchronize", "crt_destroy", "crt_last_error", "crt_device_count", "crt_test_pow5",
                   "crt_debug_stream_counts", "crt_debug_packet_counters", "crt_get_executed_counters"]
 HOST_SYMBOLS = ["crt_host_scene_parse_file", "crt_host_scene_parse_text", "crt_host_scene_free", "crt_host_scene_desc",
                 "crt_host_scene_settings", "crt_host_scene_camera", "crt_host_scene_mesh_count",
                 "crt_host_tree_node_count", "crt_host_tree_index_total", "crt_host_tree_dump", "crt_host_mesh_sizes",
-                "crt_host_mesh_normals", "crt_host_bucket_rects", "crt_host_camera_apply", "crt_host_tracer_create",
+                "crt_host_mesh_normals", "crt_host_bucket_rects", "crt_host_camera_apply", "crt_host_tracer_create", "crt_host_tracer_create_tuned",
                 "crt_host_tracer_free", "crt_host_tracer_set_camera", "crt_host_tracer_render", "crt_host_tracer_ctx",
                 "crt_host_export_ppm", "crt_host_last_error"]
 
@@ -165,6 +197,10 @@ def lib():
     L.crt_host_bucket_rects.argtypes = [u32, u32, u32, i32, u32, C.POINTER(Rect), u32]
     L.crt_host_camera_apply.argtypes = [vp, vp, i32, vp]
     L.crt_host_tracer_create.argtypes = [vp, i32, C.POINTER(vp)]
+    L.crt_host_tracer_create_tuned.argtypes = [vp, i32, C.POINTER(Tuning), C.POINTER(vp)]
+    L.crt_tuning_defaults.argtypes = [C.POINTER(Tuning)]
+    L.crt_tuning_defaults.restype = None
+    L.crt_create_tuned.argtypes = [C.POINTER(SceneDesc), i32, C.POINTER(Tuning), C.POINTER(vp)]
     L.crt_host_tracer_free.argtypes = [vp]
     L.crt_host_tracer_free.restype = None
     L.crt_host_tracer_set_camera.argtypes = [vp, vp, vp]
@@ -291,11 +327,12 @@ def export_ppm(path, rgb):
 class Tracer:
     """crt::RayTracer on one GPU: scene + tree resident in HBM, re-renderable with a new camera."""
 
-    def __init__(self, scene: Scene, device=0):
+    def __init__(self, scene: Scene, device=0, tuning: Tuning = None):
         L = lib()
         self.scene = scene
         h = C.c_void_p()
-        _host_check(L.crt_host_tracer_create(scene._h, device, C.byref(h)))
+        _host_check(L.crt_host_tracer_create_tuned(scene._h, device, C.byref(tuning) if tuning is not None else None,
+                                                   C.byref(h)))
         self._h = h
         self.ctx = C.c_void_p(L.crt_host_tracer_ctx(h))
         self.width, self.height = scene.width, scene.height

@@ -22,20 +22,8 @@
 //  * arithmetic is IEEE binary32 with no contraction (-ffp-contract=off), correctly rounded divide and sqrt,
 //    std::min/std::max semantics written out, so results are bit-identical to the x86-64 reference build.
 //
-// Tuning variables read by crt_create (none is needed; defaults are what bench.py measures):
-//   CRT_MODE=stream|packets|lanes   kernel family (default stream)
-//   CRT_STEP_BUDGET (256)           steps after which a closest-hit walk goes to heavy_trace_closest; 0 = faithful kernels only
-//   CRT_SHADOW_BUDGET (4096)        cap of the same for shadow pass 0 (the launch scales it down with its size)
-//   CRT_PASS1_BUDGET (= step)       cap for the second shadow pass
-//   CRT_HEAVY_LEVEL (100000)        recursion levels with fewer rays skip the per-lane kernel
-//   CRT_HEAVY_BLOCKS (4096)         grid of the wave-per-ray kernels
-//   CRT_SIDE_BLOCKS (4)             workgroups per CU of shadow pass 0 on the side stream; 0 = no side stream
-//   CRT_QUAD (1) / CRT_QUAD_STACK (16)  which lean kernels walk quad nodes (bit 0 levels, 1 shadow pass 0, 2 pass 1); LDS words per lane
-//   CRT_PRUNE (0)                   exact distance pruning of closest-hit walks (bit 0 quad walk, bit 1 heavy_trace)
-//   CRT_BUNDLE (16)                 shadow pass 0 refills a wave when at most this many of its lanes still walk (64: lane by lane)
-//   CRT_FIXED0 (1)                  level 0's shadow rays in fixed tile-ordered slots (0: queued like the deeper levels')
-//   CRT_PACKET_BUDGET (0)           level 0 by packets first, giving a tile up after this many wave-level visits
-//   CRT_DEBUG_SKIP                  path selection for tests: 256 = no lean kernels (faithful walk + heavy_trace), 512 = no packets
+// Kernel selection and sizing come in through crt_tuning (include/crt_hip.h); this file reads no environment
+// variables.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -58,6 +46,7 @@ namespace {
 #include "kernel_lane.h"
 #include "kernel_stream.h"
 #include "kernel_heavy.h"
+#include "kernel_plan.h"
 
 // scatter gathered packed tiles into the row-major frame
 __global__ void unpack_kernel(const float *packed, uint32_t n_parts, uint64_t part_stride, float *frame, uint32_t width,
@@ -106,7 +95,8 @@ struct crt_ctx {
     uint8_t *d_quant = nullptr;
     WorkItem *d_items = nullptr;
     size_t items_cap = 0;
-    std::vector<crt_rect> cached_rects;
+    std::vector<crt_rect> cached_rects;   // coverage the work items were built for: crt_render's rectangles ...
+    bool cached_is_partition = false;     // ... or crt_render_tiles_device's {first, stride} (held in cached_rects[0].row / .col)
     uint32_t cached_n_items = 0;
     uint64_t cached_pixels = 0;
     uint32_t *d_sync = nullptr;      // [0] lane-kernel pixel counter, [1] packet-kernel tile counter, [2] deferred count
@@ -122,7 +112,8 @@ struct crt_ctx {
     uint32_t *d_scounts = nullptr;
     unsigned long long *d_exec = nullptr;           // executed-test tallies of a collect_counters == 2 render
     unsigned long long exec_counters[4] = {0, 0, 0, 0};
-    uint32_t *h_overflow = nullptr;   // pinned copy of the stream pass's overflow word
+    uint32_t *h_overflow = nullptr;   // pinned copy of d_fallback_total, refreshed after every frame
+    uint32_t *d_fallback_total = nullptr;  // frames redone by the queue-less kernel since crt_create
     uint32_t *d_heavy = nullptr;      // evicted ray ids
     uint32_t *d_sheavy = nullptr;     // evicted shadow ray ids
     uint32_t *d_todo_tiles = nullptr, *d_todo_shadow = nullptr;  // what stream_packets_gen0 gave up on
@@ -148,6 +139,7 @@ struct crt_ctx {
     uint64_t stream_items = 0;        // work items the stream buffers are sized for
     uint64_t overflows = 0;           // frames redone by the fallback (diagnostic)
     uint32_t n_lights = 0;
+    crt_tuning tuning{};
     unsigned long long *d_counters = nullptr;
     float *d_frames = nullptr;
     size_t frames_floats = 0;
@@ -213,6 +205,12 @@ static int validate_scene(const crt_scene_desc *s, std::string &err) {
     if (s->n_vertices && !s->vertex_normals) return bad("missing vertex normals");
     if (s->n_meshes && !s->meshes) return bad("missing meshes");
     if (s->n_materials == 0 && s->n_meshes) return bad("meshes without materials");
+    if (s->n_leaf_triangles && !s->leaf_triangles) return bad("missing leaf_triangles");
+    if (s->n_leaf_meshes && !s->leaf_meshes) return bad("missing leaf_meshes");
+    if (s->n_materials && !s->materials) return bad("missing materials");
+    if (s->n_textures && !s->textures) return bad("missing textures");
+    if (s->n_texels && !s->texels) return bad("missing texels");
+    if (s->n_lights && !s->lights) return bad("missing lights");
     if (s->n_leaf_triangles > 0x7FFFFFFFull) return bad("too many leaf entries");
     // every index the kernel will follow is checked here, on the host, before anything is launched
     // Links must point FORWARD (nodes stored in visit order): this makes every walk finite whatever the
@@ -254,14 +252,33 @@ static int validate_scene(const crt_scene_desc *s, std::string &err) {
             if (t.texel_offset + (uint64_t)t.width * t.height > s->n_texels) return bad("bitmap texels out of range");
         }
     }
-    // leaf links must point inside the entry arrays; a leaf of the top tree is told from a mesh-tree
-    // leaf by reachability, so both bounds are checked against the larger array here and the
-    // builder's own tests pin the exact structure
-    for (uint32_t i = 0; i < s->n_nodes; i++) {
-        const crt_node &n = s->nodes[i];
-        if (!is_leaf_link(n.link)) continue;
-        uint64_t b = n.link & ~CRT_LINK_LEAF;
-        if (b >= s->n_leaf_triangles && b >= s->n_leaf_meshes) return bad("leaf begin out of range");
+    // Leaf links must point inside THEIR entry array: a leaf of the top-level tree lists meshes, a leaf of a mesh tree
+    // lists triangles.  Which tree a node belongs to is decided by reachability from top_root (links point forward,
+    // so the walk below is finite); both arrays end with a terminated entry (checked above), so a leaf that begins
+    // inside its array also ends inside it.
+    {
+        std::vector<bool> is_top(s->n_nodes, false);
+        std::vector<uint32_t> stack{s->top_root};
+        while (!stack.empty()) {
+            const uint32_t i = stack.back();
+            stack.pop_back();
+            if (i >= s->n_nodes || is_top[i]) continue;
+            is_top[i] = true;
+            const crt_node &n = s->nodes[i];
+            if (is_leaf_link(n.link) || n.link == CRT_LINK_END) continue;
+            stack.push_back(n.link);
+            const uint32_t c2 = s->nodes[n.link].miss;
+            if (c2 != n.miss && c2 != CRT_LINK_END) stack.push_back(c2);
+        }
+        for (uint32_t i = 0; i < s->n_nodes; i++) {
+            const crt_node &n = s->nodes[i];
+            if (!is_leaf_link(n.link)) continue;
+            const uint64_t b = n.link & ~CRT_LINK_LEAF;
+            if (is_top[i]) { if (b >= s->n_leaf_meshes) return bad("top-level leaf begins outside leaf_meshes"); }
+            else if (b >= s->n_leaf_triangles) return bad("mesh-tree leaf begins outside leaf_triangles");
+        }
+        for (uint32_t i = 0; i < s->n_meshes; i++)
+            if (is_top[s->meshes[i].root]) return bad("mesh root inside the top-level tree");
     }
     return CRT_OK;
 }
@@ -326,9 +343,36 @@ static void triangle_loose_box(const crt_triangle &T, double S, float lo[3], flo
     }
 }
 
-extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
+extern "C" void crt_tuning_defaults(crt_tuning *t) {
+    if (!t) return;
+    memset(t, 0, sizeof(*t));
+    t->size = (uint32_t)sizeof(*t);
+    t->mode = CRT_MODE_STREAM;
+    t->step_budget = 256; t->shadow_budget = 4096; t->pass1_budget = 0;
+    t->heavy_level = 100000; t->heavy_blocks = 4096; t->side_blocks = 4;
+    t->quad = 1; t->quad_stack = 16; t->prune = 0; t->bundle = 16; t->fixed0 = 1;
+    t->packet_budget = 0; t->path_mask = 0; t->top_in_registers = 1; t->tiny_meshes = 1;
+    t->node_cap = t->ray_cap = t->shadow_cap = 0;
+    t->deep = 1; t->deep_blocks = 0;
+    t->plan = 1;
+}
+
+extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) { return crt_create_tuned(s, device, nullptr, out); }
+
+extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_tuning *tuning, crt_ctx **out) {
     if (!out) return CRT_ERR_INVALID;
     *out = nullptr;
+    crt_tuning tune;
+    crt_tuning_defaults(&tune);
+    if (tuning) {
+        if (tuning->size == 0 || tuning->size > sizeof(crt_tuning) || (tuning->size & 3u)) {
+            g_create_error = "crt_tuning.size is not set (call crt_tuning_defaults first)";
+            return CRT_ERR_INVALID;
+        }
+        memcpy(&tune, tuning, tuning->size);  // an older, shorter struct keeps the defaults of the newer fields
+        tune.size = (uint32_t)sizeof(crt_tuning);
+        if (tune.mode > CRT_MODE_LANES) { g_create_error = "crt_tuning.mode out of range"; return CRT_ERR_INVALID; }
+    }
     int rc = validate_scene(s, g_create_error);
     if (rc != CRT_OK) return rc;
     int ndev = 0;
@@ -436,8 +480,7 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
             uint32_t lo = UINT32_MAX, hi = 0, cnt = 0;
             for (uint32_t i = 0; i < s->n_nodes; i++)
                 if (is_top[i]) { lo = i < lo ? i : lo; hi = i > hi ? i : hi; cnt++; }
-            const bool off = getenv("CRT_TOP_REGS") && atoi(getenv("CRT_TOP_REGS")) == 0;
-            A.top_fast = (!off && cnt > 0 && hi - lo + 1 == cnt && cnt <= 64u && s->n_leaf_meshes <= 128u && s->n_meshes <= 64u) ? 1u : 0u;
+            A.top_fast = (tune.top_in_registers && cnt > 0 && hi - lo + 1 == cnt && cnt <= 64u && s->n_leaf_meshes <= 128u && s->n_meshes <= 64u) ? 1u : 0u;
             A.top_first = cnt ? lo : 0u;
             A.top_count = cnt;
             A.top_leaf_entries = s->n_leaf_meshes;
@@ -620,7 +663,7 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
         std::vector<crt_mesh> dm(s->meshes, s->meshes + s->n_meshes);
         std::vector<uint32_t> tiny_at, tiny_flags;
         uint64_t tiny_tris = 0;
-        const bool use_tiny = !(getenv("CRT_TINY") && atoi(getenv("CRT_TINY")) == 0);
+        const bool use_tiny = tune.tiny_meshes != 0;
         for (uint32_t m = 0; m < s->n_meshes; m++) {
             dm[m].pad = 0;
             const crt_node &root = s->nodes[s->meshes[m].root];
@@ -686,6 +729,51 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
         }
         A.nested_boxes = nested ? 1u : 0u;
     }
+    {
+        // The plan of the top-level tree (kernel_plan.h): its leaves in visit order, which is index order.
+        std::vector<float4> boxes;
+        std::vector<uint2> masks;
+        std::vector<uint32_t> order;  // non-refractive meshes, most leaves first
+        for (uint32_t m = 0; m < s->n_meshes; m++)
+            if (!(s->meshes[m].flags & 1u)) order.push_back(m);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hmesh_host[a].count[0] > hmesh_host[b].count[0]; });
+        std::vector<uint32_t> bit_of(s->n_meshes, 64u);
+        for (size_t b = 0; b < order.size(); b++) bit_of[order[b]] = (uint32_t)b;
+        bool ok = A.top_fast && A.nested_boxes && s->n_meshes <= 64u;
+        for (uint32_t i = A.top_first; ok && i < A.top_first + A.top_count; i++) {
+            const crt_node &n = s->nodes[i];
+            if (!is_leaf_link(n.link)) continue;
+            const uint32_t begin = n.link & ~CRT_LINK_LEAF;
+            uint32_t count = 0;
+            unsigned long long mask = 0;
+            for (uint32_t e = begin; e < s->n_leaf_meshes; e++) {
+                const uint32_t mi = s->leaf_meshes[e] & ~CRT_ENTRY_LAST;
+                if (bit_of[mi] < 64u) mask |= 1ull << bit_of[mi];
+                count++;
+                if (s->leaf_meshes[e] & CRT_ENTRY_LAST) break;
+            }
+            float bb, cb;
+            memcpy(&bb, &begin, 4);
+            memcpy(&cb, &count, 4);
+            float ml, mh;
+            const uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
+            memcpy(&ml, &mlo, 4);
+            memcpy(&mh, &mhi, 4);
+            boxes.push_back(make_float4(n.lo[0], n.lo[1], n.lo[2], bb));  // PLAN_LEAF_DWORDS = 16 per leaf (kernel_plan.h)
+            boxes.push_back(make_float4(n.hi[0], n.hi[1], n.hi[2], cb));
+            boxes.push_back(make_float4(ml, mh, 0.0f, 0.0f));
+            boxes.push_back(make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+            masks.push_back(make_uint2(mlo, mhi));
+        }
+        if (masks.size() > 64) ok = false;
+        A.plan_ok = (ok && tune.plan) ? 1u : 0u;
+        A.plan_leaves = (uint32_t)masks.size();
+        A.plan_shadow_bits = (uint32_t)order.size();
+        A.plan_list_words = (s->n_meshes + 3u) / 4u;
+        if (upload(ctx, boxes.data(), boxes.size(), &A.plan_boxes)) return fail(CRT_ERR_HIP);
+        if (upload(ctx, masks.data(), masks.size(), &A.plan_shadow_masks)) return fail(CRT_ERR_HIP);
+        if (upload(ctx, order.data(), order.size(), &A.plan_shadow_mesh)) return fail(CRT_ERR_HIP);
+    }
     A.bgx = s->background[0]; A.bgy = s->background[1]; A.bgz = s->background[2];
     A.width = s->width; A.height = s->height; A.tiles_x = ctx->tiles_x;
     const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -697,49 +785,30 @@ extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) {
     CK(hipMemset(ctx->d_frame, 0, frame_bytes));  // colorBuffer starts as Color() = (0,0,0), RayTracer.cpp:46-50
     CK(hipMalloc((void **)&ctx->d_quant, (size_t)s->width * s->height * 3));
     CK(hipMalloc((void **)&ctx->d_sync, 4 * sizeof(uint32_t)));
-    {
-        const char *m = getenv("CRT_MODE");
-        if (m && !strcmp(m, "packets")) ctx->mode = crt_ctx::MODE_PACKETS;
-        else if (m && !strcmp(m, "lanes")) ctx->mode = crt_ctx::MODE_LANES;
-        else ctx->mode = crt_ctx::MODE_STREAM;
-    }
-    {
-        const char *ds = getenv("CRT_DEBUG_SKIP");
-        if (ds) ctx->debug_skip = (uint32_t)strtoul(ds, nullptr, 10);
-        const char *b = getenv("CRT_STEP_BUDGET");
-        if (b && ctx->step_budget) ctx->step_budget = (uint32_t)strtoul(b, nullptr, 10);
-        const char *pb = getenv("CRT_PACKET_BUDGET");
-        if (pb) ctx->packet_budget = (uint32_t)strtoul(pb, nullptr, 10);
-        const char *hl = getenv("CRT_HEAVY_LEVEL");
-        if (hl) ctx->heavy_level_threshold = (uint32_t)strtoul(hl, nullptr, 10);
-        ctx->lean_ok = s->n_nodes < (1u << 27) && s->n_leaf_triangles < (1ull << 26);
-        const char *qd = getenv("CRT_QUAD");
-        if (qd && ctx->use_quads) ctx->use_quads = (uint32_t)atoi(qd) & 7u;
-        const char *bd = getenv("CRT_BUNDLE");
-        if (bd) ctx->bundle = (uint32_t)strtoul(bd, nullptr, 10);
-        const char *f0 = getenv("CRT_FIXED0");
-        if (f0) ctx->fixed0 = (uint32_t)atoi(f0);
-        const char *p1 = getenv("CRT_PASS1_BUDGET");
-        if (p1) ctx->pass1_budget = (uint32_t)strtoul(p1, nullptr, 10);
-        const char *hb = getenv("CRT_HEAVY_BLOCKS");
-        if (hb && atoi(hb) > 0) ctx->heavy_blocks = (uint32_t)atoi(hb);
-        const char *pr = getenv("CRT_PRUNE");
-        if (pr) ctx->prune = (uint32_t)atoi(pr) & 3u;
-        const char *qs = getenv("CRT_QUAD_STACK");
-        if (qs) ctx->quad_stack_depth = (uint32_t)atoi(qs);
-        if (ctx->quad_stack_depth < 4) ctx->quad_stack_depth = 4;
-        if (ctx->quad_stack_depth > 60) ctx->quad_stack_depth = 60;  // 60 KB of the workgroup's 64 KB
-        const char *sbl = getenv("CRT_SIDE_BLOCKS");
-        if (sbl) ctx->side_blocks_per_cu = (uint32_t)strtoul(sbl, nullptr, 10);
-        const char *sb = getenv("CRT_SHADOW_BUDGET");
-        if (sb) ctx->shadow_budget = (uint32_t)strtoul(sb, nullptr, 10);
-    }
+    ctx->tuning = tune;
+    ctx->mode = tune.mode == CRT_MODE_PACKETS ? crt_ctx::MODE_PACKETS : (tune.mode == CRT_MODE_LANES ? crt_ctx::MODE_LANES : crt_ctx::MODE_STREAM);
+    ctx->debug_skip = tune.path_mask;
+    if (ctx->step_budget) ctx->step_budget = tune.step_budget;  // (0: a mesh with too many leaves switched the wave-per-ray path off)
+    ctx->packet_budget = tune.packet_budget;
+    ctx->heavy_level_threshold = tune.heavy_level;
+    ctx->lean_ok = s->n_nodes < (1u << 27) && s->n_leaf_triangles < (1ull << 26);
+    if (ctx->use_quads) ctx->use_quads = tune.quad & 7u;
+    ctx->bundle = tune.bundle;
+    ctx->fixed0 = tune.fixed0;
+    ctx->pass1_budget = tune.pass1_budget;
+    if (tune.heavy_blocks) ctx->heavy_blocks = tune.heavy_blocks;
+    ctx->prune = tune.prune & 3u;
+    ctx->quad_stack_depth = tune.quad_stack < 4 ? 4 : (tune.quad_stack > 60 ? 60 : tune.quad_stack);  // 60 KB of the workgroup's 64 KB
+    ctx->side_blocks_per_cu = tune.side_blocks;
+    ctx->shadow_budget = tune.shadow_budget;
     CK(hipMalloc((void **)&ctx->d_exec, 4 * sizeof(unsigned long long)));
     CK(hipMemset(ctx->d_exec, 0, 4 * sizeof(unsigned long long)));
     CK(hipMalloc((void **)&ctx->d_scounts, 512 * sizeof(uint32_t)));
     CK(hipMemset(ctx->d_scounts, 0, 512 * sizeof(uint32_t)));
     CK(hipHostMalloc((void **)&ctx->h_overflow, sizeof(uint32_t)));
     *ctx->h_overflow = 0;
+    CK(hipMalloc((void **)&ctx->d_fallback_total, sizeof(uint32_t)));
+    CK(hipMemset(ctx->d_fallback_total, 0, sizeof(uint32_t)));
     ctx->n_lights = s->n_lights;
     CK(hipMalloc((void **)&ctx->d_counters, 3 * C_N * sizeof(unsigned long long)));  // [levels | shadow pass 0 | the rest]
     // persistent grid: 8 blocks of 256 threads per CU gives every CU its 32 waves if registers allow
@@ -770,6 +839,7 @@ extern "C" void crt_destroy(crt_ctx *ctx) {
     if (ctx->d_todo_shadow) (void)hipFree(ctx->d_todo_shadow);
     if (ctx->d_hits) (void)hipFree(ctx->d_hits);
     if (ctx->h_overflow) (void)hipHostFree(ctx->h_overflow);
+    if (ctx->d_fallback_total) (void)hipFree(ctx->d_fallback_total);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_frames) (void)hipFree(ctx->d_frames);
     for (int i = 0; i < crt_ctx::EV_RING; i++) {
@@ -817,6 +887,7 @@ static int ensure_items(crt_ctx *ctx, size_t n) {
     CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_deferred, n * 64 * sizeof(uint32_t)));
     ctx->items_cap = n;
     ctx->cached_rects.clear();
+    ctx->cached_is_partition = false;
     return CRT_OK;
 }
 
@@ -852,6 +923,10 @@ static int ensure_stream(crt_ctx *ctx, uint32_t n_items) {
         uint64_t node_cap = px * 4 < (1u << 20) ? (1u << 20) : px * 4;
         uint64_t ray_cap = px * 3 < (1u << 20) ? (1u << 20) : px * 3;
         uint64_t shadow_cap = node_cap * (ctx->n_lights ? ctx->n_lights : 1);
+        // explicit capacities (crt_tuning): never below what level 0 itself needs, so that only the deeper levels can overflow
+        if (ctx->tuning.node_cap) node_cap = ctx->tuning.node_cap < px ? px : ctx->tuning.node_cap;
+        if (ctx->tuning.ray_cap) ray_cap = ctx->tuning.ray_cap;
+        if (ctx->tuning.shadow_cap) shadow_cap = ctx->tuning.shadow_cap;
         if (node_cap > 0x7FFFFFF0ull) node_cap = 0x7FFFFFF0ull;
         if (ray_cap > 0x7FFFFFF0ull) ray_cap = 0x7FFFFFF0ull;
         if (shadow_cap > 0x7FFFFFF0ull) shadow_cap = 0x7FFFFFF0ull;
@@ -915,6 +990,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
     A.counters = ctx->d_counters;
     A.s_counts = ctx->d_scounts;
     A.only_if_overflow = 0;
+    A.fallback_total = ctx->d_fallback_total;
     A.use_deferred = 0;
     A.packet_budget = ctx->packet_budget;
     A.use_packets = 0;
@@ -954,6 +1030,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
             }
         }
         const uint32_t qlds = ctx->quad_stack_depth * BLOCK * (uint32_t)sizeof(uint32_t);
+        const uint32_t plds = A.plan_list_words * BLOCK * (uint32_t)sizeof(uint32_t);  // kernel_plan.h: mesh lists
         const uint32_t heavy_blocks = ctx->heavy_blocks;
         const bool packets = lean && ctx->packet_budget != 0 && !(ctx->debug_skip & 512u);
         if (packets) {
@@ -984,6 +1061,8 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         for (uint32_t g = 0; g <= o->max_depth; g++) {
             A.step_budget = heavy ? (g == 0 ? budget0 : ctx->step_budget) : 0u;
             if (count) launch(stream_trace_shade<true>, lane_blocks, stream, A, g);
+            else if (lean && A.plan_ok && (quad & 1u)) launch_lds(stream_trace_shade_plan<true>, lane_blocks, qlds + plds, stream, A, g);
+            else if (lean && A.plan_ok) launch_lds(stream_trace_shade_plan<false>, lane_blocks, plds, stream, A, g);
             else if (lean && (quad & 1u)) launch_lds(stream_trace_shade_lean<true>, lane_blocks, qlds, stream, A, g);
             else if (lean) launch(stream_trace_shade_lean<false>, lane_blocks, stream, A, g);
             else launch(stream_trace_shade<false>, lane_blocks, stream, A, g);
@@ -1001,6 +1080,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
                 const uint32_t side_blocks = (uint32_t)ctx->num_cus * ctx->side_blocks_per_cu;
                 if (count) launch(stream_trace_shadow<true>, side_blocks, ctx->side, S, 0u);
                 else if (lean && (quad & 2u)) launch_lds(stream_trace_shadow_lean<0, true>, side_blocks, qlds, ctx->side, S);
+                else if (lean && A.plan_ok) launch(stream_trace_shadow_plan<0>, side_blocks, ctx->side, S);
                 else if (lean) launch(stream_trace_shadow_lean<0, false>, side_blocks, ctx->side, S);
                 else launch(stream_trace_shadow<false>, side_blocks, ctx->side, S, 0u);
                 // the walks it gave up follow at once, still beside the levels; the mark comes before the event the
@@ -1017,6 +1097,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
             CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s0[slot], stream));
             if (count) launch(stream_trace_shadow<true>, ctx->grid_blocks, stream, S, 0u);
             else if (lean && (quad & 2u)) launch_lds(stream_trace_shadow_lean<0, true>, ctx->grid_blocks, qlds, stream, S);
+            else if (lean && A.plan_ok) launch(stream_trace_shadow_plan<0>, ctx->grid_blocks, stream, S);
             else if (lean) launch(stream_trace_shadow_lean<0, false>, ctx->grid_blocks, stream, S);
             else launch(stream_trace_shadow<false>, ctx->grid_blocks, stream, S, 0u);
             CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s1[slot], stream));
@@ -1035,6 +1116,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         }
         if (count) launch(stream_trace_shadow<true>, lane_blocks, stream, S, 1u);
         else if (lean && (quad & 4u)) launch_lds(stream_trace_shadow_lean<1, true>, lane_blocks, qlds, stream, S);
+        else if (lean && A.plan_ok) launch(stream_trace_shadow_plan<1>, lane_blocks, stream, S);
         else if (lean) launch(stream_trace_shadow_lean<1, false>, lane_blocks, stream, S);
         else launch(stream_trace_shadow<false>, lane_blocks, stream, S, 1u);
         if (ctx->side_blocks_per_cu) CRT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_s2[slot], 0));
@@ -1049,7 +1131,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         if (count) launch(render_lanes<true>, lane_blocks, stream, A);
         else launch(render_lanes<false>, lane_blocks, stream, A);
         CRT_HIP_CHECK(ctx, hipGetLastError());
-        CRT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_overflow, ctx->d_scounts + SC_OVERFLOW, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        CRT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_overflow, ctx->d_fallback_total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         if (timed) CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev3[slot], stream));
     } else {
         if (ctx->mode == crt_ctx::MODE_PACKETS) {
@@ -1080,6 +1162,13 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
     return CRT_OK;
 }
 
+// Called after a synchronisation: the pinned copy of the last frame's overflow word tells whether the frame was redone
+// by the queue-less kernel.
+static void note_overflow(crt_ctx *ctx) {
+    if (ctx->h_overflow) ctx->overflows = *ctx->h_overflow;
+    ctx->stats.fallback_frames = (uint32_t)ctx->overflows;
+}
+
 static int fetch_counters(crt_ctx *ctx, const crt_options *o, uint64_t pixels) {
     ctx->stats.pixels = pixels;
     ctx->stats.counters_valid = o->collect_counters == 1 ? 1 : 0;
@@ -1107,7 +1196,7 @@ extern "C" int crt_render(crt_ctx *ctx, const crt_options *o, const crt_rect *re
     if (n_rects && !rects) { ctx->error = "rects is NULL"; return CRT_ERR_INVALID; }
     CRT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     // coverage: the union of the clamped rectangles (RayTracer.cpp:84-85), as 8x8 tiles with lane masks
-    bool same = ctx->cached_rects.size() == n_rects && n_rects > 0 &&
+    bool same = !ctx->cached_is_partition && ctx->cached_rects.size() == n_rects && n_rects > 0 &&
                 memcmp(ctx->cached_rects.data(), rects, n_rects * sizeof(crt_rect)) == 0;
     if (!same) {
         const uint32_t tx = ctx->tiles_x, ty = ctx->tiles_y;
@@ -1138,6 +1227,7 @@ extern "C" int crt_render(crt_ctx *ctx, const crt_options *o, const crt_rect *re
         if (!items.empty())
             CRT_HIP_CHECK(ctx, hipMemcpy(ctx->d_items, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice));
         ctx->cached_rects.assign(rects, rects + n_rects);
+        ctx->cached_is_partition = false;
         ctx->cached_n_items = (uint32_t)items.size();
         ctx->cached_pixels = pixels;
     }
@@ -1160,6 +1250,7 @@ extern "C" int crt_render(crt_ctx *ctx, const crt_options *o, const crt_rect *re
     } else ctx->stats.kernel_ms = 0;
     CRT_HIP_CHECK(ctx, hipEventElapsedTime(&ms, t0, t1));
     ctx->stats.total_ms = ms;
+    note_overflow(ctx);
     (void)hipEventDestroy(t0);
     (void)hipEventDestroy(t1);
     return fetch_counters(ctx, o, ctx->cached_pixels);
@@ -1180,9 +1271,8 @@ extern "C" int crt_render_tiles_device(crt_ctx *ctx, const crt_options *o, uint3
     if (stride == 0 || !d_packed) { ctx->error = "bad tile partition"; return CRT_ERR_INVALID; }
     CRT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const uint32_t n = crt_packed_tile_count(ctx, first, stride);
-    // cached under a synthetic rect key {first, stride, ~0, ~0}
-    crt_rect key{first, stride, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    bool same = ctx->cached_rects.size() == 1 && memcmp(ctx->cached_rects.data(), &key, sizeof(key)) == 0;
+    crt_rect key{first, stride, 0u, 0u};
+    bool same = ctx->cached_is_partition && ctx->cached_rects.size() == 1 && memcmp(ctx->cached_rects.data(), &key, sizeof(key)) == 0;
     if (!same) {
         std::vector<WorkItem> items(n);
         uint64_t pixels = 0;
@@ -1199,6 +1289,7 @@ extern "C" int crt_render_tiles_device(crt_ctx *ctx, const crt_options *o, uint3
         if (rc) return rc;
         if (n) CRT_HIP_CHECK(ctx, hipMemcpy(ctx->d_items, items.data(), n * sizeof(WorkItem), hipMemcpyHostToDevice));
         ctx->cached_rects.assign(1, key);
+        ctx->cached_is_partition = true;
         ctx->cached_n_items = n;
         ctx->cached_pixels = pixels;
     }
@@ -1284,7 +1375,7 @@ extern "C" int crt_kernel_times_ms(crt_ctx *ctx, double *out_phase_ms, uint32_t 
         }
     }
     *count = (uint32_t)n;
-    if (*ctx->h_overflow) { ctx->overflows++; }
+    note_overflow(ctx);
     return CRT_OK;
 }
 
@@ -1330,5 +1421,6 @@ extern "C" int crt_synchronize(crt_ctx *ctx) {
     if (!ctx) return CRT_ERR_INVALID;
     CRT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     CRT_HIP_CHECK(ctx, hipDeviceSynchronize());
+    note_overflow(ctx);
     return CRT_OK;
 }

@@ -81,6 +81,7 @@ struct KernelArgs {
     uint32_t *s_counts;           // SC_WORDS counters / cursors, zeroed before every frame
     uint32_t s_ray_cap, s_shadow_cap, s_node_cap;
     uint32_t only_if_overflow;    // lane kernel: run only when the stream pass overflowed its queues
+    uint32_t *fallback_total;     // frames redone that way since crt_create (never reset)
     // heavy-ray path (kernel_heavy.h): leaf boxes in visit order + 64-ary group boxes above them
     const float4 *hbox;           // 2 x float4 per entry: {lo, begin|-} {hi, count|-}
     const HeavyMesh *hmesh;       // per mesh
@@ -118,6 +119,17 @@ struct KernelArgs {
     const float4 *hloose;         // loose boxes of the hbox entries, same indexing
     float scene_scale;            // largest coordinate magnitude of the scene's triangles
     uint32_t prune;               // closest-hit walks skip subtrees whose loose box lies beyond the best hit so far
+    // The top-level tree as a PLAN for the per-lane kernels (kernel_plan.h), built by crt_create when the tree is small
+    // (top_fast) and its boxes are nested: the top-level LEAVES in visit order.  A ray reaches a leaf exactly when the leaf's
+    // own box passes (nesting + monotone slab test, as for the mesh trees), so a wave tests its rays against leaf k with k
+    // uniform -- boxes in scalar registers, no gathers, no divergence -- instead of walking ~40 nodes and ~75 entries per lane.
+    uint32_t plan_ok;             // the plan kernels may be used
+    uint32_t plan_leaves;         // number of top-level leaves, <= 64
+    const float4 *plan_boxes;     // 2 x float4 per leaf: {lo, first entry in leaf_meshes} {hi, number of entries}
+    const uint2 *plan_shadow_masks;  // per leaf: the non-refractive meshes it lists, as bits of the shadow order below
+    const uint32_t *plan_shadow_mesh;  // shadow order: bit b = mesh plan_shadow_mesh[b] (big meshes first: likeliest occluders)
+    uint32_t plan_shadow_bits;    // number of non-refractive meshes, <= 64
+    uint32_t plan_list_words;     // LDS words per lane of a closest-hit ray's mesh list: ceil(meshes / 4)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -284,6 +296,20 @@ __device__ __forceinline__ void primary_ray(const KernelArgs &A, uint32_t px, ui
     ray_prepare(R);
 }
 
+// float -> integer conversions as the reference's x86-64 build performs them (Texture.cpp:38-39, 67-68).  In range both
+// targets truncate; out of range the GPU's conversions saturate, whereas cvttss2si returns the "integer indefinite"
+// value -- and `(unsigned int)f` is compiled as a 64-bit cvttss2si whose low half is kept, so negative UVs wrap
+// (-1.5 -> 0xFFFFFFFF) instead of clamping to 0.  Written out here so that the checker parity and the bitmap clamp see
+// the same integers as the reference for every input, NaN included.
+__device__ __forceinline__ int x86_float_to_int(float f) {
+    return (f >= -2147483648.0f && f < 2147483648.0f) ? (int)f : (int)0x80000000;
+}
+__device__ __forceinline__ unsigned int x86_float_to_uint(float f) {
+    const bool in_range = f >= -9223372036854775808.0f && f < 9223372036854775808.0f;  // NaN: false
+    const long long v = in_range ? (long long)f : (long long)0x8000000000000000ull;
+    return (unsigned int)(unsigned long long)v;
+}
+
 // Texture::getColor (Texture.cpp:14-72)
 template <bool COUNT>
 __device__ __forceinline__ void texture_color(const KernelArgs &A, const DTexture &T, uint32_t tri, float u, float v,
@@ -301,14 +327,14 @@ __device__ __forceinline__ void texture_color(const KernelArgs &A, const DTextur
     const float uvx = (u * A.vuvs[3 * (size_t)i1] + v * A.vuvs[3 * (size_t)i2]) + w * A.vuvs[3 * (size_t)i0];
     const float uvy = (u * A.vuvs[3 * (size_t)i1 + 1] + v * A.vuvs[3 * (size_t)i2 + 1]) + w * A.vuvs[3 * (size_t)i0 + 1];
     if (T.kind == CRT_TEX_CHECKER) {
-        const unsigned int x = (unsigned int)(uvx / T.scalar);
-        const unsigned int y = (unsigned int)(uvy / T.scalar);
+        const unsigned int x = x86_float_to_uint(uvx / T.scalar);
+        const unsigned int y = x86_float_to_uint(uvy / T.scalar);
         if (x % 2 == y % 2) { r = T.ax; g = T.ay; b = T.az; } else { r = T.bx; g = T.by; b = T.bz; }
         return;
     }
     is_bitmap = true;
-    int x = (int)(uvx * (float)(int)T.w);
-    int y = (int)((1.0f - uvy) * (float)(int)T.h);
+    int x = x86_float_to_int(uvx * (float)(int)T.w);
+    int y = x86_float_to_int((1.0f - uvy) * (float)(int)T.h);
     x = (x < 0) ? 0 : (((int)T.w - 1 < x) ? (int)T.w - 1 : x);  // std::clamp
     y = (y < 0) ? 0 : (((int)T.h - 1 < y) ? (int)T.h - 1 : y);
     const uint32_t px = A.texels[T.offset + (size_t)y * T.w + (size_t)x];

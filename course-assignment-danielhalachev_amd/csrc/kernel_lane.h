@@ -136,7 +136,10 @@ __global__ __launch_bounds__(BLOCK) void render_lanes(const KernelArgs A) {
     float basex = 0, basey = 0, basez = 0, accx = 0, accy = 0, accz = 0, kfac = 0;
     uint32_t li = 0;
     bool base_is_bitmap = false;
-    if (A.only_if_overflow && !A.s_counts[SC_OVERFLOW_WORD]) return;  // fallback of the stream pass: usually nothing to do
+    if (A.only_if_overflow) {  // fallback of the stream pass: usually nothing to do
+        if (!A.s_counts[SC_OVERFLOW_WORD]) return;
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(A.fallback_total, 1u);  // reported as crt_stats::fallback_frames
+    }
     const uint32_t total_px = A.use_deferred ? *A.deferred_count : A.n_items * 64u;
 
     for (;;) {

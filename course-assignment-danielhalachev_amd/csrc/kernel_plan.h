@@ -1,0 +1,409 @@
+// kernel_plan.h -- the per-lane ray-stream kernels with the top-level tree evaluated as a PLAN.
+//
+// What kernel_walk.h's walks spend most of their loop trips on is not the mesh trees but the top-level tree: on the
+// benchmark scene (9 meshes, 39 top-level nodes, 20 leaves listing 75 entries) a ray takes ~17 node steps and ~37 entry
+// steps up there -- each one a trip through the "rare" block of a divergent wave -- against ~14 node and ~9 triangle steps
+// inside the meshes.  None of that depends on anything but the ray and a table of a kilobyte:
+//
+//  * the top-level tree's boxes are nested (crt_create checks it) and the slab test is monotone under that nesting, so the
+//    reference reaches a top-level leaf exactly when the leaf's OWN box passes its exact test (the argument of
+//    kernel_heavy.h for the mesh trees);
+//  * so when a wave refills, the new rays are tested against leaf k for k = 0 .. leaves-1 in a WAVE-UNIFORM loop: the box
+//    sits in scalar registers (one s_load per leaf for the whole wave), there is no gather and no divergence;
+//  * a SHADOW ray only needs the SET of non-refractive meshes listed in the leaves it reaches
+//    (AccelerationStructure.cpp:60-90 is an OR over them): a 64-bit mask, walked big meshes first (likeliest occluders);
+//  * a CLOSEST-HIT ray needs them in the reference's order -- leaves in visit order, entries in list order, every mesh at
+//    its first occurrence (kernel_common.h: mesh_walk_is_repeat) -- because ties between meshes go to the first one
+//    collected (KDTree.cpp:159-166): the same uniform loop appends them to a per-lane byte list in LDS.
+//
+// What remains per lane is the walk of the mesh trees themselves: two blocks (one triangle / one node), the step from one
+// mesh to the next folded into the node block.
+//
+// A shadow walk needs no per-mesh bookkeeping at all: the early exit (kernel_walk.h: shadow_hit_occludes) fires on the
+// first accepted hit with a finite t within the light's distance, and the reference's end-of-mesh test on the mesh's
+// closest hit can only succeed if that very test had succeeded when the hit was accepted (same floats, same expression;
+// an infinite or NaN t fails both).  So "occluded" == "some accepted hit passes the distance test", mesh by mesh or not.
+#pragma once
+
+#include "kernel_common.h"
+#include "kernel_packet.h"
+#include "kernel_stream.h"
+#include "kernel_walk.h"
+
+// one top-level leaf: {lo.xyz, first entry} {hi.xyz, entry count} {shadow mask lo, hi, -, -} {-}: 16 dwords, one s_load_dwordx16
+constexpr int PLAN_LEAF_DWORDS = 16;
+
+__device__ __forceinline__ v16f plan_leaf(const KernelArgs &A, uint32_t k) {
+    return *(kv16p)((kfp)(const float *)A.plan_boxes + PLAN_LEAF_DWORDS * (size_t)k);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- shadow
+template <uint32_t pass>
+__global__ __launch_bounds__(BLOCK) void stream_trace_shadow_plan(const KernelArgs A) {
+    __shared__ uint32_t root_of_bit[64];  // shadow order -> root node of the mesh's tree
+    if (threadIdx.x < 64u) root_of_bit[threadIdx.x] = threadIdx.x < A.plan_shadow_bits ? A.meshes[A.plan_shadow_mesh[threadIdx.x]].root : END;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    if (A.s_counts[SC_OVERFLOW]) return;
+    const uint32_t split = A.s_counts[SC_SHADOW_SPLIT];
+    const uint32_t first = pass == 0 ? 0u : split;
+    const uint32_t total = pass == 0 ? split : A.s_counts[SC_SHADOW] - split;
+    uint32_t *cursor = A.s_counts + (pass == 0 ? SC_SHADOW_FETCH : SC_SHADOW_FETCH2);
+    const char *nodes_b = reinterpret_cast<const char *>(A.nodes);
+    const char *ltris_b = reinterpret_cast<const char *>(A.ltris);
+
+    Ray R;
+    uint32_t wn = END, we = NONE;   // next mesh-tree node, next leaf entry
+    uint32_t mlo = 0, mhi = 0;      // meshes still to walk, bits of the shadow order
+    float light_dist = 0;
+    uint32_t nbox = 0, ntri = 0;
+    int state = ST_FETCH;
+    uint32_t r = 0, steps = 0;
+    for (;;) {
+        // ---- refill: free lanes wait until no more than `bundle` lanes still walk, then fetch together (the plan below
+        //      costs the wave the same for one new ray as for 64)
+        if (__ballot(state == ST_FETCH) && (A.bundle >= 64u || (uint32_t)__popcll(__ballot(state == ST_TRAVERSE)) <= A.bundle)) {
+            bool fresh = false;
+            while (state == ST_FETCH) {
+                r = wave_fetch(cursor, lane);
+                if (r >= total) { state = ST_DONE; break; }
+                r += first;
+                const float4 q0 = A.s_shadowq[2 * (size_t)r], q1 = A.s_shadowq[2 * (size_t)r + 1];
+                if (__float_as_uint(q0.w) == SHADOW_SLOT_UNUSED) continue;  // a level-0 pixel without a diffuse hit
+                R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
+                R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;  // already normalised once; shadow rays skip shootRay (RayTracer.cpp:313-317)
+                ray_prepare(R);
+                if (R.parmask != 0) {  // BoundingBox.h:90-93 needs the general test: the wave-per-ray kernel has it
+                    if (evict_ray(A.s_sheavy, A.s_heavy_cap, A.s_counts + SC_SHEAVY, r, lane)) continue;
+                    A.s_counts[SC_OVERFLOW] = 1;
+                    continue;
+                }
+                light_dist = q0.w;
+                fresh = true;
+                steps = 0;
+                state = ST_TRAVERSE;
+            }
+            if (fresh) {
+                // the plan: which meshes does this ray have to walk?  (k is wave-uniform: scalar loads, no gathers)
+                uint32_t lo = 0, hi = 0;
+                for (uint32_t k = 0; k < A.plan_leaves; k++) {
+                    const v16f L = plan_leaf(A, k);
+                    const bool hit = slab_test_no_parallel(R, L[0], L[1], L[2], L[4], L[5], L[6]);
+                    lo |= hit ? __float_as_uint(L[8]) : 0u;
+                    hi |= hit ? __float_as_uint(L[9]) : 0u;
+                }
+                if (A.exec_count) nbox += A.plan_leaves;
+                mlo = lo; mhi = hi; wn = END; we = NONE;
+            }
+        }
+        if (!__ballot(state != ST_DONE)) break;
+        if (state == ST_TRAVERSE) {
+            bool done = false, occluded = false;
+            for (int it = 0; it < 64; ++it) {
+                steps++;
+                if (we != NONE) {
+                    // ---- one triangle of the current leaf (Ray.cpp:9-31, Triangle.cpp:37-57), branch-free
+                    const float4 *T = reinterpret_cast<const float4 *>(ltris_b + (size_t)(uint32_t)(we << 6));
+                    const float4 a = T[0], b = T[1], c = T[2], d = T[3];
+                    if (A.exec_count) ntri++;
+                    const float nx = a.w, ny = b.w, nz = c.w;
+                    const float nd = dot3(R.dx, R.dy, R.dz, nx, ny, nz);
+                    const float t = -(dot3(nx, ny, nz, R.ox, R.oy, R.oz) + d.x) / nd;
+                    const float px = R.ox + R.dx * t, py = R.oy + R.dy * t, pz = R.oz + R.dz * t;
+                    float s0, s1, s2;
+                    {
+                        const float ex = b.x - a.x, ey = b.y - a.y, ez = b.z - a.z, cx = px - a.x, cy = py - a.y, cz = pz - a.z;
+                        s0 = dot3(nx, ny, nz, ey * cz - ez * cy, ez * cx - ex * cz, ex * cy - ey * cx);
+                    }
+                    {
+                        const float ex = c.x - b.x, ey = c.y - b.y, ez = c.z - b.z, cx = px - b.x, cy = py - b.y, cz = pz - b.z;
+                        s1 = dot3(nx, ny, nz, ey * cz - ez * cy, ez * cx - ex * cz, ex * cy - ey * cx);
+                    }
+                    {
+                        const float ex = a.x - c.x, ey = a.y - c.y, ez = a.z - c.z, cx = px - c.x, cy = py - c.y, cz = pz - c.z;
+                        s2 = dot3(nx, ny, nz, ey * cz - ez * cy, ez * cx - ex * cz, ex * cy - ey * cx);
+                    }
+                    // shadow rays are not culled (Ray.cpp:13 is PrimaryRay only)
+                    const bool ok = !(t < 0) && !(s0 < -FLT_EPSILON) && !(s1 < -FLT_EPSILON) && !(s2 < -FLT_EPSILON);
+                    we = __float_as_uint(d.z) ? NONE : we + 1;
+                    if (ok && t < INFINITY && shadow_hit_occludes(R, px, py, pz, light_dist)) { occluded = true; done = true; break; }
+                } else {
+                    if (wn == END) {  // the next mesh, or the end of the walk
+                        if ((mlo | mhi) == 0u) { done = true; break; }
+                        const uint32_t bit = mlo ? (uint32_t)__builtin_ctz(mlo) : 32u + (uint32_t)__builtin_ctz(mhi);
+                        if (mlo) mlo &= mlo - 1u; else mhi &= mhi - 1u;
+                        wn = root_of_bit[bit];
+                    }
+                    // ---- one mesh-tree node (KDTree.cpp:53-74, BoundingBox.h:85-108), branch-free
+                    const float4 *N = reinterpret_cast<const float4 *>(nodes_b + (size_t)(uint32_t)(wn << 5));
+                    const float4 q0 = N[0], q1 = N[1];
+                    if (A.exec_count) nbox++;
+                    const uint32_t miss = __float_as_uint(q0.w), link = __float_as_uint(q1.w);
+                    const bool hit = slab_test_no_parallel(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
+                    const bool leaf = is_leaf_link(link);
+                    we = (hit && leaf) ? (link & ~LEAF) : NONE;
+                    wn = (hit && !leaf) ? link : miss;
+                }
+            }
+            if (done) {
+                A.s_occluded[r] = occluded ? 1 : 0;
+                state = ST_FETCH;
+            } else if (steps >= A.step_budget) {
+                // a long walk goes to the wave-per-ray kernel, which restarts it (the list full: keep walking here)
+                if (evict_ray(A.s_sheavy, A.s_heavy_cap, A.s_counts + SC_SHEAVY, r, lane)) state = ST_FETCH;
+                steps = 0;
+            }
+        }
+    }
+    exec_counters_flush(A, nbox, ntri, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------- closest hit
+// The meshes a closest-hit ray has to walk, in the reference's order, as a byte list per lane in LDS: word w of thread t at
+// list[w * BLOCK + t] holds entries 4w .. 4w+3 (conflict-free: consecutive lanes, consecutive words).
+struct PlanList {
+    uint32_t *words;   // this thread's column
+    uint32_t count;    // entries written
+    uint32_t next;     // next entry to read
+};
+
+// Appends, for every top-level leaf the ray reaches, the meshes it lists that the ray has not met before -- in leaf visit
+// order and list order, i.e. in the order the reference collects their hits (KDTree.cpp:132-155).  Wave-uniform loops:
+// leaf boxes and entries come through scalar loads.
+__device__ __forceinline__ void plan_closest_meshes(const KernelArgs &A, const Ray &R, PlanList &PL, uint32_t &nbox) {
+    const ku32p entries = (ku32p)A.leaf_meshes;
+    uint32_t seen_lo = 0, seen_hi = 0, acc = 0, cnt = 0;
+    for (uint32_t k = 0; k < A.plan_leaves; k++) {
+        const v16f L = plan_leaf(A, k);
+        const bool hit = slab_test_no_parallel(R, L[0], L[1], L[2], L[4], L[5], L[6]);
+        // (no `continue` on the wave-uniform ballot: DESIGN.md "compiler notes")
+        const uint32_t first = __builtin_amdgcn_readfirstlane(__float_as_uint(L[3]));
+        const uint32_t n = __ballot(hit) ? __builtin_amdgcn_readfirstlane(__float_as_uint(L[7])) : 0u;
+        for (uint32_t j = 0; j < n; j++) {
+            const uint32_t m = entries[first + j] & ~LAST;  // uniform, < 64 (plan_ok)
+            const uint32_t bit = 1u << (m & 31u);
+            const bool lo = m < 32u;
+            const bool fresh = hit && !((lo ? seen_lo : seen_hi) & bit);
+            if (fresh) {
+                if (lo) seen_lo |= bit; else seen_hi |= bit;
+                acc |= m << (8u * (cnt & 3u));
+                cnt++;
+                if ((cnt & 3u) == 0u) { PL.words[((cnt >> 2) - 1u) * BLOCK] = acc; acc = 0; }
+            }
+        }
+    }
+    if (cnt & 3u) PL.words[(cnt >> 2) * BLOCK] = acc;
+    if (A.exec_count) nbox += A.plan_leaves;
+    PL.count = cnt;
+    PL.next = 0;
+}
+
+__device__ __forceinline__ uint32_t plan_list_pop(PlanList &PL) {
+    const uint32_t i = PL.next++;
+    return (PL.words[(i >> 2) * BLOCK] >> (8u * (i & 3u))) & 255u;
+}
+
+// Every ray of recursion level `gen`, one per lane: plan, walk of the listed meshes (quad or binary nodes), material
+// dispatch.  Same results and same queues as stream_trace_shade_lean; rays with a parallel axis, walks longer than the
+// step budget and (QUAD) walks that outgrow the LDS stack go to heavy_trace_closest.
+template <bool QUAD>
+__global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArgs A, const uint32_t gen) {
+    extern __shared__ uint32_t plan_lds[];  // [quad stack: A.quad_stack_depth x BLOCK (QUAD only)] [mesh lists: A.plan_list_words x BLOCK]
+    __shared__ TopLdsStorage top_storage;
+    const TopLds TL = top_lds_load(A, top_storage);  // mesh records {flags, tree root, quad root} (a barrier inside)
+    uint32_t *const stk = plan_lds + threadIdx.x;
+    PlanList PL;
+    PL.words = plan_lds + (QUAD ? A.quad_stack_depth * BLOCK : 0u) + threadIdx.x;
+    PL.count = 0; PL.next = 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (A.s_counts[SC_OVERFLOW]) return;
+    const uint32_t count = stream_level_count(A, gen);
+    const uint32_t node_base = stream_level_base(A, gen);
+    const uint32_t child_base = node_base + count;
+    const float4 *in_q = A.s_rayq[gen & 1u];
+    const bool primary = gen == 0;
+    const bool todo = gen == 0 && A.use_packets;  // level 0 after stream_packets_gen0: only the tiles that kernel gave up on
+    const uint32_t fetch_count = todo ? A.s_counts[SC_TODO_TILES] * 64u : count;
+    if (stream_level_is_whole_heavy(A, gen, count)) return;
+    const char *nodes_b = reinterpret_cast<const char *>(A.nodes);
+    const char *quads_b = reinterpret_cast<const char *>(A.quads);
+    const char *ltris_b = reinterpret_cast<const char *>(A.ltris);
+
+    Ray R;
+    Prune prune;
+    uint32_t wq = NONE, we = NONE, sp = 0, top = NONE;  // QUAD: quad to test, leaf entry, stack; binary: wq = next node (END: none)
+    uint32_t mesh = NONE, mtri = 0, btri = 0, bmesh = 0;
+    float mmin = INFINITY, mt = 0, tmin = INFINITY, bt = 0;
+    bool mhave = false, have = false;
+    uint32_t nbox = 0, ntri = 0;
+    int state = ST_FETCH;
+    uint32_t r = 0, steps = 0;
+    for (;;) {
+        if (__ballot(state == ST_FETCH) && (A.bundle >= 64u || (uint32_t)__popcll(__ballot(state == ST_TRAVERSE)) <= A.bundle)) {
+            bool fresh = false;
+            while (state == ST_FETCH) {
+                r = wave_fetch(A.s_counts + SC_FETCH + gen, lane);
+                if (r >= fetch_count) { state = ST_DONE; break; }
+                if (todo) r = A.s_todo_tiles[r >> 6] * 64u + (r & 63u);
+                if (gen == 0) {
+                    const WorkItem wi = A.items[r >> 6];
+                    const uint32_t sub = r & 63u;
+                    const uint32_t px = (wi.tile % A.tiles_x) * TILE + (sub & 7u);
+                    const uint32_t py = (wi.tile / A.tiles_x) * TILE + (sub >> 3);
+                    if (!((wi.mask >> sub) & 1ull) || px >= A.width || py >= A.height) {
+                        reinterpret_cast<uint32_t *>(A.s_nodes + 2 * (size_t)r)[3] = TN_SKIP;
+                        level0_release_shadow_slots(A, r);
+                        continue;
+                    }
+                    primary_ray(A, px, py, R);
+                } else {
+                    const float4 q0 = in_q[2 * (size_t)r], q1 = in_q[2 * (size_t)r + 1];
+                    R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
+                    R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;
+                    normalize3(R.dx, R.dy, R.dz);  // shootRay entry (RayTracer.cpp:420)
+                    ray_prepare(R);
+                }
+                if (R.parmask != 0) {
+                    if (evict_ray(A.s_heavy, A.s_heavy_cap, A.s_counts + SC_HEAVY + gen, r, lane)) continue;
+                    A.s_counts[SC_OVERFLOW] = 1;  // cannot walk it here: let the fallback redo the frame
+                    continue;
+                }
+                fresh = true;
+                steps = 0;
+                state = ST_TRAVERSE;
+            }
+            if (fresh) {
+                plan_closest_meshes(A, R, PL, nbox);
+                if (QUAD) prune_prepare(prune, R, A.scene_scale);
+                wq = QUAD ? NONE : END; we = NONE; sp = 0; top = NONE; mesh = NONE;
+                mhave = false; mmin = INFINITY; mt = 0; mtri = 0;
+                have = false; tmin = INFINITY; bt = 0; btri = 0; bmesh = 0;
+            }
+        }
+        if (!__ballot(state != ST_DONE)) break;
+        if (state == ST_TRAVERSE) {
+            bool done = false, stack_full = false;
+            for (int it = 0; it < 64; ++it) {
+                steps++;
+                bool next = false;
+                uint32_t cur = NONE;
+                if (we != NONE) {
+                    // ---- one triangle of the current leaf (Ray.cpp:9-31, Triangle.cpp:37-57), branch-free
+                    const float4 *T = reinterpret_cast<const float4 *>(ltris_b + (size_t)(uint32_t)(we << 6));
+                    const float4 a = T[0], b = T[1], c = T[2], d = T[3];
+                    if (A.exec_count) ntri++;
+                    const float nx = a.w, ny = b.w, nz = c.w;
+                    const float nd = dot3(R.dx, R.dy, R.dz, nx, ny, nz);
+                    const float t = -(dot3(nx, ny, nz, R.ox, R.oy, R.oz) + d.x) / nd;
+                    const float px = R.ox + R.dx * t, py = R.oy + R.dy * t, pz = R.oz + R.dz * t;
+                    float s0, s1, s2;
+                    {
+                        const float ex = b.x - a.x, ey = b.y - a.y, ez = b.z - a.z, cx = px - a.x, cy = py - a.y, cz = pz - a.z;
+                        s0 = dot3(nx, ny, nz, ey * cz - ez * cy, ez * cx - ex * cz, ex * cy - ey * cx);
+                    }
+                    {
+                        const float ex = c.x - b.x, ey = c.y - b.y, ez = c.z - b.z, cx = px - b.x, cy = py - b.y, cz = pz - b.z;
+                        s1 = dot3(nx, ny, nz, ey * cz - ez * cy, ez * cx - ex * cz, ex * cy - ey * cx);
+                    }
+                    {
+                        const float ex = a.x - c.x, ey = a.y - c.y, ez = a.z - c.z, cx = px - c.x, cy = py - c.y, cz = pz - c.z;
+                        s2 = dot3(nx, ny, nz, ey * cz - ez * cy, ez * cx - ex * cz, ex * cy - ey * cx);
+                    }
+                    const bool ok = !(primary && nd >= 0) && !(t < 0) && !(s0 < -FLT_EPSILON) && !(s1 < -FLT_EPSILON) && !(s2 < -FLT_EPSILON);
+                    // `closest = hits[0]; min = inf; for h: if (h.d < min) { min = h.d; closest = h; }` (KDTree.cpp:75-86)
+                    const bool less = ok && (t < mmin);
+                    const bool take = less || (ok && !mhave);
+                    mt = take ? t : mt;
+                    mtri = take ? __float_as_uint(d.y) : mtri;
+                    mmin = less ? t : mmin;
+                    mhave = mhave || ok;
+                    const bool last = __float_as_uint(d.z) != 0;
+                    if (QUAD) { next = last; we = last ? NONE : we + 1; }
+                    else we = last ? NONE : we + 1;
+                } else {
+                    if (QUAD ? (wq == NONE) : (wq == END)) {
+                        // ---- a mesh ended (scene-level rule, KDTree.cpp:156-167), the next one begins
+                        if (mesh != NONE && mhave) {
+                            if (!have) { have = true; bt = mt; btri = mtri; bmesh = mesh; }
+                            if (mt < tmin) { tmin = mt; bt = mt; btri = mtri; bmesh = mesh; }
+                        }
+                        if (PL.next >= PL.count) { done = true; break; }
+                        mesh = plan_list_pop(PL);
+                        const lds_v4u m = TL.meshes[mesh];
+                        wq = QUAD ? m[2] : m[1];
+                        mhave = false;
+                        mmin = INFINITY;
+                    }
+                    if constexpr (QUAD) {
+                        // ---- one quad: four boxes (BoundingBox.h:85-108), the slots that pass go on the stack, last first
+                        if (sp + 4 > A.quad_stack_depth) { stack_full = true; break; }
+                        const float4 *Q = reinterpret_cast<const float4 *>(quads_b + (size_t)(uint32_t)(wq << 8));
+                        const float4 lx = Q[0], ly = Q[1], lz = Q[2], hx = Q[3], hy = Q[4], hz = Q[5];
+                        const uint4 lk = reinterpret_cast<const uint4 *>(Q)[6];
+                        if (A.exec_count) nbox += (lk.x != NONE) + (lk.y != NONE) + (lk.z != NONE) + (lk.w != NONE);
+                        bool h0 = lk.x != NONE && slab_test_no_parallel(R, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x);
+                        bool h1 = lk.y != NONE && slab_test_no_parallel(R, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y);
+                        bool h2 = lk.z != NONE && slab_test_no_parallel(R, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z);
+                        bool h3 = lk.w != NONE && slab_test_no_parallel(R, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w);
+                        if (A.prune & 1u) {
+                            const float bound = fminf(tmin, mmin);  // only a strictly smaller distance changes anything
+                            if (bound < INFINITY) {
+                                const float4 cx = Q[(prune.bits & 8u) ? 8 : 11], cy = Q[(prune.bits & 16u) ? 9 : 12], cz = Q[(prune.bits & 32u) ? 10 : 13];
+                                h0 = h0 && !(prune_bound(prune, R, cx.x, cy.x, cz.x) >= bound);
+                                h1 = h1 && !(prune_bound(prune, R, cx.y, cy.y, cz.y) >= bound);
+                                h2 = h2 && !(prune_bound(prune, R, cx.z, cy.z, cz.z) >= bound);
+                                h3 = h3 && !(prune_bound(prune, R, cx.w, cy.w, cz.w) >= bound);
+                            }
+                        }
+#define CRT_PPUSH(x)                                              \
+    do {                                                          \
+        if (sp > 0) stk[(sp - 1) * BLOCK] = top;                  \
+        top = (x);                                                \
+        sp++;                                                     \
+    } while (0)
+                        if (h3) cur = lk.w;
+                        if (h2) { if (cur != NONE) CRT_PPUSH(cur); cur = lk.z; }
+                        if (h1) { if (cur != NONE) CRT_PPUSH(cur); cur = lk.y; }
+                        if (h0) { if (cur != NONE) CRT_PPUSH(cur); cur = lk.x; }
+#undef CRT_PPUSH
+                        wq = NONE;
+                        next = true;
+                    } else {
+                        // ---- one mesh-tree node (KDTree.cpp:53-74, BoundingBox.h:85-108), branch-free
+                        const float4 *N = reinterpret_cast<const float4 *>(nodes_b + (size_t)(uint32_t)(wq << 5));
+                        const float4 q0 = N[0], q1 = N[1];
+                        if (A.exec_count) nbox++;
+                        const uint32_t miss = __float_as_uint(q0.w), link = __float_as_uint(q1.w);
+                        const bool hit = slab_test_no_parallel(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
+                        const bool leaf = is_leaf_link(link);
+                        we = (hit && leaf) ? (link & ~LEAF) : NONE;
+                        wq = (hit && !leaf) ? link : miss;
+                    }
+                }
+                if (QUAD && next) {
+                    // the next slot: the first one that passed just now, else the most recent pending one
+                    if (cur == NONE && sp > 0) {
+                        cur = top;
+                        sp--;
+                        if (sp > 0) top = stk[(sp - 1) * BLOCK];
+                    }
+                    if (cur != NONE) {
+                        if (cur & LEAF) we = cur & ~LEAF;
+                        else wq = cur;
+                    }
+                }
+            }
+            if (done) {
+                shade_and_emit<false>(A, gen, r, node_base, child_base, R, have, bt, btri, bmesh, nullptr, lane);
+                state = ST_FETCH;
+            } else if (stack_full) {  // restart it in the wave-per-ray kernel, which needs no stack
+                if (!evict_ray(A.s_heavy, A.s_heavy_cap, A.s_counts + SC_HEAVY + gen, r, lane)) A.s_counts[SC_OVERFLOW] = 1;
+                state = ST_FETCH;
+            } else if (steps >= A.step_budget) {
+                if (evict_ray(A.s_heavy, A.s_heavy_cap, A.s_counts + SC_HEAVY + gen, r, lane)) state = ST_FETCH;
+                steps = 0;
+            }
+        }
+    }
+    exec_counters_flush(A, nbox, ntri, lane);
+}

@@ -98,9 +98,10 @@ void writePPMQuantized(const std::string &path, const uint8_t *rgb8, unsigned in
 }
 
 // ------------------------------------------------------------------------------------------------ RayTracer
-RayTracer::RayTracer(Scene &scene, int device) : accelerationStructure(scene), scene(scene), camera(scene.camera) {
+RayTracer::RayTracer(Scene &scene, int device, const crt_tuning *tuning)
+    : accelerationStructure(scene), scene(scene), camera(scene.camera) {
   flattenScene(scene, accelerationStructure, flat);
-  int rc = crt_create(&flat.desc, device, &ctx);
+  int rc = crt_create_tuned(&flat.desc, device, tuning, &ctx);
   if (rc != CRT_OK) throw std::runtime_error(std::string("crt_create failed: ") + crt_last_error(nullptr));
   {  // the context starts with the scene's camera, as RayTracer::RayTracer copies scene.camera (RayTracer.cpp:46)
     const float pos[3] = {camera.getPosition().x, camera.getPosition().y, camera.getPosition().z};

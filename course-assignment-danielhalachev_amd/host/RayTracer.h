@@ -67,7 +67,7 @@ class RayTracer {
   // Builds the two-level tree once (as RayTracer::RayTracer does, RayTracer.cpp:45-51), flattens it and
   // uploads scene + tree to the GPU.  Throws std::runtime_error when no usable GPU exists: there is no
   // CPU fallback.
-  explicit RayTracer(Scene &scene, int device = 0);
+  explicit RayTracer(Scene &scene, int device = 0, const crt_tuning *tuning = nullptr);
   ~RayTracer();
   RayTracer(const RayTracer &) = delete;
   RayTracer &operator=(const RayTracer &) = delete;

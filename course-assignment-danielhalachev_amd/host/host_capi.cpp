@@ -154,6 +154,10 @@ extern "C" int crt_host_camera_apply(float position[3], float matrix[9], int op,
 }
 
 extern "C" int crt_host_tracer_create(crt_host_scene *scene, int device, crt_host_tracer **out) {
+  return crt_host_tracer_create_tuned(scene, device, nullptr, out);
+}
+
+extern "C" int crt_host_tracer_create_tuned(crt_host_scene *scene, int device, const crt_tuning *tuning, crt_host_tracer **out) {
   if (!scene || !out) return CRT_ERR_INVALID;
   *out = nullptr;
   int ndev = crt_device_count();
@@ -164,7 +168,7 @@ extern "C" int crt_host_tracer_create(crt_host_scene *scene, int device, crt_hos
   return guarded([&]() {
     std::unique_ptr<crt_host_tracer> t(new crt_host_tracer());
     t->scene = scene;
-    t->tracer.reset(new crt::RayTracer(scene->scene, device));
+    t->tracer.reset(new crt::RayTracer(scene->scene, device, tuning));
     *out = t.release();
     return CRT_OK;
   });

@@ -353,6 +353,13 @@ CONFIGS = {
     "hw14": (hw14_scene, 1920, 1080, 8),
     "hw12": (hw12_scene, 3840, 2160, 8),
 }
+DESCRIPTIONS = {
+    "hw07": "HW07 Scene-like: one flat-shaded diffuse sphere, one light",
+    "hw08": "HW08 Light-like: floor + smooth diffuse sphere, three lights (primary + shadow rays)",
+    "hw11": "HW11 Shading03-like: coloured room with a reflective and a refractive sphere, four lights",
+    "hw14": "HW14 Optimizations02-like BVH scene: room + seeded torus knot + reflective and refractive spheres, four lights",
+    "hw12": "HW12 Textures-like: albedo / edge / checker / bitmap textures on quads and a large textured mesh",
+}
 
 
 def make(name, width=None, height=None, detail=1.0, **kw):

@@ -154,14 +154,52 @@ typedef struct crt_stats {
     uint64_t primary_rays, secondary_rays, shadow_rays;
     uint64_t pixels;           /* pixels rendered by the last call */
     uint32_t counters_valid;   /* 1 when the last render ran with collect_counters */
+    uint32_t fallback_frames;  /* frames since crt_create whose ray queues overflowed and that were redone by the
+                                * queue-less kernel (same pixels, much slower): raise crt_tuning's *_cap if this grows.
+                                * Updated by the synchronous calls (crt_render, crt_kernel_times_ms, crt_synchronize). */
 } crt_stats;
 
 typedef struct crt_ctx crt_ctx;
+
+/* Kernel selection and sizing.  Nothing here changes a pixel: every combination renders the same frame bit for
+ * bit (tests/test_gpu_parity.py runs the matrix); the defaults are what bench.py measures.  The reference has no
+ * counterpart (its only tunables are RenderOptions, above); the library reads NO environment variables. */
+enum { CRT_MODE_STREAM = 0, CRT_MODE_PACKETS = 1, CRT_MODE_LANES = 2 };
+typedef struct crt_tuning {
+    uint32_t size;            /* sizeof(crt_tuning), filled in by crt_tuning_defaults */
+    uint32_t mode;            /* CRT_MODE_STREAM (ray stream, default) | _PACKETS (wave per 8x8 tile) | _LANES (full recursion per lane) */
+    uint32_t step_budget;     /* 256: steps after which a closest-hit walk goes to the wave-per-ray kernel; 0 = faithful kernels only */
+    uint32_t shadow_budget;   /* 4096: cap of the same for the bulk shadow pass (the launch scales it down with its size) */
+    uint32_t pass1_budget;    /* 0 (= step_budget): cap for the second shadow pass */
+    uint32_t heavy_level;     /* 100000: recursion levels with fewer rays skip the per-lane kernel */
+    uint32_t heavy_blocks;    /* 4096: grid of the wave-per-ray kernels */
+    uint32_t side_blocks;     /* 4: workgroups per CU of the bulk shadow pass on the side stream; 0 = no side stream */
+    uint32_t quad;            /* 1: which lean kernels walk quad nodes (bit 0 levels, 1 bulk shadow pass, 2 second shadow pass) */
+    uint32_t quad_stack;      /* 16: LDS words per lane of the quad walk's stack (4..60) */
+    uint32_t prune;           /* 0: exact distance pruning of closest-hit walks (bit 0 quad walk, bit 1 wave-per-ray) */
+    uint32_t bundle;          /* 16: the bulk shadow pass refills a wave when at most this many lanes still walk (64: lane by lane) */
+    uint32_t fixed0;          /* 1: level 0's shadow rays in fixed tile-ordered slots (0: queued like the deeper levels') */
+    uint32_t packet_budget;   /* 0: level 0 by packets first, giving a tile up after this many wave-level visits */
+    uint32_t path_mask;       /* 0: path selection for tests: 256 = no lean kernels, 512 = no packets */
+    uint32_t top_in_registers; /* 1: small top-level trees are held in registers / LDS */
+    uint32_t tiny_meshes;     /* 1: single-leaf meshes are tested in one step by the wave-per-ray kernels */
+    uint32_t node_cap, ray_cap, shadow_cap; /* 0 = sized from the frame (4x / 3x / n_lights x 4x the pixels, at least 2^20);
+                                             * smaller values make queue overflow -- and the fallback -- reachable in tests */
+    uint32_t deep;            /* 1: recursion levels >= 1 run as ONE persistent queue-driven launch (no level barriers);
+                               * 0: one launch triple per level */
+    uint32_t deep_blocks;     /* 0 (= 4 per CU): workgroups of that launch */
+    uint32_t plan;            /* 1: the per-lane kernels evaluate a small top-level tree as a plan (its leaves tested in a
+                               * wave-uniform loop) instead of walking it node by node per lane */
+    uint32_t reserved[5];
+} crt_tuning;
+void crt_tuning_defaults(crt_tuning *tuning);
 
 /* replaces RayTracer::RayTracer(Scene&) (RayTracer.cpp:45-51): copies the flattened scene + tree to
  * HBM on `device` and allocates the persistent H*W colour buffer (zero-initialised like
  * colorBuffer, RayTracer.h:69). */
 int crt_create(const crt_scene_desc *scene, int device, crt_ctx **out);
+/* the same with explicit tuning (NULL = defaults) */
+int crt_create_tuned(const crt_scene_desc *scene, int device, const crt_tuning *tuning, crt_ctx **out);
 
 /* replaces RayTracer::setCamera() (RayTracer.cpp:57-59): position + row-major 3x3 matrix
  * (Camera.h:7-8).  The tree is not rebuilt. */

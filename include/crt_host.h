@@ -56,6 +56,8 @@ int crt_host_camera_apply(float position[3], float matrix[9], int op, const floa
 
 /* replaces RayTracer::RayTracer(Scene&) / setCamera / render / exportPPM (RayTracer.h:96-101) */
 int crt_host_tracer_create(crt_host_scene *scene, int device, crt_host_tracer **out);
+/* the same with explicit kernel tuning (crt_hip.h: crt_tuning; NULL = defaults) */
+int crt_host_tracer_create_tuned(crt_host_scene *scene, int device, const crt_tuning *tuning, crt_host_tracer **out);
 void crt_host_tracer_free(crt_host_tracer *tracer);
 int crt_host_tracer_set_camera(crt_host_tracer *tracer, const float position[3], const float matrix[9]);
 /* ppm_path may be NULL or "" (no file, RayTracer.cpp:294); out_rgb = H*W*3 floats or NULL */

@@ -12,6 +12,10 @@
 // usage: ref_render <scene.crts> <out.f32> [--depth N] [--mode NAME] [--ppm out.ppm] [--repeat K]
 //   out.f32 = H*W*3 little-endian float32, row 0 = top  (the reference's colorBuffer)
 //   prints one JSON line: {"render_s": ..., "build_s": ..., "width": W, "height": H, ...}
+// usage: ref_render --camera-ops <ops.txt> <out.txt>
+//   drives the reference's own Camera (Camera.cpp:33-70).  ops.txt: first line = position (3) and row-major matrix (9)
+//   as hexadecimal float bit patterns; every further line = "<truck|pan|tilt|roll> <3 bit patterns>", applied one after the
+//   other to the same camera.  out.txt: the 12 bit patterns of the camera after every operation, one line each.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -41,7 +45,53 @@ static RenderOptimization parseMode(const std::string &s) {
   std::exit(2);
 }
 
+static float bitsToFloat(const std::string &hex) {
+  const uint32_t u = (uint32_t)std::strtoul(hex.c_str(), nullptr, 16);
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+
+static int cameraOps(const char *opsPath, const char *outPath) {
+  std::ifstream in(opsPath);
+  std::ofstream out(outPath);
+  std::string tok;
+  float v[12];
+  for (int i = 0; i < 12; i++) {
+    if (!(in >> tok)) return 2;
+    v[i] = bitsToFloat(tok);
+  }
+  Camera camera(Vector(v[0], v[1], v[2]));
+  camera.setRotationMatrix() = Matrix<3>(std::vector<float>(v + 3, v + 12));
+  std::string op;
+  while (in >> op) {
+    float a[3];
+    for (int i = 0; i < 3; i++) {
+      if (!(in >> tok)) return 2;
+      a[i] = bitsToFloat(tok);
+    }
+    if (op == "truck") camera.truck(Vector(a[0], a[1], a[2]));
+    else if (op == "pan") camera.pan(a[0]);
+    else if (op == "tilt") camera.tilt(a[0]);
+    else if (op == "roll") camera.roll(a[0]);
+    else return 2;
+    float r[12] = {camera.getPosition()[0], camera.getPosition()[1], camera.getPosition()[2]};
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) r[3 + 3 * i + j] = camera.getRotationMatrix()[i][j];
+    char line[160];
+    int n = 0;
+    for (int i = 0; i < 12; i++) {
+      uint32_t u;
+      std::memcpy(&u, &r[i], 4);
+      n += std::snprintf(line + n, sizeof(line) - n, "%08x%c", u, i == 11 ? '\n' : ' ');
+    }
+    out << line;
+  }
+  return 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc == 4 && std::string(argv[1]) == "--camera-ops") return cameraOps(argv[2], argv[3]);
   if (argc < 3) {
     std::fprintf(stderr, "usage: %s scene.crts out.f32 [--depth N] [--mode NAME] [--ppm P] [--repeat K]\n", argv[0]);
     return 2;

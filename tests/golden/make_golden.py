@@ -45,7 +45,7 @@ def main():
         out = {"blob": np.frombuffer(blob, dtype=np.uint8), "depth": np.int32(depth), "rgb": rgb,
                "json_sha256": np.frombuffer(hashlib.sha256(sc.to_json(scene).encode()).digest(), dtype=np.uint8)}
         if ppm is not None:
-            out["ppm_gz"] = np.frombuffer(gzip.compress(ppm, 9), dtype=np.uint8)
+            out["ppm_gz"] = np.frombuffer(gzip.compress(ppm, 9, mtime=0), dtype=np.uint8)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
         print(name, rgb.shape, "depth", depth, "blob", len(blob), "bytes")
     # a partial-coverage case: bucket count 7 on a 100x60 frame leaves pixels unrendered
@@ -56,6 +56,51 @@ def main():
     np.savez_compressed(os.path.join(HERE, "coverage.npz"), blob=np.frombuffer(blob, dtype=np.uint8), depth=np.int32(1),
                         rgb=rgb)
     print("coverage", rgb.shape, "unrendered pixels:", int((rgb.sum(axis=2) == 0).sum()))
+    # texture coordinates outside [0, 1): negative ones and ones beyond 1 (Texture.cpp:38-39 casts a negative float to
+    # unsigned; :67-70 clamps the bitmap index).  The x86-64 reference wraps / clamps them in its own way, pinned here.
+    scene, depth, _ = small_case(sc, "hw12")
+    for o in scene["objects"]:
+        if "uvs" in o:
+            uv = np.asarray(o["uvs"], dtype=np.float32).copy()
+            uv[:, :2] = uv[:, :2] * np.float32(3.0) - np.float32(1.5)
+            o["uvs"] = uv
+    blob = sc.to_blob(scene)
+    rgb, _ = oa.reference_render(blob, max_depth=depth)
+    np.savez_compressed(os.path.join(HERE, "uvwrap.npz"), blob=np.frombuffer(blob, dtype=np.uint8), depth=np.int32(depth),
+                        rgb=rgb)
+    print("uvwrap", rgb.shape)
+    camera_ops()
+
+
+def camera_ops():
+    """Camera::truck / pan / tilt / roll of the REAL reference (Camera.cpp:33-70, degreesToRadians with 22/7), driven
+    through oracle/_ref/ref_render --camera-ops: a chain of operations and the camera after each one."""
+    import subprocess
+    rng = np.random.default_rng(20240607)
+    start = np.concatenate([rng.uniform(-3, 3, 3), np.eye(3).ravel()]).astype(np.float32)
+    ops = []
+    for k in range(64):
+        name = ("pan", "tilt", "roll", "truck")[k % 4] if k >= 4 else ("pan", "tilt", "roll", "truck")[k]
+        if name == "truck":
+            v = rng.uniform(-2, 2, 3).astype(np.float32)
+        else:
+            v = np.array([rng.uniform(-400, 400), 0, 0], dtype=np.float32)
+        ops.append((name, v))
+    ops += [("pan", np.array([0, 0, 0], np.float32)), ("pan", np.array([360, 0, 0], np.float32)),      # 360 deg with pi = 22/7
+            ("tilt", np.array([-90, 0, 0], np.float32)), ("roll", np.array([1e-3, 0, 0], np.float32))]  # is not a full turn
+    with tempfile.TemporaryDirectory() as td:
+        ip, op = os.path.join(td, "ops.txt"), os.path.join(td, "out.txt")
+        with open(ip, "w") as f:
+            f.write(" ".join("%08x" % u for u in start.view(np.uint32)) + "\n")
+            for name, v in ops:
+                f.write(name + " " + " ".join("%08x" % u for u in v.view(np.uint32)) + "\n")
+        subprocess.check_call([oa.REF_PLAIN, "--camera-ops", ip, op])
+        after = np.array([[int(t, 16) for t in line.split()] for line in open(op)], dtype=np.uint32)
+    assert after.shape == (len(ops), 12)
+    np.savez_compressed(os.path.join(HERE, "camera_ops.npz"), start=start,
+                        op_names=np.array([n for n, _ in ops]), op_args=np.stack([v for _, v in ops]),
+                        after=after.view(np.float32))
+    print("camera_ops", after.shape)
 
 
 if __name__ == "__main__":

@@ -5,7 +5,7 @@ import pytest
 
 from helpers import assert_same_floats, blob_to_scene, load_golden
 
-CASES = ["hw07", "hw08", "hw11", "hw14", "hw12", "coverage"]
+CASES = ["hw07", "hw08", "hw11", "hw14", "hw12", "coverage", "uvwrap"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -13,6 +13,12 @@ def test_oracle_reproduces_reference_frame(oracle, name):
     g = load_golden(name)
     got, _ = oracle.OracleScene(g["blob"]).render(g["depth"])
     assert_same_floats(got, g["rgb"], name)
+
+
+def test_uvwrap_fixture_has_coordinates_outside_the_unit_square():
+    g = load_golden("uvwrap")
+    uv = np.concatenate([np.asarray(o["uvs"])[:, :2].ravel() for o in blob_to_scene(g["blob"])["objects"] if "uvs" in o])
+    assert uv.min() <= -1.0 and uv.max() > 1.0   # negative float -> unsigned (Texture.cpp:38-39), clamped bitmap index (:67-70)
 
 
 def test_coverage_fixture_has_unrendered_pixels():

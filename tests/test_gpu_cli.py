@@ -26,3 +26,58 @@ def test_crt_main_writes_the_reference_ppm(scenes, oracle, name, tmp_path):
     ref = str(tmp_path / "ref.ppm")
     oracle.write_ppm(ref, want)
     assert open(out, "rb").read() == open(ref, "rb").read()
+
+
+def _orbit_cameras(pkg, fps, seconds, radius):
+    """The camera of every frame of app/animation.cpp:16-38, in the reference's float arithmetic (libm's sinf / cosf /
+    atan2f, `std::atan2(float, float)` being the float overload) with the pan done by the host mirror's Camera::pan,
+    which tests/test_host_layer.py pins to the reference's own Camera.cpp."""
+    import ctypes as C
+    import numpy as np
+    libm = C.CDLL("libm.so.6")
+    for fn, n in (("sinf", 1), ("cosf", 1), ("atan2f", 2)):
+        getattr(libm, fn).restype = C.c_float
+        getattr(libm, fn).argtypes = [C.c_float] * n
+    f = np.float32
+    pi = f(3.14159265358979323846)
+    deg_change = f(360.0) / f(fps * seconds)
+    degrees = f(0)
+    t = f(0)
+    while t <= fps * seconds:
+        radians = f(degrees * f(pi / f(180.0)))
+        x = f(f(libm.sinf(radians)) * f(radius))
+        z = f(f(f(libm.cosf(radians)) * f(radius)) - f(3))
+        look = f(f(libm.atan2f(f(x - f(0)), f(z + f(3)))) * f(f(180.0) / pi))
+        pos, mat = pkg.camera_apply([x, 0, z], np.eye(3, dtype=np.float32).ravel(), "pan", look)
+        yield float(t), pos, mat
+        degrees = f(degrees + deg_change)
+        t = f(t + f(1))
+
+
+def test_crt_animation_renders_the_orbit_frames(pkg, scenes, oracle, tmp_path):
+    """app/animation.cpp:24-38 end to end: one resident scene, a new camera per frame, one PPM per frame named
+    prefix + std::to_string(t) + ".ppm"; every file against the oracle's frame for that camera, byte for byte."""
+    exe = os.path.join(ROOT, "course-assignment-danielhalachev_amd", "crt_animation")
+    if not os.path.exists(exe):
+        pytest.skip("crt_animation not built")
+    scene, _, _ = small_case(scenes, "hw14")
+    (tmp_path / "scene.crtscene").write_text(scenes.to_json(scene))
+    prefix = str(tmp_path / "frame")
+    fps, seconds, radius, depth = 2, 2, 5.12, 3
+    r = subprocess.run([exe, "scene.crtscene", prefix, "--depth", str(depth), "--fps", str(fps), "--seconds", str(seconds),
+                        "--radius", repr(radius)], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    o = oracle.OracleScene(scenes.to_blob(scene))
+    frames = list(_orbit_cameras(pkg, fps, seconds, radius))
+    assert len(frames) == fps * seconds + 1
+    seen = set()
+    for t, pos, mat in frames:
+        o.set_camera(pos, mat)
+        want, _ = o.render(depth)
+        ref = str(tmp_path / "ref.ppm")
+        oracle.write_ppm(ref, want)
+        path = prefix + "%f.ppm" % t                      # std::to_string(float) prints "%f"
+        data = open(path, "rb").read()
+        assert data == open(ref, "rb").read(), path
+        seen.add(data)
+    assert len(seen) > 1                                   # the camera did move

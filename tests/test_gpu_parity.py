@@ -13,10 +13,11 @@ pytestmark = pytest.mark.gpu
 CONFIGS = ["hw07", "hw08", "hw11", "hw14", "hw12"]
 
 
-def make_tracer(pkg, scenes, scene, folder=""):
+def make_tracer(pkg, scenes, scene, folder="", tuning=None):
     if scene.get("textures") and folder:
         scenes.write_bitmaps(scene, folder)
-    return pkg.Tracer(pkg.Scene(json_text=scenes.to_json(scene), folder=folder))
+    return pkg.Tracer(pkg.Scene(json_text=scenes.to_json(scene), folder=folder),
+                      tuning=pkg.make_tuning(**tuning) if tuning else None)
 
 
 @pytest.mark.parametrize("name", CONFIGS)
@@ -35,7 +36,7 @@ def test_frame_matches_oracle(pkg, scenes, oracle, name, tmp_path):
     assert np.array_equal(q.astype(np.uint16), oracle.quantize(want))
 
 
-@pytest.mark.parametrize("name", CONFIGS + ["coverage"])
+@pytest.mark.parametrize("name", CONFIGS + ["coverage", "uvwrap"])
 def test_frame_matches_reference_fixture(pkg, scenes, name, tmp_path):
     g = load_golden(name)
     scene = blob_to_scene(g["blob"])
@@ -52,30 +53,55 @@ def test_ppm_file_matches_reference_bytes(pkg, scenes, tmp_path):
     assert open(path, "rb").read() == g["ppm"]
 
 
-@pytest.mark.parametrize("env", [
-    {"CRT_MODE": "lanes"},                                             # recursive one-ray-per-lane kernel for every pixel
-    {"CRT_MODE": "packets"},                                           # wave-per-tile packets + lanes for the deferred pixels
-    {"CRT_STEP_BUDGET": "8", "CRT_SHADOW_BUDGET": "8"},                # nearly every walk through heavy_trace
-    {"CRT_STEP_BUDGET": "0"},                                          # heavy_trace off: faithful stream kernels
-    {"CRT_HEAVY_LEVEL": "1000000"},                                    # deeper levels entirely by heavy_trace
-    {"CRT_PACKET_BUDGET": "60", "CRT_STEP_BUDGET": "64"},              # level 0 by packets, most walks abandoned to the stream
-    {"CRT_PACKET_BUDGET": "100000"},                                   # level 0 by packets, nothing abandoned
-    {"CRT_SIDE_BLOCKS": "0"},                                          # no side stream
-    {"CRT_QUAD": "7", "CRT_HEAVY_LEVEL": "0"},                         # quad-node walk in every lean kernel
-    {"CRT_QUAD": "7", "CRT_QUAD_STACK": "4", "CRT_HEAVY_LEVEL": "0"},  # ... with a stack so short that walks overflow into heavy_trace
-    {"CRT_QUAD": "0", "CRT_HEAVY_LEVEL": "0"},                         # binary lean walk (no pruning there)
-    {"CRT_PRUNE": "0"},                                                # closest-hit walks without distance pruning
-    {"CRT_STEP_BUDGET": "100000", "CRT_SHADOW_BUDGET": "100000", "CRT_HEAVY_LEVEL": "0"},  # nothing evicted: lean kernels alone
-])
+# kernel paths, selected through crt_tuning (include/crt_hip.h); mode: 1 = packets, 2 = lanes
+KERNEL_PATHS = [
+    dict(mode=2),                                                # recursive one-ray-per-lane kernel for every pixel
+    dict(mode=1),                                                # wave-per-tile packets + lanes for the deferred pixels
+    dict(step_budget=8, shadow_budget=8),                        # nearly every walk through the wave-per-ray kernels
+    dict(step_budget=0),                                         # wave-per-ray kernels off: faithful stream kernels
+    dict(heavy_level=1000000),                                   # deeper levels entirely by the wave-per-ray kernel
+    dict(packet_budget=60, step_budget=64),                      # level 0 by packets, most walks abandoned to the stream
+    dict(packet_budget=100000),                                  # level 0 by packets, nothing abandoned
+    dict(side_blocks=0),                                         # no side stream
+    dict(quad=7, heavy_level=0),                                 # quad-node walk in every lean kernel
+    dict(quad=7, quad_stack=4, heavy_level=0),                   # ... with a stack so short that walks overflow into heavy_trace
+    dict(quad=0, heavy_level=0),                                 # binary lean walk
+    dict(prune=3),                                               # closest-hit walks with distance pruning
+    dict(step_budget=100000, shadow_budget=100000, heavy_level=0),  # nothing evicted: lean kernels alone
+    dict(deep=0),                                                # one launch triple per recursion level (no persistent deep kernel)
+    dict(deep=0, heavy_level=0),                                 # ... with the per-lane kernels at every level
+    dict(deep=1, deep_blocks=3),                                 # persistent deep kernel on a tiny grid
+    dict(top_in_registers=0, tiny_meshes=0),                     # top-level tree and single-leaf meshes read from memory
+    dict(fixed0=0, bundle=64),                                   # level 0's shadow rays queued; lanes refill one by one
+]
+
+
+@pytest.mark.parametrize("tuning", KERNEL_PATHS, ids=lambda t: ",".join("%s=%s" % kv for kv in t.items()))
 @pytest.mark.parametrize("name", ["hw11", "hw12", "hw14"])
-def test_every_kernel_path_gives_the_same_frame(pkg, scenes, oracle, name, env, tmp_path, monkeypatch):
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)                          # read by crt_create
+def test_every_kernel_path_gives_the_same_frame(pkg, scenes, oracle, name, tuning, tmp_path):
     scene, depth, folder = small_case(scenes, name, tmp_path)
-    tracer = make_tracer(pkg, scenes, scene, folder)
+    tracer = make_tracer(pkg, scenes, scene, folder, tuning=tuning)
     got = tracer.render(max_depth=depth)
     want, _ = oracle.OracleScene(scenes.to_blob(scene)).render(depth)
-    assert_same_floats(got, want, "%s %r" % (name, env))
+    assert_same_floats(got, want, "%s %r" % (name, tuning))
+    assert tracer.stats().fallback_frames == 0
+
+
+@pytest.mark.parametrize("caps", [dict(ray_cap=256), dict(node_cap=1), dict(shadow_cap=1 << 14)])
+def test_queue_overflow_hands_the_frame_to_the_fallback(pkg, scenes, oracle, caps):
+    """Ray queues too small for the frame: the stream kernels raise the overflow word and stop, render_lanes redoes the
+    whole frame without queues.  Same pixels, and crt_stats says that the fallback ran."""
+    scene, depth, _ = small_case(scenes, "hw11")
+    want, _ = oracle.OracleScene(scenes.to_blob(scene)).render(depth)
+    for deep in (0, 1):
+        tracer = make_tracer(pkg, scenes, scene, tuning=dict(caps, deep=deep))
+        assert_same_floats(tracer.render(max_depth=depth), want, "overflow %r deep=%d" % (caps, deep))
+        assert tracer.stats().fallback_frames == 1
+        assert_same_floats(tracer.render(max_depth=depth), want, "overflow again %r" % (caps,))
+        assert tracer.stats().fallback_frames == 2
+    roomy = make_tracer(pkg, scenes, scene)
+    assert_same_floats(roomy.render(max_depth=depth), want, "default capacities")
+    assert roomy.stats().fallback_frames == 0
 
 
 def test_depth_rule_and_bias_options(pkg, scenes, oracle):
@@ -212,7 +238,7 @@ def test_full_size_sample_against_oracle(full_hw14, oracle, scenes):
             assert np.array_equal(buf[row, col].view(np.uint32), got[row, col].view(np.uint32)), (row, col)
 
 
-@pytest.mark.parametrize("name", ["hw08", "hw11", "hw12"])
+@pytest.mark.parametrize("name", ["hw08", "hw11", "hw12", "hw14"])
 def test_full_size_configs_against_oracle_samples_and_counting_build(pkg, scenes, oracle, name, tmp_path):
     """BASELINE.json's other configurations at their full sizes (HW12: 3840x2160 with its bitmap texture): the production
     kernels must give the counting build's frame bit for bit over the WHOLE frame, and the oracle's colour on a grid of
@@ -245,7 +271,7 @@ def _random_camera(rng, scene_radius):
 
 
 @pytest.mark.parametrize("name", ["hw11", "hw14", "hw12"])
-def test_early_exits_change_nothing_from_random_viewpoints(pkg, scenes, name, tmp_path, monkeypatch):
+def test_early_exits_change_nothing_from_random_viewpoints(pkg, scenes, name, tmp_path):
     """Distance pruning and the shadow early exit skip work the reference does; the frames must not move by a bit.
     The counting build walks every ray to the end the reference's way (and is itself checked against the oracle
     above), so it is the yardstick here, from viewpoints the fixed camera never shows."""

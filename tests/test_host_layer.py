@@ -225,6 +225,19 @@ def test_camera_helpers_follow_the_reference_formulas(pkg):
     assert np.array_equal(bits(r), bits(np.array([c, -s, 0, s, c, 0, 0, 0, 1], dtype=np.float32)))
 
 
+def test_camera_helpers_match_the_reference_camera(pkg):
+    """tests/golden/camera_ops.npz: a chain of 68 truck / pan / tilt / roll calls on the REAL reference's Camera
+    (Camera.cpp:33-70, pi = 22/7) and the camera after each; crt_host_camera_apply must reproduce every bit."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "camera_ops.npz"))
+    pos, mat = z["start"][:3].copy(), z["start"][3:].copy()
+    assert set(z["op_names"].tolist()) == {"truck", "pan", "tilt", "roll"}
+    for name, arg, want in zip(z["op_names"], z["op_args"], z["after"]):
+        pos, mat = pkg.camera_apply(pos, mat, str(name), arg)
+        got = np.concatenate([pos, mat])
+        assert np.array_equal(bits(got), bits(want)), (str(name), arg.tolist())
+
+
 def test_ppm_writer_is_byte_identical_to_the_oracle_writer(pkg, oracle, tmp_path):
     rng = np.random.RandomState(1)
     rgb = (rng.rand(37, 53, 3) * 1.3 - 0.15).astype(np.float32)

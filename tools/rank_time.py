@@ -5,7 +5,7 @@ import torch
 pkg = importlib.import_module('course-assignment-danielhalachev_amd'); sc = pkg.scenes
 tiles = importlib.import_module('course-assignment-danielhalachev_amd.tiles')
 name = sys.argv[1] if len(sys.argv) > 1 else 'hw14'
-s = sc.make(name); tr = pkg.Tracer(pkg.Scene(json_text=sc.to_json(s)))
+s = sc.make(name); tr = pkg.Tracer(pkg.Scene(json_text=sc.to_json(s)), tuning=pkg.tuning_from_string(__import__('os').environ.get('CRT_TUNING', '')))
 depth = sc.CONFIGS[name][3]
 opts = pkg.make_options(depth)
 dev = torch.device('cuda', 0)

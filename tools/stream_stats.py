@@ -1,4 +1,5 @@
-"""Dev helper: per-level ray counts / evictions of the ray-stream pass on a full-size BASELINE scene."""
+"""Dev helper: per-level ray counts / evictions of the ray-stream pass on a full-size BASELINE scene.
+CRT_TUNING="quad=0 heavy_level=0" (crt_tuning fields) selects kernels; the tool, not the library, reads it."""
 import importlib, sys, ctypes as C
 sys.path.insert(0, '.')
 pkg = importlib.import_module('course-assignment-danielhalachev_amd'); sc = pkg.scenes
@@ -6,7 +7,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else 'hw14'
 import tempfile
 s = sc.make(name); folder = tempfile.mkdtemp() + '/'
 if s.get('textures'): sc.write_bitmaps(s, folder)
-hs = pkg.Scene(json_text=sc.to_json(s), folder=folder); tr = pkg.Tracer(hs)
+hs = pkg.Scene(json_text=sc.to_json(s), folder=folder); tr = pkg.Tracer(hs, tuning=pkg.tuning_from_string(__import__('os').environ.get('CRT_TUNING', '')))
 depth = sc.CONFIGS[name][3]
 for i in range(3):
     tr.render(max_depth=depth)

@@ -1,12 +1,9 @@
-"""Dev helper: run tools/stream_stats.py under several environment settings, one child process each.
-usage: python tools/sweep.py hw14 "CRT_QUAD=1 CRT_QUAD_STACK=16" "CRT_QUAD=0" ..."""
+"""Dev helper: run tools/stream_stats.py under several crt_tuning settings, one child process each.
+usage: python tools/sweep.py hw14 "quad=1 quad_stack=16" "quad=0" "" ..."""
 import os, subprocess, sys
 scene = sys.argv[1]
 for setting in sys.argv[2:]:
-    env = dict(os.environ)
-    for kv in setting.split():
-        k, v = kv.split('=')
-        env[k] = v
+    env = dict(os.environ, CRT_TUNING=setting)
     try:
         out = subprocess.run([sys.executable, 'tools/stream_stats.py', scene], env=env, capture_output=True, text=True, timeout=90)
         lines = out.stdout.strip().splitlines()

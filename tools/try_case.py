@@ -1,4 +1,4 @@
-"""Dev helper: render one small case in the current CRT_MODE / CRT_STEP_BUDGET and compare with the oracle."""
+"""Dev helper: render one small case under CRT_TUNING (crt_tuning fields, e.g. 'mode=2') and compare with the oracle."""
 import importlib, sys, time
 import numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
@@ -7,7 +7,7 @@ from oracle import oracle_api as oa
 from helpers import small_case
 name = sys.argv[1]
 scene, depth, folder = small_case(sc, name, '/tmp')
-hs = pkg.Scene(json_text=sc.to_json(scene), folder=folder); tr = pkg.Tracer(hs)
+hs = pkg.Scene(json_text=sc.to_json(scene), folder=folder); tr = pkg.Tracer(hs, tuning=pkg.tuning_from_string(__import__('os').environ.get('CRT_TUNING', '')))
 t = time.time(); got = tr.render(max_depth=depth); print('render s', time.time() - t, flush=True)
 want, _ = oa.OracleScene(sc.to_blob(scene)).render(depth)
 print(name, 'differing floats:', int((got.view(np.uint32) != want.view(np.uint32)).sum()), 'times', tr.kernel_times_ms(1), flush=True)
