@@ -104,7 +104,7 @@ class Tuning(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "size", "mode", "step_budget", "shadow_budget", "pass1_budget", "heavy_level", "heavy_blocks", "side_blocks",
         "quad", "quad_stack", "prune", "bundle", "fixed0", "packet_budget", "path_mask", "top_in_registers",
-        "tiny_meshes", "node_cap", "ray_cap", "shadow_cap", "deep", "deep_blocks", "plan")] + [("reserved", C.c_uint32 * 5)]
+        "tiny_meshes", "node_cap", "ray_cap", "shadow_cap", "deep", "deep_blocks", "plan", "deep_waves", "tri_gather")] + [("reserved", C.c_uint32 * 3)]
 
 
 def make_tuning(**fields):
@@ -132,11 +132,14 @@ def tuning_from_string(text):
 DEVICE_SYMBOLS = ["crt_tuning_defaults", "crt_create_tuned", "crt_create", "crt_set_camera", "crt_render", "crt_render_tiles_device", "crt_packed_tile_count",
                   "crt_unpack_tiles_device", "crt_quantize_device", "crt_read_quantized", "crt_kernel_elapsed_ms", "crt_kernel_times_ms",
                   "crt_get_stats", "crt_get_kernel_counters", "crt_synchronize", "crt_destroy", "crt_last_error", "crt_device_count", "crt_test_pow5",
-                  "crt_debug_stream_counts", "crt_debug_packet_counters", "crt_get_executed_counters"]
+                  "crt_debug_stream_counts", "crt_debug_packet_counters", "crt_get_executed_counters",
+                  "crt_multi_create", "crt_multi_set_camera", "crt_multi_render", "crt_multi_read_quantized", "crt_multi_get_stats",
+                  "crt_multi_device_count", "crt_multi_context", "crt_multi_last_error", "crt_multi_destroy"]
 HOST_SYMBOLS = ["crt_host_scene_parse_file", "crt_host_scene_parse_text", "crt_host_scene_free", "crt_host_scene_desc",
                 "crt_host_scene_settings", "crt_host_scene_camera", "crt_host_scene_mesh_count",
                 "crt_host_tree_node_count", "crt_host_tree_index_total", "crt_host_tree_dump", "crt_host_mesh_sizes",
                 "crt_host_mesh_normals", "crt_host_bucket_rects", "crt_host_camera_apply", "crt_host_tracer_create", "crt_host_tracer_create_tuned",
+                "crt_host_tracer_create_multi", "crt_host_tracer_stats",
                 "crt_host_tracer_free", "crt_host_tracer_set_camera", "crt_host_tracer_render", "crt_host_tracer_ctx",
                 "crt_host_export_ppm", "crt_host_last_error"]
 
@@ -198,6 +201,8 @@ def lib():
     L.crt_host_camera_apply.argtypes = [vp, vp, i32, vp]
     L.crt_host_tracer_create.argtypes = [vp, i32, C.POINTER(vp)]
     L.crt_host_tracer_create_tuned.argtypes = [vp, i32, C.POINTER(Tuning), C.POINTER(vp)]
+    L.crt_host_tracer_create_multi.argtypes = [vp, C.POINTER(C.c_int), u32, C.POINTER(Tuning), C.POINTER(vp)]
+    L.crt_host_tracer_stats.argtypes = [vp, C.POINTER(Stats)]
     L.crt_tuning_defaults.argtypes = [C.POINTER(Tuning)]
     L.crt_tuning_defaults.restype = None
     L.crt_create_tuned.argtypes = [C.POINTER(SceneDesc), i32, C.POINTER(Tuning), C.POINTER(vp)]
@@ -327,12 +332,18 @@ def export_ppm(path, rgb):
 class Tracer:
     """crt::RayTracer on one GPU: scene + tree resident in HBM, re-renderable with a new camera."""
 
-    def __init__(self, scene: Scene, device=0, tuning: Tuning = None):
+    def __init__(self, scene: Scene, device=0, tuning: Tuning = None, devices=None):
+        """devices: a list of GPU indices -> the frame's tiles are dealt over them (crt_multi), devices[0] gathers."""
         L = lib()
         self.scene = scene
         h = C.c_void_p()
-        _host_check(L.crt_host_tracer_create_tuned(scene._h, device, C.byref(tuning) if tuning is not None else None,
-                                                   C.byref(h)))
+        tp = C.byref(tuning) if tuning is not None else None
+        if devices:
+            arr = (C.c_int * len(devices))(*devices)
+            _host_check(L.crt_host_tracer_create_multi(scene._h, arr, len(devices), tp, C.byref(h)))
+        else:
+            _host_check(L.crt_host_tracer_create_tuned(scene._h, device, tp, C.byref(h)))
+        self.devices = list(devices) if devices else [device]
         self._h = h
         self.ctx = C.c_void_p(L.crt_host_tracer_ctx(h))
         self.width, self.height = scene.width, scene.height
@@ -364,7 +375,7 @@ class Tracer:
 
     def stats(self) -> Stats:
         s = Stats()
-        lib().crt_get_stats(self.ctx, C.byref(s))
+        lib().crt_host_tracer_stats(self._h, C.byref(s))
         return s
 
     def executed_counters(self):
@@ -414,6 +425,14 @@ class Tracer:
         n = C.c_uint32()
         self._check(lib().crt_kernel_times_ms(self.ctx, a, max_count, C.byref(n)))
         return [tuple(a[5 * i + j] for j in range(5)) for i in range(n.value)]
+
+    def stream_counts(self):
+        """Diagnostics: the ray-stream pass's counter block of the last frame (SC_* layout of csrc/kernel_stream.h)."""
+        out = (C.c_uint32 * 512)()
+        L = lib()
+        L.crt_debug_stream_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]
+        self._check(L.crt_debug_stream_counts(self.ctx, out, 512))
+        return np.array(out[:], dtype=np.uint32)
 
     def read_quantized(self):
         out = np.zeros((self.height, self.width, 3), dtype=np.uint8)

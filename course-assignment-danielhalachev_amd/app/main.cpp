@@ -5,7 +5,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <vector>
 
 #include "../host/RayTracer.h"
 #include "../host/SceneParser.h"
@@ -13,25 +15,39 @@
 int main(int argc, char **argv) {
   if (argc < 3) {
     std::fprintf(stderr,
-                 "usage: %s scene.crtscene out.ppm [--folder DIR] [--depth N] [--mode 0..9] [--device D] [--repeat K]\n",
+                 "usage: %s scene.crtscene out.ppm [--folder DIR] [--depth N] [--mode 0..9] [--device D | --devices 0-7 | --devices 0,2,5] [--repeat K]\n",
                  argv[0]);
     return 2;
   }
   std::string scenePath = argv[1], outPath = argv[2], folder;
   unsigned depth = 5;
   int mode = crt::BVHBucketsThreadPool, device = 0, repeat = 1;
+  std::vector<int> devices;  // --devices: the frame's tiles over several GPUs (first one gathers)
   for (int i = 3; i < argc; i++) {
     if (!strcmp(argv[i], "--folder") && i + 1 < argc) folder = argv[++i];
     else if (!strcmp(argv[i], "--depth") && i + 1 < argc) depth = (unsigned)atoi(argv[++i]);
     else if (!strcmp(argv[i], "--mode") && i + 1 < argc) mode = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--devices") && i + 1 < argc) {
+      const char *p = argv[++i];
+      while (*p) {
+        char *end = nullptr;
+        long a = strtol(p, &end, 10), b = a;
+        if (end == p) break;
+        if (*end == '-') { p = end + 1; b = strtol(p, &end, 10); if (end == p) break; }
+        for (long d = a; d <= b && devices.size() < 64; d++) devices.push_back((int)d);
+        p = (*end == ',') ? end + 1 : end;
+        if (*end && *end != ',') break;
+      }
+    }
     else if (!strcmp(argv[i], "--repeat") && i + 1 < argc) repeat = atoi(argv[++i]);
   }
   try {
     crt::SceneParser parser;
     crt::Scene scene = parser.parseScene(scenePath, folder);
     auto t0 = std::chrono::high_resolution_clock::now();
-    crt::RayTracer tracer(scene, device);
+    std::unique_ptr<crt::RayTracer> tracerPtr(devices.size() > 0 ? new crt::RayTracer(scene, devices) : new crt::RayTracer(scene, device));
+    crt::RayTracer &tracer = *tracerPtr;
     auto t1 = std::chrono::high_resolution_clock::now();
     crt::RenderOptions options((crt::RenderOptimization)mode, depth, false);
     double best = 1e30;

@@ -31,9 +31,13 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <new>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/crt_hip.h"
@@ -47,6 +51,7 @@ namespace {
 #include "kernel_stream.h"
 #include "kernel_heavy.h"
 #include "kernel_plan.h"
+#include "kernel_deep.h"
 
 // scatter gathered packed tiles into the row-major frame
 __global__ void unpack_kernel(const float *packed, uint32_t n_parts, uint64_t part_stride, float *frame, uint32_t width,
@@ -58,6 +63,20 @@ __global__ void unpack_kernel(const float *packed, uint32_t n_parts, uint64_t pa
     if (px >= width || py >= height) return;
     const uint32_t part = tile % n_parts, local = tile / n_parts;
     const float *src = packed + (uint64_t)part * part_stride + ((uint64_t)local * 64 + sub) * 3;
+    float *dst = frame + ((uint64_t)py * width + px) * 3;
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+}
+
+// crt_multi: scatter the parts' packed tiles into the frame; item j = {tile, slot in `packed`, mask of its rendered pixels}
+__global__ void unpack_items_kernel(const float *packed, const WorkItem *items, uint32_t n_items, float *frame, uint32_t width,
+                                    uint32_t height, uint32_t tiles_x) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (item, pixel)
+    if (gid >= (uint64_t)n_items * 64) return;
+    const WorkItem wi = items[gid >> 6];
+    const uint32_t sub = (uint32_t)(gid & 63);
+    const uint32_t px = (wi.tile % tiles_x) * TILE + (sub & 7u), py = (wi.tile / tiles_x) * TILE + (sub >> 3);
+    if (!((wi.mask >> sub) & 1ull) || px >= width || py >= height) return;
+    const float *src = packed + ((uint64_t)wi.out_tile * 64 + sub) * 3;
     float *dst = frame + ((uint64_t)py * width + px) * 3;
     dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
 }
@@ -121,6 +140,8 @@ struct crt_ctx {
     hipStream_t side = nullptr;       // shadow pass 0 overlaps the deeper recursion levels on this stream
     hipEvent_t ev_fork[EV_RING] = {}, ev_s0[EV_RING] = {}, ev_s1[EV_RING] = {}, ev_s2[EV_RING] = {}, ev4[EV_RING] = {};
     float4 *d_hits = nullptr;         // their closest hits
+    uint32_t *d_ready = nullptr;      // kernel_deep.h: publication flags of the deep queue's slots
+    uint32_t epoch = 0;               // frames launched (the deep queue's tag)
     uint32_t heavy_cap = 0;
     uint32_t step_budget = 256;       // CRT_STEP_BUDGET: closest-hit walks are evicted to heavy_trace after this many steps (0 = never)
     uint32_t shadow_budget = 4096;    // CRT_SHADOW_BUDGET: same for shadow walks (one big launch: only its tail matters)
@@ -353,8 +374,10 @@ extern "C" void crt_tuning_defaults(crt_tuning *t) {
     t->quad = 1; t->quad_stack = 16; t->prune = 0; t->bundle = 16; t->fixed0 = 1;
     t->packet_budget = 0; t->path_mask = 0; t->top_in_registers = 1; t->tiny_meshes = 1;
     t->node_cap = t->ray_cap = t->shadow_cap = 0;
-    t->deep = 1; t->deep_blocks = 0;
+    t->deep = 0; t->deep_blocks = 0;
     t->plan = 1;
+    t->deep_waves = 5;
+    t->tri_gather = 0;
 }
 
 extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) { return crt_create_tuned(s, device, nullptr, out); }
@@ -444,6 +467,49 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
             lt[4 * e + 3] = make_float4(T.plane, idbits, lastbits, 0.0f);
         }
         if (upload(ctx, lt.data(), lt.size(), &A.ltris)) return fail(CRT_ERR_HIP);
+    }
+    // Compact forms for the plan kernels (kernel_plan.h), whose cost is the number of vector-memory instructions per step:
+    // a triangle as 3 x float4 {v0,nx} {v1,ny} {v2,nz} (the plane offset is recomputed, -(v0 . n) as on the host, Ray.cpp:17;
+    // the triangle's id is looked up in leaf_tris only for a hit) and a leaf node's link as LEAF | (count - 1) << 24 | first
+    // entry, so that a walk knows where its leaf ends without the record's `last` flag.
+    std::vector<uint32_t> compact_link(s->n_nodes);
+    {
+        bool ok = s->n_leaf_triangles < (1ull << 24);
+        std::vector<float4> pn((size_t)s->n_nodes * 2);
+        for (uint32_t i = 0; i < s->n_nodes; i++) {
+            const crt_node &n = s->nodes[i];
+            uint32_t link = n.link;
+            if (is_leaf_link(n.link)) {
+                const uint64_t begin = n.link & ~CRT_LINK_LEAF;
+                uint64_t count = 0;
+                if (begin < s->n_leaf_triangles) {  // (a top-level leaf's link indexes leaf_meshes: whatever this gives is not used)
+                    uint64_t e = begin;
+                    do { count++; } while (!(s->leaf_triangles[e++] & CRT_ENTRY_LAST) && e < s->n_leaf_triangles);
+                }
+                if (count >= 1 && count <= 128 && begin < (1ull << 24)) link = CRT_LINK_LEAF | (uint32_t)((count - 1) << 24) | (uint32_t)begin;
+                else if (begin < s->n_leaf_triangles) ok = false;
+            }
+            compact_link[i] = link;
+            float lb, mb;
+            memcpy(&lb, &link, 4);
+            memcpy(&mb, &n.miss, 4);
+            pn[2 * (size_t)i] = make_float4(n.lo[0], n.lo[1], n.lo[2], mb);
+            pn[2 * (size_t)i + 1] = make_float4(n.hi[0], n.hi[1], n.hi[2], lb);
+        }
+        std::vector<float4> pt(ok ? (size_t)s->n_leaf_triangles * 3 : 0);
+        for (uint64_t e = 0; ok && e < s->n_leaf_triangles; e++) {
+            const crt_triangle &T = s->triangles[s->leaf_triangles[e] & ~CRT_ENTRY_LAST];
+            pt[3 * e + 0] = make_float4(T.v0[0], T.v0[1], T.v0[2], T.nx);
+            pt[3 * e + 1] = make_float4(T.v1[0], T.v1[1], T.v1[2], T.ny);
+            pt[3 * e + 2] = make_float4(T.v2[0], T.v2[1], T.v2[2], T.nz);
+            // the kernels recompute the plane offset: it must be the stored one, bit for bit, or this form is not used
+            const float plane = -(T.v0[0] * T.nx + T.v0[1] * T.ny + T.v0[2] * T.nz);
+            if (memcmp(&plane, &T.plane, 4) != 0) ok = false;
+        }
+        if (!ok) { pt.clear(); pn.clear(); }
+        A.plan_compact = ok ? 1u : 0u;
+        if (upload(ctx, pt.data(), pt.size(), &A.ptris)) return fail(CRT_ERR_HIP);
+        if (upload(ctx, pn.data(), pn.size(), &A.pnodes)) return fail(CRT_ERR_HIP);
     }
     std::vector<HeavyMesh> hmesh_host;  // filled with the leaf sequences below, read again for the single-leaf mesh table
     // loose boxes (see triangle_loose_box) of every mesh-tree node: a leaf's = union over its triangles, an inner
@@ -589,6 +655,7 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
             const crt_scene_desc *s;
             std::vector<float4> &quads;
             const std::vector<float> &loose_lo, &loose_hi;
+            const std::vector<uint32_t> &compact_link;
             void children(uint32_t i, std::vector<uint32_t> &out) const {
                 const crt_node &n = s->nodes[i];
                 if (is_leaf_link(n.link) || n.link == CRT_LINK_END) return;
@@ -623,7 +690,7 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
                 const uint32_t q = (uint32_t)(quads.size() / 16);
                 quads.resize(quads.size() + 16, make_float4(0, 0, 0, 0));
                 float box[6][4], lbox[6][4];
-                uint32_t link[4] = {NONE, NONE, NONE, NONE};
+                uint32_t link[4] = {NONE, NONE, NONE, NONE}, clink[4] = {NONE, NONE, NONE, NONE};
                 for (int k = 0; k < 4; k++) for (int a = 0; a < 6; a++) { box[a][k] = 0.0f; lbox[a][k] = 0.0f; }
                 for (size_t k = 0; k < slots.size(); k++) {
                     const crt_node &n = s->nodes[slots[k]];
@@ -633,10 +700,12 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
                     }
                     if (is_leaf_link(n.link)) {
                         link[k] = n.link;  // LEAF + first entry
+                        clink[k] = compact_link[slots[k]];  // ... and with the leaf's length (plan kernels)
                     } else {
                         std::vector<uint32_t> kids;
                         children(slots[k], kids);
                         link[k] = build(kids, depth + 1);
+                        clink[k] = link[k];
                     }
                 }
                 for (int a = 0; a < 6; a++) quads[(size_t)q * 16 + a] = make_float4(box[a][0], box[a][1], box[a][2], box[a][3]);
@@ -644,9 +713,11 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
                 float lb[4];
                 memcpy(lb, link, 16);
                 quads[(size_t)q * 16 + 6] = make_float4(lb[0], lb[1], lb[2], lb[3]);
+                memcpy(lb, clink, 16);
+                quads[(size_t)q * 16 + 7] = make_float4(lb[0], lb[1], lb[2], lb[3]);
                 return q;
             }
-        } builder{s, quads, nloose_lo, nloose_hi};
+        } builder{s, quads, nloose_lo, nloose_hi, compact_link};
         for (uint32_t m = 0; m < s->n_meshes; m++) qroots[m] = builder.build(std::vector<uint32_t>{s->meshes[m].root});
         ctx->n_quads = (uint32_t)(quads.size() / 16);
         if (builder.too_deep || quads.size() / 16 >= (1u << 24)) ctx->use_quads = 0;
@@ -766,7 +837,7 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
             masks.push_back(make_uint2(mlo, mhi));
         }
         if (masks.size() > 64) ok = false;
-        A.plan_ok = (ok && tune.plan) ? 1u : 0u;
+        A.plan_ok = (ok && tune.plan && A.plan_compact) ? 1u : 0u;
         A.plan_leaves = (uint32_t)masks.size();
         A.plan_shadow_bits = (uint32_t)order.size();
         A.plan_list_words = (s->n_meshes + 3u) / 4u;
@@ -838,6 +909,7 @@ extern "C" void crt_destroy(crt_ctx *ctx) {
     if (ctx->d_todo_tiles) (void)hipFree(ctx->d_todo_tiles);
     if (ctx->d_todo_shadow) (void)hipFree(ctx->d_todo_shadow);
     if (ctx->d_hits) (void)hipFree(ctx->d_hits);
+    if (ctx->d_ready) (void)hipFree(ctx->d_ready);
     if (ctx->h_overflow) (void)hipHostFree(ctx->h_overflow);
     if (ctx->d_fallback_total) (void)hipFree(ctx->d_fallback_total);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
@@ -935,6 +1007,10 @@ static int ensure_stream(crt_ctx *ctx, uint32_t n_items) {
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_shadowq, shadow_cap * 2 * sizeof(float4)));
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_occluded, shadow_cap));
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_nodes, node_cap * 2 * sizeof(float4)));
+        if (ctx->d_ready) (void)hipFree(ctx->d_ready);
+        ctx->d_ready = nullptr;
+        CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_ready, ray_cap * sizeof(uint32_t)));
+        CRT_HIP_CHECK(ctx, hipMemset(ctx->d_ready, 0, ray_cap * sizeof(uint32_t)));  // no epoch is 0
         if (ctx->d_heavy) (void)hipFree(ctx->d_heavy);
         if (ctx->d_sheavy) (void)hipFree(ctx->d_sheavy);
         if (ctx->d_hits) (void)hipFree(ctx->d_hits);
@@ -954,6 +1030,7 @@ static int ensure_stream(crt_ctx *ctx, uint32_t n_items) {
     A.s_shadowq = ctx->d_shadowq; A.s_occluded = ctx->d_occluded; A.s_nodes = ctx->d_nodes;
     A.s_heavy = ctx->d_heavy; A.s_sheavy = ctx->d_sheavy; A.s_hits = ctx->d_hits; A.s_heavy_cap = ctx->heavy_cap;
     A.s_todo_tiles = ctx->d_todo_tiles; A.s_todo_shadow = ctx->d_todo_shadow;
+    A.s_ready = ctx->d_ready;
     return CRT_OK;
 }
 
@@ -1006,7 +1083,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
     if (ctx->mode == crt_ctx::MODE_STREAM) {
         rc = ensure_stream(ctx, n_items);
         if (rc) return rc;
-        CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_scounts, 0, SC_WORDS * sizeof(uint32_t), stream));
+        CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_scounts, 0, SC_ALLOC_WORDS * sizeof(uint32_t), stream));
         // 1) closest-hit walks + material dispatch, one launch per recursion level
         // the wave-per-ray path needs nested boxes; the counting build walks every ray the reference's way
         const bool heavy = ctx->step_budget && A.nested_boxes && !count;
@@ -1020,7 +1097,8 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         A.exec_count = exec_count ? 1u : 0u;
         A.exec_counters = ctx->d_exec;
         if (exec_count) CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_exec, 0, 4 * sizeof(unsigned long long), stream));
-        A.bundle = 64;
+        // the plan kernels (kernel_plan.h) pay a wave-uniform loop per refill, whatever the number of new rays: refill in bundles
+        A.bundle = (A.plan_ok && ctx->bundle < 64u) ? ctx->bundle : 64u;
         A.fixed0 = 0;
         if (ctx->fixed0) {  // level 0 owns the first n_items * 64 * n_lights slots of the shadow queue; the deeper levels append
             const uint64_t n0 = (uint64_t)n_items * 64u * ctx->n_lights;
@@ -1040,6 +1118,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
             launch(stream_packets_gen0, need < ctx->grid_blocks ? need : ctx->grid_blocks, stream, A);
             hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, stream, A, (uint32_t)SC_SHADOW_SPLIT, (uint32_t)SC_SHADOW);
         }
+        A.tri_gather = ctx->tuning.tri_gather > 64u ? 64u : ctx->tuning.tri_gather;
         KernelArgs S = A;  // argument block of the shadow passes
         S.counters = ctx->d_counters + C_N;
         S.bundle = ctx->bundle;
@@ -1058,7 +1137,11 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         // the same reasoning for level 0 (one launch over all primary rays, ~70 steps per ray)
         const uint64_t est0 = (uint64_t)n_items * 64u * 70u / ((uint64_t)lane_blocks * BLOCK);
         const uint32_t budget0 = est0 >= ctx->step_budget ? ctx->step_budget : (est0 < 64u ? 64u : (uint32_t)est0);
-        for (uint32_t g = 0; g <= o->max_depth; g++) {
+        // the recursion levels >= 1: one persistent queue-driven launch (kernel_deep.h), or a launch triple per level
+        const bool deep = heavy && ctx->tuning.deep && o->max_depth >= 1;
+        ctx->epoch = ctx->epoch == 0xFFFFFFFFu ? 1u : ctx->epoch + 1u;
+        A.epoch = ctx->epoch;
+        for (uint32_t g = 0; g <= (deep ? 0u : o->max_depth); g++) {
             A.step_budget = heavy ? (g == 0 ? budget0 : ctx->step_budget) : 0u;
             if (count) launch(stream_trace_shade<true>, lane_blocks, stream, A, g);
             else if (lean && A.plan_ok && (quad & 1u)) launch_lds(stream_trace_shade_plan<true>, lane_blocks, qlds + plds, stream, A, g);
@@ -1091,6 +1174,13 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
                 CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s2[slot], ctx->side));
             }
         }
+        if (deep) {
+            A.step_budget = ctx->step_budget;
+            hipLaunchKernelGGL(deep_begin, dim3(1), dim3(64), 0, stream, A);
+            const uint32_t deep_blocks = ctx->tuning.deep_blocks ? ctx->tuning.deep_blocks : (uint32_t)ctx->num_cus * 4u;
+            if (ctx->tuning.deep_waves == 4u) launch(deep_trace<4>, deep_blocks, stream, A);
+            else launch(deep_trace<5>, deep_blocks, stream, A);
+        }
         CRT_HIP_CHECK(ctx, hipGetLastError());
         if (timed) CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev1[slot], stream));
         if (!ctx->side_blocks_per_cu) {  // no overlap: pass 0 here, on the caller's stream
@@ -1105,7 +1195,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         // 2b) the shadow rays of the deeper levels, then the evicted shadow walks of both passes
         CRT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_s1[slot], 0));
         S.counters = ctx->d_counters + 2 * C_N;
-        S.bundle = 64;
+        S.bundle = A.bundle;
         S.exec_counters = ctx->d_exec;
         {
             // few rays, all tail: the short budget of the levels, or less when this launch is small (the deeper levels
@@ -1189,6 +1279,36 @@ static int fetch_counters(crt_ctx *ctx, const crt_options *o, uint64_t pixels) {
     return CRT_OK;
 }
 
+// The pixels a set of rectangles covers -- clamped to the image like renderRectangle does (RayTracer.cpp:84-85), overlaps
+// merged -- as work items: one per 8x8 tile that has any covered pixel, with the mask of those pixels.  Returns the count
+// of covered pixels.  out_tile = the tile itself; callers that pack their output renumber it.
+static uint64_t coverage_items(uint32_t width, uint32_t height, const crt_rect *rects, uint32_t n_rects, std::vector<WorkItem> &items) {
+    const uint32_t tx = (width + TILE - 1) / TILE, ty = (height + TILE - 1) / TILE;
+    std::vector<uint64_t> masks((size_t)tx * ty, 0);
+    for (uint32_t r = 0; r < n_rects; r++) {
+        uint64_t row_lim = (uint64_t)rects[r].row + rects[r].height, col_lim = (uint64_t)rects[r].col + rects[r].width;
+        if (row_lim > height) row_lim = height;
+        if (col_lim > width) col_lim = width;
+        for (uint64_t row = rects[r].row; row < row_lim; row++) {
+            for (uint64_t col = rects[r].col; col < col_lim;) {
+                uint64_t tcol = col / TILE, cend = (tcol + 1) * TILE;
+                if (cend > col_lim) cend = col_lim;
+                uint64_t bits = ((cend - col) >= 64 ? ~0ull : ((1ull << (cend - col)) - 1ull)) << ((row % TILE) * TILE + (col % TILE));
+                masks[(row / TILE) * tx + tcol] |= bits;
+                col = cend;
+            }
+        }
+    }
+    items.clear();
+    uint64_t pixels = 0;
+    for (uint32_t t = 0; t < tx * ty; t++)
+        if (masks[t]) {
+            items.push_back(WorkItem{t, t, masks[t]});
+            pixels += (uint64_t)__builtin_popcountll(masks[t]);
+        }
+    return pixels;
+}
+
 extern "C" int crt_render(crt_ctx *ctx, const crt_options *o, const crt_rect *rects, uint32_t n_rects, float *out_rgb) {
     if (!ctx) return CRT_ERR_INVALID;
     int rc = check_options(ctx, o);
@@ -1199,29 +1319,8 @@ extern "C" int crt_render(crt_ctx *ctx, const crt_options *o, const crt_rect *re
     bool same = !ctx->cached_is_partition && ctx->cached_rects.size() == n_rects && n_rects > 0 &&
                 memcmp(ctx->cached_rects.data(), rects, n_rects * sizeof(crt_rect)) == 0;
     if (!same) {
-        const uint32_t tx = ctx->tiles_x, ty = ctx->tiles_y;
-        std::vector<uint64_t> masks((size_t)tx * ty, 0);
-        for (uint32_t r = 0; r < n_rects; r++) {
-            uint64_t row_lim = (uint64_t)rects[r].row + rects[r].height, col_lim = (uint64_t)rects[r].col + rects[r].width;
-            if (row_lim > ctx->height) row_lim = ctx->height;
-            if (col_lim > ctx->width) col_lim = ctx->width;
-            for (uint64_t row = rects[r].row; row < row_lim; row++) {
-                for (uint64_t col = rects[r].col; col < col_lim;) {
-                    uint64_t tcol = col / TILE, cend = (tcol + 1) * TILE;
-                    if (cend > col_lim) cend = col_lim;
-                    uint64_t bits = ((cend - col) >= 64 ? ~0ull : ((1ull << (cend - col)) - 1ull)) << ((row % TILE) * TILE + (col % TILE));
-                    masks[(row / TILE) * tx + tcol] |= bits;
-                    col = cend;
-                }
-            }
-        }
         std::vector<WorkItem> items;
-        uint64_t pixels = 0;
-        for (uint32_t t = 0; t < tx * ty; t++)
-            if (masks[t]) {
-                items.push_back(WorkItem{t, t, masks[t]});
-                pixels += (uint64_t)__builtin_popcountll(masks[t]);
-            }
+        const uint64_t pixels = coverage_items(ctx->width, ctx->height, rects, n_rects, items);
         rc = ensure_items(ctx, items.size() ? items.size() : 1);
         if (rc) return rc;
         if (!items.empty())
@@ -1423,4 +1522,277 @@ extern "C" int crt_synchronize(crt_ctx *ctx) {
     CRT_HIP_CHECK(ctx, hipDeviceSynchronize());
     note_overflow(ctx);
     return CRT_OK;
+}
+
+// =================================================================================================
+// crt_multi: one scene on several devices of a node, behind the same render call (SURVEY.md section 8b "multi-GPU handled
+// inside the context", section 8e).  One context, one host thread and one stream per device; the covered 8x8 tiles are
+// dealt round-robin over the devices; every device renders its tiles packed and copies them to device[0] over xGMI
+// (hipMemcpyPeerAsync: point-to-point, no collective is needed inside one process); device[0] scatters them into its
+// persistent colour buffer.  The same device may be listed more than once (several contexts on one GPU).
+struct crt_multi {
+    std::vector<crt_ctx *> ctx;
+    std::vector<int> devices;
+    std::vector<float *> d_packed;        // part p's packed tiles on its own device (part 0: inside d_staging)
+    float *d_staging = nullptr;           // device[0]: every part's packed tiles, part after part
+    size_t staging_tiles = 0;
+    WorkItem *d_all_items = nullptr;      // device[0]: every covered tile {tile, slot in d_staging, mask}
+    size_t all_items_cap = 0;
+    std::vector<std::vector<WorkItem>> part_items;
+    std::vector<uint32_t> slot_base;      // first slot of part p in d_staging
+    std::vector<hipEvent_t> done;         // part p's tiles have arrived on device[0]
+    std::vector<crt_rect> cached_rects;
+    uint32_t n_all_items = 0;
+    uint64_t pixels = 0;
+    std::string error;
+    crt_stats stats{};
+    // one worker thread per device: launching a frame is ~35 kernel launches per device, issued in parallel
+    struct Worker {
+        std::thread th;
+        std::mutex m;
+        std::condition_variable cv;
+        bool go = false, quit = false, finished = false;
+        int rc = CRT_OK;
+    };
+    std::vector<Worker *> workers;
+    const crt_options *job_options = nullptr;
+};
+
+static int multi_part_launch(crt_multi *M, uint32_t p) {
+    crt_ctx *ctx = M->ctx[p];
+    if (hipSetDevice(ctx->device) != hipSuccess) { ctx->error = "hipSetDevice failed"; return CRT_ERR_HIP; }
+    const uint32_t n = (uint32_t)M->part_items[p].size();
+    int rc = launch_render(ctx, M->job_options, n, M->d_packed[p], 1, ctx->stream, true);
+    if (rc) return rc;
+    if (p != 0 && n)  // part 0 renders straight into the staging buffer
+        CRT_HIP_CHECK(ctx, hipMemcpyPeerAsync(M->d_staging + (size_t)M->slot_base[p] * 192, M->devices[0], M->d_packed[p],
+                                              M->devices[p], (size_t)n * 192 * sizeof(float), ctx->stream));
+    CRT_HIP_CHECK(ctx, hipEventRecord(M->done[p], ctx->stream));
+    return CRT_OK;
+}
+
+static void multi_worker(crt_multi *M, uint32_t p) {
+    crt_multi::Worker *W = M->workers[p];
+    for (;;) {
+        std::unique_lock<std::mutex> lock(W->m);
+        W->cv.wait(lock, [&] { return W->go || W->quit; });
+        if (W->quit) return;
+        W->go = false;
+        lock.unlock();
+        const int rc = multi_part_launch(M, p);
+        lock.lock();
+        W->rc = rc;
+        W->finished = true;
+        W->cv.notify_all();
+    }
+}
+
+extern "C" void crt_multi_destroy(crt_multi *M) {
+    if (!M) return;
+    for (crt_multi::Worker *W : M->workers) {
+        if (!W) continue;
+        { std::lock_guard<std::mutex> lock(W->m); W->quit = true; }
+        W->cv.notify_all();
+        if (W->th.joinable()) W->th.join();
+        delete W;
+    }
+    for (size_t p = 0; p < M->ctx.size(); p++) {
+        if (!M->ctx[p]) continue;
+        (void)hipSetDevice(M->devices[p]);
+        if (p < M->done.size() && M->done[p]) (void)hipEventDestroy(M->done[p]);
+        if (p != 0 && p < M->d_packed.size() && M->d_packed[p]) (void)hipFree(M->d_packed[p]);
+    }
+    if (!M->devices.empty()) {
+        (void)hipSetDevice(M->devices[0]);
+        if (M->d_staging) (void)hipFree(M->d_staging);
+        if (M->d_all_items) (void)hipFree(M->d_all_items);
+    }
+    for (crt_ctx *c : M->ctx) crt_destroy(c);
+    delete M;
+}
+
+extern "C" int crt_multi_create(const crt_scene_desc *scene, const int *devices, uint32_t n_devices, const crt_tuning *tuning,
+                                crt_multi **out) {
+    if (!out) return CRT_ERR_INVALID;
+    *out = nullptr;
+    if (!devices || n_devices == 0 || n_devices > 64) { g_create_error = "crt_multi_create: 1..64 devices"; return CRT_ERR_INVALID; }
+    crt_multi *M = new (std::nothrow) crt_multi();
+    if (!M) return CRT_ERR_NOMEM;
+    M->devices.assign(devices, devices + n_devices);
+    M->ctx.assign(n_devices, nullptr);
+    M->d_packed.assign(n_devices, nullptr);
+    M->done.assign(n_devices, nullptr);
+    M->part_items.resize(n_devices);
+    M->slot_base.assign(n_devices, 0);
+    for (uint32_t p = 0; p < n_devices; p++) {
+        int rc = crt_create_tuned(scene, devices[p], tuning, &M->ctx[p]);
+        if (rc != CRT_OK) { crt_multi_destroy(M); return rc; }
+        if (hipSetDevice(devices[p]) != hipSuccess || hipEventCreateWithFlags(&M->done[p], hipEventDisableTiming) != hipSuccess) {
+            g_create_error = "crt_multi_create: event creation failed";
+            crt_multi_destroy(M);
+            return CRT_ERR_HIP;
+        }
+        // direct xGMI stores to device[0] where the platform allows them (otherwise the copy is staged by the runtime)
+        if (devices[p] != devices[0]) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[p], devices[0]) == hipSuccess && can) {
+                hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                else (void)hipGetLastError();
+            }
+        }
+    }
+    M->workers.assign(n_devices, nullptr);
+    for (uint32_t p = 0; p < n_devices; p++) {
+        M->workers[p] = new crt_multi::Worker();
+        M->workers[p]->th = std::thread(multi_worker, M, p);
+    }
+    *out = M;
+    return CRT_OK;
+}
+
+extern "C" const char *crt_multi_last_error(const crt_multi *M) { return M ? M->error.c_str() : g_create_error.c_str(); }
+extern "C" uint32_t crt_multi_device_count(const crt_multi *M) { return M ? (uint32_t)M->ctx.size() : 0u; }
+extern "C" crt_ctx *crt_multi_context(crt_multi *M, uint32_t part) { return (M && part < M->ctx.size()) ? M->ctx[part] : nullptr; }
+
+extern "C" int crt_multi_set_camera(crt_multi *M, const float position[3], const float matrix[9]) {
+    if (!M) return CRT_ERR_INVALID;
+    for (crt_ctx *c : M->ctx) {
+        int rc = crt_set_camera(c, position, matrix);
+        if (rc) return rc;
+    }
+    return CRT_OK;
+}
+
+extern "C" int crt_multi_render(crt_multi *M, const crt_options *o, const crt_rect *rects, uint32_t n_rects, float *out_rgb) {
+    if (!M) return CRT_ERR_INVALID;
+    crt_ctx *c0 = M->ctx[0];
+    auto fail = [&](crt_ctx *c, int rc) { M->error = c->error; return rc; };
+    int rc = check_options(c0, o);
+    if (rc) return fail(c0, rc);
+    if (n_rects && !rects) { M->error = "rects is NULL"; return CRT_ERR_INVALID; }
+    const uint32_t N = (uint32_t)M->ctx.size();
+    const bool same = M->cached_rects.size() == n_rects && n_rects > 0 &&
+                      memcmp(M->cached_rects.data(), rects, n_rects * sizeof(crt_rect)) == 0;
+    if (!same) {
+        // the covered tiles, dealt round-robin: neighbouring tiles cost about the same, so every device gets every kind
+        std::vector<WorkItem> items;
+        M->pixels = coverage_items(c0->width, c0->height, rects, n_rects, items);
+        for (uint32_t p = 0; p < N; p++) M->part_items[p].clear();
+        for (size_t j = 0; j < items.size(); j++) {
+            std::vector<WorkItem> &part = M->part_items[j % N];
+            part.push_back(WorkItem{items[j].tile, (uint32_t)part.size(), items[j].mask});
+        }
+        std::vector<WorkItem> all;
+        uint32_t slot = 0;
+        for (uint32_t p = 0; p < N; p++) {
+            M->slot_base[p] = slot;
+            for (const WorkItem &w : M->part_items[p]) all.push_back(WorkItem{w.tile, slot + w.out_tile, w.mask});
+            slot += (uint32_t)M->part_items[p].size();
+        }
+        M->n_all_items = (uint32_t)all.size();
+        CRT_HIP_CHECK(c0, hipSetDevice(M->devices[0]));
+        if (all.size() > M->all_items_cap) {
+            if (M->d_all_items) (void)hipFree(M->d_all_items);
+            M->d_all_items = nullptr;
+            M->all_items_cap = 0;
+            if (hipMalloc((void **)&M->d_all_items, all.size() * sizeof(WorkItem)) != hipSuccess) { M->error = "out of device memory"; return CRT_ERR_NOMEM; }
+            M->all_items_cap = all.size();
+        }
+        if (all.size() > M->staging_tiles) {
+            if (M->d_staging) (void)hipFree(M->d_staging);
+            M->d_staging = nullptr;
+            M->staging_tiles = 0;
+            if (hipMalloc((void **)&M->d_staging, all.size() * 192 * sizeof(float)) != hipSuccess) { M->error = "out of device memory"; return CRT_ERR_NOMEM; }
+            M->staging_tiles = all.size();
+        }
+        if (!all.empty()) CRT_HIP_CHECK(c0, hipMemcpy(M->d_all_items, all.data(), all.size() * sizeof(WorkItem), hipMemcpyHostToDevice));
+        for (uint32_t p = 0; p < N; p++) {
+            crt_ctx *c = M->ctx[p];
+            const std::vector<WorkItem> &part = M->part_items[p];
+            if (hipSetDevice(M->devices[p]) != hipSuccess) { M->error = "hipSetDevice failed"; return CRT_ERR_HIP; }
+            rc = ensure_items(c, part.size() ? part.size() : 1);
+            if (rc) return fail(c, rc);
+            if (!part.empty() && hipMemcpy(c->d_items, part.data(), part.size() * sizeof(WorkItem), hipMemcpyHostToDevice) != hipSuccess) {
+                M->error = "item upload failed";
+                return CRT_ERR_HIP;
+            }
+            c->cached_rects.clear();  // the context's own crt_render cache no longer describes d_items
+            c->cached_is_partition = false;
+            if (p != 0) {
+                if (M->d_packed[p]) (void)hipFree(M->d_packed[p]);
+                M->d_packed[p] = nullptr;
+                if (hipMalloc((void **)&M->d_packed[p], (part.size() ? part.size() : 1) * 192 * sizeof(float)) != hipSuccess) { M->error = "out of device memory"; return CRT_ERR_NOMEM; }
+            }
+        }
+        M->cached_rects.assign(rects, rects + n_rects);
+    }
+    M->d_packed[0] = M->d_staging + (size_t)M->slot_base[0] * 192;
+    // launch every part from its own thread, then gather on device[0]
+    M->job_options = o;
+    const auto wall0 = std::chrono::steady_clock::now();
+    for (uint32_t p = 0; p < N; p++) {
+        crt_multi::Worker *W = M->workers[p];
+        { std::lock_guard<std::mutex> lock(W->m); W->finished = false; W->go = true; }
+        W->cv.notify_all();
+    }
+    int first_rc = CRT_OK;
+    for (uint32_t p = 0; p < N; p++) {
+        crt_multi::Worker *W = M->workers[p];
+        std::unique_lock<std::mutex> lock(W->m);
+        W->cv.wait(lock, [&] { return W->finished; });
+        if (W->rc != CRT_OK && first_rc == CRT_OK) { first_rc = W->rc; M->error = M->ctx[p]->error; }
+    }
+    if (first_rc != CRT_OK) {
+        for (uint32_t p = 0; p < N; p++) { (void)hipSetDevice(M->devices[p]); (void)hipDeviceSynchronize(); }
+        return first_rc;
+    }
+    CRT_HIP_CHECK(c0, hipSetDevice(M->devices[0]));
+    for (uint32_t p = 1; p < N; p++) CRT_HIP_CHECK(c0, hipStreamWaitEvent(c0->stream, M->done[p], 0));
+    if (M->n_all_items) {
+        const uint64_t threads = (uint64_t)M->n_all_items * 64;
+        hipLaunchKernelGGL(unpack_items_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c0->stream, M->d_staging,
+                           M->d_all_items, M->n_all_items, c0->d_frame, c0->width, c0->height, c0->tiles_x);
+        CRT_HIP_CHECK(c0, hipGetLastError());
+    }
+    if (out_rgb)
+        CRT_HIP_CHECK(c0, hipMemcpyAsync(out_rgb, c0->d_frame, (size_t)c0->width * c0->height * 3 * sizeof(float), hipMemcpyDeviceToHost, c0->stream));
+    CRT_HIP_CHECK(c0, hipStreamSynchronize(c0->stream));
+    const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    // statistics: counters summed over the parts, device time = the slowest part's
+    crt_stats total{};
+    for (uint32_t p = 0; p < N; p++) {
+        crt_ctx *c = M->ctx[p];
+        if (hipSetDevice(M->devices[p]) != hipSuccess) continue;
+        (void)hipStreamSynchronize(c->stream);
+        uint64_t px = 0;
+        for (const WorkItem &w : M->part_items[p]) px += (uint64_t)__builtin_popcountll(w.mask);
+        rc = fetch_counters(c, o, px);
+        if (rc) return fail(c, rc);
+        note_overflow(c);
+        double ms = 0;
+        if (!M->part_items[p].empty() && crt_kernel_elapsed_ms(c, &ms) == CRT_OK && ms > total.kernel_ms) total.kernel_ms = ms;
+        total.box_tests += c->stats.box_tests; total.tri_tests += c->stats.tri_tests; total.leaf_index_reads += c->stats.leaf_index_reads;
+        total.shaded_hits += c->stats.shaded_hits; total.light_evals += c->stats.light_evals; total.texel_fetches += c->stats.texel_fetches;
+        total.primary_rays += c->stats.primary_rays; total.secondary_rays += c->stats.secondary_rays; total.shadow_rays += c->stats.shadow_rays;
+        total.fallback_frames += c->stats.fallback_frames;
+    }
+    total.pixels = M->pixels;
+    total.total_ms = wall_ms;
+    total.counters_valid = o->collect_counters == 1 ? 1u : 0u;
+    M->stats = total;
+    return CRT_OK;
+}
+
+extern "C" int crt_multi_get_stats(crt_multi *M, crt_stats *out) {
+    if (!M || !out) return CRT_ERR_INVALID;
+    *out = M->stats;
+    return CRT_OK;
+}
+
+extern "C" int crt_multi_read_quantized(crt_multi *M, uint8_t *out_rgb8) {
+    if (!M) return CRT_ERR_INVALID;
+    int rc = crt_read_quantized(M->ctx[0], out_rgb8);
+    if (rc) M->error = M->ctx[0]->error;
+    return rc;
 }

@@ -97,7 +97,7 @@ struct KernelArgs {
     uint32_t *s_todo_shadow;      // shadow-queue slots whose packet walk was abandoned
     uint32_t debug;               // development switches
     // quad nodes of the mesh trees (kernel_walk.h): 256 bytes each = {lo.x[4]} {lo.y[4]} {lo.z[4]} {hi.x[4]} {hi.y[4]} {hi.z[4]}
-    // {slot links: quad index | LEAF + first leaf entry | NONE} {unused}, then the slots' LOOSE boxes in the same
+    // {slot links: quad index | LEAF + first leaf entry | NONE} {the same with compact leaf links}, then the slots' LOOSE boxes in the same
     // six-vector layout (crt_device.hip: triangle_loose_box) and two unused vectors
     const float4 *quads;
     const uint32_t *quad_roots;   // per mesh
@@ -129,7 +129,16 @@ struct KernelArgs {
     const uint2 *plan_shadow_masks;  // per leaf: the non-refractive meshes it lists, as bits of the shadow order below
     const uint32_t *plan_shadow_mesh;  // shadow order: bit b = mesh plan_shadow_mesh[b] (big meshes first: likeliest occluders)
     uint32_t plan_shadow_bits;    // number of non-refractive meshes, <= 64
+    // compact forms (crt_create): 3 x float4 per leaf entry {v0,nx} {v1,ny} {v2,nz}; the nodes again with leaf links
+    // LEAF | (entries - 1) << 24 | first entry; quads carry the same links in their vector 7
+    uint32_t plan_compact;
+    const float4 *ptris;
+    const float4 *pnodes;
     uint32_t plan_list_words;     // LDS words per lane of a closest-hit ray's mesh list: ceil(meshes / 4)
+    // kernel_deep.h: the level-free queue of the recursion levels >= 1
+    uint32_t tri_gather;          // kernel_plan.h shadow walk: lanes wait at a leaf until this many do (0: every trip runs both blocks)
+    uint32_t *s_ready;            // one word per slot of s_rayq[1]: == epoch once the slot's record has been published
+    uint32_t epoch;               // this frame's tag (never 0; s_ready starts zeroed and is not cleared between frames)
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -37,6 +37,11 @@ __device__ __forceinline__ v16f plan_leaf(const KernelArgs &A, uint32_t k) {
     return *(kv16p)((kfp)(const float *)A.plan_boxes + PLAN_LEAF_DWORDS * (size_t)k);
 }
 
+// Leaf cursor of the plan kernels: bits 0..23 = the next entry of the leaf, bits 24..30 = entries that follow it (compact
+// leaf links, KernelArgs::pnodes); NONE = not inside a leaf.
+__device__ __forceinline__ uint32_t leaf_cursor_entry(uint32_t c) { return c & 0x00FFFFFFu; }
+__device__ __forceinline__ uint32_t leaf_cursor_next(uint32_t c) { return (c >> 24) ? c + 1u - (1u << 24) : NONE; }
+
 // ---------------------------------------------------------------------------------------------------------------- shadow
 template <uint32_t pass>
 __global__ __launch_bounds__(BLOCK) void stream_trace_shadow_plan(const KernelArgs A) {
@@ -49,11 +54,11 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shadow_plan(const KernelAr
     const uint32_t first = pass == 0 ? 0u : split;
     const uint32_t total = pass == 0 ? split : A.s_counts[SC_SHADOW] - split;
     uint32_t *cursor = A.s_counts + (pass == 0 ? SC_SHADOW_FETCH : SC_SHADOW_FETCH2);
-    const char *nodes_b = reinterpret_cast<const char *>(A.nodes);
-    const char *ltris_b = reinterpret_cast<const char *>(A.ltris);
+    const char *nodes_b = reinterpret_cast<const char *>(A.pnodes);
+    const char *ptris_b = reinterpret_cast<const char *>(A.ptris);
 
     Ray R;
-    uint32_t wn = END, we = NONE;   // next mesh-tree node, next leaf entry
+    uint32_t wn = END, we = NONE;   // next mesh-tree node, leaf cursor
     uint32_t mlo = 0, mhi = 0;      // meshes still to walk, bits of the shadow order
     float light_dist = 0;
     uint32_t nbox = 0, ntri = 0;
@@ -100,15 +105,27 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shadow_plan(const KernelAr
         if (state == ST_TRAVERSE) {
             bool done = false, occluded = false;
             for (int it = 0; it < 64; ++it) {
-                steps++;
-                if (we != NONE) {
+                // What a trip costs the wave is its vector-memory instructions (a divergent gather occupies the vector L1 for
+                // ~64 cycles however few lanes take part): 4 for the triangle block, 2 for the node block.  With tri_gather
+                // set, a trip runs ONE of the blocks: lanes that have reached a leaf wait there until tri_gather of them
+                // do (or nobody has a node left to test), then the triangle block runs with many lanes instead of a few.
+                bool run_tri = we != NONE, run_node = we == NONE;
+                if (A.tri_gather) {
+                    const unsigned long long at_leaf = __ballot(we != NONE), active = __ballot(1);
+                    const bool tri_trip = (uint32_t)__popcll(at_leaf) >= A.tri_gather || at_leaf == active;
+                    run_tri = run_tri && tri_trip;
+                    run_node = run_node && !tri_trip;
+                }
+                if (run_tri) {
+                    steps++;
                     // ---- one triangle of the current leaf (Ray.cpp:9-31, Triangle.cpp:37-57), branch-free
-                    const float4 *T = reinterpret_cast<const float4 *>(ltris_b + (size_t)(uint32_t)(we << 6));
-                    const float4 a = T[0], b = T[1], c = T[2], d = T[3];
+                    const float4 *T = reinterpret_cast<const float4 *>(ptris_b + (size_t)(leaf_cursor_entry(we) * 48u));
+                    const float4 a = T[0], b = T[1], c = T[2];
                     if (A.exec_count) ntri++;
                     const float nx = a.w, ny = b.w, nz = c.w;
                     const float nd = dot3(R.dx, R.dy, R.dz, nx, ny, nz);
-                    const float t = -(dot3(nx, ny, nz, R.ox, R.oy, R.oz) + d.x) / nd;
+                    const float plane = -dot3(a.x, a.y, a.z, nx, ny, nz);  // distanceToPlane, Ray.cpp:17
+                    const float t = -(dot3(nx, ny, nz, R.ox, R.oy, R.oz) + plane) / nd;
                     const float px = R.ox + R.dx * t, py = R.oy + R.dy * t, pz = R.oz + R.dz * t;
                     float s0, s1, s2;
                     {
@@ -125,9 +142,10 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shadow_plan(const KernelAr
                     }
                     // shadow rays are not culled (Ray.cpp:13 is PrimaryRay only)
                     const bool ok = !(t < 0) && !(s0 < -FLT_EPSILON) && !(s1 < -FLT_EPSILON) && !(s2 < -FLT_EPSILON);
-                    we = __float_as_uint(d.z) ? NONE : we + 1;
+                    we = leaf_cursor_next(we);
                     if (ok && t < INFINITY && shadow_hit_occludes(R, px, py, pz, light_dist)) { occluded = true; done = true; break; }
-                } else {
+                } else if (run_node) {
+                    steps++;
                     if (wn == END) {  // the next mesh, or the end of the walk
                         if ((mlo | mhi) == 0u) { done = true; break; }
                         const uint32_t bit = mlo ? (uint32_t)__builtin_ctz(mlo) : 32u + (uint32_t)__builtin_ctz(mhi);
@@ -225,9 +243,9 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArg
     const bool todo = gen == 0 && A.use_packets;  // level 0 after stream_packets_gen0: only the tiles that kernel gave up on
     const uint32_t fetch_count = todo ? A.s_counts[SC_TODO_TILES] * 64u : count;
     if (stream_level_is_whole_heavy(A, gen, count)) return;
-    const char *nodes_b = reinterpret_cast<const char *>(A.nodes);
+    const char *nodes_b = reinterpret_cast<const char *>(A.pnodes);
     const char *quads_b = reinterpret_cast<const char *>(A.quads);
-    const char *ltris_b = reinterpret_cast<const char *>(A.ltris);
+    const char *ptris_b = reinterpret_cast<const char *>(A.ptris);
 
     Ray R;
     Prune prune;
@@ -289,12 +307,14 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArg
                 uint32_t cur = NONE;
                 if (we != NONE) {
                     // ---- one triangle of the current leaf (Ray.cpp:9-31, Triangle.cpp:37-57), branch-free
-                    const float4 *T = reinterpret_cast<const float4 *>(ltris_b + (size_t)(uint32_t)(we << 6));
-                    const float4 a = T[0], b = T[1], c = T[2], d = T[3];
+                    const uint32_t entry = leaf_cursor_entry(we);
+                    const float4 *T = reinterpret_cast<const float4 *>(ptris_b + (size_t)(entry * 48u));
+                    const float4 a = T[0], b = T[1], c = T[2];
                     if (A.exec_count) ntri++;
                     const float nx = a.w, ny = b.w, nz = c.w;
                     const float nd = dot3(R.dx, R.dy, R.dz, nx, ny, nz);
-                    const float t = -(dot3(nx, ny, nz, R.ox, R.oy, R.oz) + d.x) / nd;
+                    const float plane = -dot3(a.x, a.y, a.z, nx, ny, nz);  // distanceToPlane, Ray.cpp:17
+                    const float t = -(dot3(nx, ny, nz, R.ox, R.oy, R.oz) + plane) / nd;
                     const float px = R.ox + R.dx * t, py = R.oy + R.dy * t, pz = R.oz + R.dz * t;
                     float s0, s1, s2;
                     {
@@ -314,12 +334,11 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArg
                     const bool less = ok && (t < mmin);
                     const bool take = less || (ok && !mhave);
                     mt = take ? t : mt;
-                    mtri = take ? __float_as_uint(d.y) : mtri;
+                    mtri = take ? entry : mtri;  // the leaf ENTRY: its triangle is looked up once, when the ray is shaded
                     mmin = less ? t : mmin;
                     mhave = mhave || ok;
-                    const bool last = __float_as_uint(d.z) != 0;
-                    if (QUAD) { next = last; we = last ? NONE : we + 1; }
-                    else we = last ? NONE : we + 1;
+                    we = leaf_cursor_next(we);
+                    if (QUAD) next = we == NONE;
                 } else {
                     if (QUAD ? (wq == NONE) : (wq == END)) {
                         // ---- a mesh ended (scene-level rule, KDTree.cpp:156-167), the next one begins
@@ -339,7 +358,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArg
                         if (sp + 4 > A.quad_stack_depth) { stack_full = true; break; }
                         const float4 *Q = reinterpret_cast<const float4 *>(quads_b + (size_t)(uint32_t)(wq << 8));
                         const float4 lx = Q[0], ly = Q[1], lz = Q[2], hx = Q[3], hy = Q[4], hz = Q[5];
-                        const uint4 lk = reinterpret_cast<const uint4 *>(Q)[6];
+                        const uint4 lk = reinterpret_cast<const uint4 *>(Q)[7];  // slot links with compact leaf links
                         if (A.exec_count) nbox += (lk.x != NONE) + (lk.y != NONE) + (lk.z != NONE) + (lk.w != NONE);
                         bool h0 = lk.x != NONE && slab_test_no_parallel(R, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x);
                         bool h1 = lk.y != NONE && slab_test_no_parallel(R, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y);
@@ -394,6 +413,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArg
                 }
             }
             if (done) {
+                if (have) btri = A.leaf_tris[btri] & ~LAST;  // leaf entry -> triangle
                 shade_and_emit<false>(A, gen, r, node_base, child_base, R, have, bt, btri, bmesh, nullptr, lane);
                 state = ST_FETCH;
             } else if (stack_full) {  // restart it in the wave-per-ray kernel, which needs no stack

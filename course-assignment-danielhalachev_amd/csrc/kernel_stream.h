@@ -40,7 +40,12 @@ constexpr int MAX_GENERATIONS = 64;
 enum : int { SC_COUNT = 0, SC_FETCH = MAX_GENERATIONS, SC_HEAVY = 2 * MAX_GENERATIONS, SC_HEAVY_FETCH = 3 * MAX_GENERATIONS,
              SC_EVICT_FETCH = 4 * MAX_GENERATIONS, SC_SHADOW = 5 * MAX_GENERATIONS, SC_SHADOW_FETCH, SC_OVERFLOW, SC_SHEAVY,
              SC_SHEAVY_FETCH, SC_GUARD, SC_SHADOW_SPLIT, SC_SHADOW_FETCH2,
-             SC_TODO_TILES, SC_TODO_SHADOW, SC_TILE_FETCH, SC_SHEAVY_SPLIT, SC_WORDS };
+             SC_TODO_TILES, SC_TODO_SHADOW, SC_TILE_FETCH, SC_SHEAVY_SPLIT,
+             SC_DEEP_TAIL0, SC_DEEP_CHAINED,  // kernel_deep.h
+             SC_WORDS,
+             // kernel_deep.h's hot counters, each on a 128-byte line of its own (atomics on one line are served one by one)
+             SC_DEEP_DONE = 384, SC_DEEP_NODES = 416, SC_DEEP_WAITS = 448, SC_ALLOC_WORDS = 512 };
+static_assert(SC_WORDS <= 352, "the deep kernel's counters start at word 384");
 
 static_assert(SC_OVERFLOW == SC_OVERFLOW_WORD, "kernel_common.h SC_OVERFLOW_WORD must match");
 
@@ -92,21 +97,31 @@ __device__ __forceinline__ void level0_release_shadow_slots(const KernelArgs &A,
         A.s_shadowq[2 * (first + (size_t)li * 64u)] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(SHADOW_SLOT_UNUSED));
 }
 
-// shootRay's dispatch on the closest hit (RayTracer.cpp:431-450) for ray `r` of level `gen`: writes the ray-tree
-// node, appends the child rays of level gen+1 and the shadow rays.  Called by every lane whose walk has just
-// ended (any subset of the wave); allocations are aggregated over those lanes.
+// shootRay's dispatch on the closest hit (RayTracer.cpp:431-450), in two steps.  shade_hit: everything but the child
+// rays' queue slots -- the ray-tree node's contents, the shadow rays (appended to the shadow queue), and the child rays
+// themselves (reflection, and transmission for a refractive hit without total internal reflection).  The caller then
+// allocates the children and stores the node: shade_and_emit for the per-level queues, kernel_deep.h for the level-free one.
+struct Shaded {
+    TNode N;               // N.a / N.b: CHILD_BG / CHILD_NONE / 0 until the caller fills in the children's node indices
+    bool reflect, transmit;  // child rays to trace (false beyond MAX_DEPTH: such a child is background without tracing)
+    float rox, roy, roz, rdx, rdy, rdz;   // reflection ray (both mirror materials)
+    float tox, toy, toz, tdx, tdy, tdz;   // transmission ray
+};
+
+// Called by every lane whose walk has just ended (any subset of the wave); shadow-slot allocation is aggregated over them.
 template <bool COUNT>
-__device__ __forceinline__ void shade_and_emit(const KernelArgs &A, const uint32_t gen, const uint32_t r, const uint32_t node_base,
-                                       const uint32_t child_base, const Ray &R, const bool have, const float bt,
-                                       const uint32_t btri, const uint32_t bmesh, uint32_t *cnt, const uint32_t lane,
-                                       bool *out_diffuse = nullptr, uint32_t *out_first = nullptr, uint32_t *out_stride = nullptr) {
+__device__ __forceinline__ void shade_hit(const KernelArgs &A, const uint32_t gen, const uint32_t r, const Ray &R, const bool have,
+                                          const float bt, const uint32_t btri, const uint32_t bmesh, uint32_t *cnt,
+                                          const uint32_t lane, Shaded &E, bool *out_diffuse = nullptr,
+                                          uint32_t *out_first = nullptr, uint32_t *out_stride = nullptr) {
     if (out_diffuse) *out_diffuse = false;
-    float4 *out_q = A.s_rayq[(gen + 1u) & 1u];
-    uint32_t *out_count = A.s_counts + SC_COUNT + gen + 1;
     const bool spawn_allowed = gen + 1 <= A.max_depth;  // a child enters shootRay with depth gen+1 (RayTracer.cpp:427)
-    TNode N;
+    TNode &N = E.N;
     N.cx = A.bgx; N.cy = A.bgy; N.cz = A.bgz;
     N.kind = TN_CONST; N.a = 0; N.b = 0; N.f = 0; N.pad = 0;
+    E.reflect = false; E.transmit = false;
+    E.rox = E.roy = E.roz = E.rdx = E.rdy = E.rdz = 0;
+    E.tox = E.toy = E.toz = E.tdx = E.tdy = E.tdz = 0;
     if (have) {
         Surface S;
         surface_at(A, R, bt, btri, bmesh, S);
@@ -156,7 +171,6 @@ __device__ __forceinline__ void shade_and_emit(const KernelArgs &A, const uint32
             const bool refractive = S.M.type == CRT_MAT_REFRACTIVE;
             float nx = S.nx, ny = S.ny, nz = S.nz;
             bool transmit = false;
-            float tox = 0, toy = 0, toz = 0, tdx = 0, tdy = 0, tdz = 0;
             if (refractive) {
                 // calculateRefraction (RayTracer.cpp:375-417)
                 float eta1 = 1.0f, eta2 = S.M.ior;
@@ -175,11 +189,11 @@ __device__ __forceinline__ void shade_and_emit(const KernelArgs &A, const uint32
                     const float r0 = q * q;  // std::powf(q, 2), folded to q*q by the reference's compiler at -O2
                     N.f = r0 + (1 - r0) * crt_pow5(1.0f - cos_a);
                     const float cos_b = sqrtf(std_max(0.0f, 1 - sin_b * sin_b));
-                    tdx = eta_ratio * (R.dx + cos_a * nx) - cos_b * nx;
-                    tdy = eta_ratio * (R.dy + cos_a * ny) - cos_b * ny;
-                    tdz = eta_ratio * (R.dz + cos_a * nz) - cos_b * nz;
-                    normalize3(tdx, tdy, tdz);
-                    tox = S.px - nx * A.refraction_bias; toy = S.py - ny * A.refraction_bias; toz = S.pz - nz * A.refraction_bias;
+                    E.tdx = eta_ratio * (R.dx + cos_a * nx) - cos_b * nx;
+                    E.tdy = eta_ratio * (R.dy + cos_a * ny) - cos_b * ny;
+                    E.tdz = eta_ratio * (R.dz + cos_a * nz) - cos_b * nz;
+                    normalize3(E.tdx, E.tdy, E.tdz);
+                    E.tox = S.px - nx * A.refraction_bias; E.toy = S.py - ny * A.refraction_bias; E.toz = S.pz - nz * A.refraction_bias;
                     transmit = true;
                 }
                 N.kind = TN_REFRACT;
@@ -189,42 +203,66 @@ __device__ __forceinline__ void shade_and_emit(const KernelArgs &A, const uint32
             }
             // the reflection ray (both materials): origin + n*bias, reflect(d, n) normalised (Vector.cpp:119-122)
             const float k = 2 * dot3(R.dx, R.dy, R.dz, nx, ny, nz);
-            float rdx = R.dx - k * nx, rdy = R.dy - k * ny, rdz = R.dz - k * nz;
-            normalize3(rdx, rdy, rdz);
-            const float rox = S.px + nx * A.reflection_bias, roy = S.py + ny * A.reflection_bias,
-                        roz = S.pz + nz * A.reflection_bias;
+            E.rdx = R.dx - k * nx; E.rdy = R.dy - k * ny; E.rdz = R.dz - k * nz;
+            normalize3(E.rdx, E.rdy, E.rdz);
+            E.rox = S.px + nx * A.reflection_bias; E.roy = S.py + ny * A.reflection_bias; E.roz = S.pz + nz * A.reflection_bias;
             N.a = CHILD_BG;
             N.b = refractive ? (transmit ? CHILD_BG : CHILD_NONE) : 0u;
-            if (spawn_allowed) {
-                // wave-aggregated append of 1 or 2 child rays per lane
-                const unsigned long long m1 = __ballot(1), m2 = __ballot(transmit);
-                const unsigned long long below = (1ull << lane) - 1ull;
-                const uint32_t n1 = (uint32_t)__popcll(m1), n2 = (uint32_t)__popcll(m2);
-                uint32_t base = 0;
-                if ((m1 & below) == 0) base = atomicAdd(out_count, n1 + n2);
-                base = __shfl(base, __ffsll((long long)m1) - 1);
-                if ((uint64_t)base + n1 + n2 > A.s_ray_cap || (uint64_t)child_base + base + n1 + n2 > A.s_node_cap) {
-                    A.s_counts[SC_OVERFLOW] = 1;
-                } else {
-                    const uint32_t i1 = base + (uint32_t)__popcll(m1 & below);
-                    out_q[2 * (size_t)i1] = make_float4(rox, roy, roz, 0.0f);
-                    out_q[2 * (size_t)i1 + 1] = make_float4(rdx, rdy, rdz, 0.0f);
-                    N.a = child_base + i1;
-                    if (transmit) {
-                        const uint32_t i2 = base + n1 + (uint32_t)__popcll(m2 & below);
-                        out_q[2 * (size_t)i2] = make_float4(tox, toy, toz, 0.0f);
-                        out_q[2 * (size_t)i2 + 1] = make_float4(tdx, tdy, tdz, 0.0f);
-                        N.b = child_base + i2;
-                    }
-                }
-            }
+            E.reflect = spawn_allowed;
+            E.transmit = spawn_allowed && transmit;
         }
         // any other material type (Constant): background, RayTracer.cpp:443-446
     }
     if (gen == 0 && (N.kind & TN_KIND_MASK) != TN_DIFFUSE) level0_release_shadow_slots(A, r);
-    float4 *dst = A.s_nodes + 2 * ((size_t)node_base + r);
+}
+
+__device__ __forceinline__ void store_tnode(const KernelArgs &A, const size_t index, const TNode &N) {
+    float4 *dst = A.s_nodes + 2 * index;
     dst[0] = make_float4(N.cx, N.cy, N.cz, __uint_as_float(N.kind));
     dst[1] = make_float4(__uint_as_float(N.a), __uint_as_float(N.b), N.f, 0.0f);
+}
+
+// A child ray in a closest-hit queue: {origin, recursion level} {direction, index of its ray-tree node}
+__device__ __forceinline__ void store_child_ray(float4 *q, const size_t index, const float ox, const float oy, const float oz,
+                                                const float dx, const float dy, const float dz, const uint32_t level,
+                                                const uint32_t node) {
+    q[2 * index] = make_float4(ox, oy, oz, __uint_as_float(level));
+    q[2 * index + 1] = make_float4(dx, dy, dz, __uint_as_float(node));
+}
+
+// shade_hit + the per-level queues: ray `r` of level `gen` writes node node_base + r, its children are appended to the
+// queue of level gen+1 (child k of that queue owns node child_base + k).  Allocations are aggregated over the calling lanes.
+template <bool COUNT>
+__device__ __forceinline__ void shade_and_emit(const KernelArgs &A, const uint32_t gen, const uint32_t r, const uint32_t node_base,
+                                       const uint32_t child_base, const Ray &R, const bool have, const float bt,
+                                       const uint32_t btri, const uint32_t bmesh, uint32_t *cnt, const uint32_t lane,
+                                       bool *out_diffuse = nullptr, uint32_t *out_first = nullptr, uint32_t *out_stride = nullptr) {
+    Shaded E;
+    shade_hit<COUNT>(A, gen, r, R, have, bt, btri, bmesh, cnt, lane, E, out_diffuse, out_first, out_stride);
+    if (E.reflect) {
+        float4 *out_q = A.s_rayq[(gen + 1u) & 1u];
+        uint32_t *out_count = A.s_counts + SC_COUNT + gen + 1;
+        // wave-aggregated append of 1 or 2 child rays per lane
+        const unsigned long long m1 = __ballot(1), m2 = __ballot(E.transmit);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const uint32_t n1 = (uint32_t)__popcll(m1), n2 = (uint32_t)__popcll(m2);
+        uint32_t base = 0;
+        if ((m1 & below) == 0) base = atomicAdd(out_count, n1 + n2);
+        base = __shfl(base, __ffsll((long long)m1) - 1);
+        if ((uint64_t)base + n1 + n2 > A.s_ray_cap || (uint64_t)child_base + base + n1 + n2 > A.s_node_cap) {
+            A.s_counts[SC_OVERFLOW] = 1;
+        } else {
+            const uint32_t i1 = base + (uint32_t)__popcll(m1 & below);
+            store_child_ray(out_q, i1, E.rox, E.roy, E.roz, E.rdx, E.rdy, E.rdz, gen + 1u, child_base + i1);
+            E.N.a = child_base + i1;
+            if (E.transmit) {
+                const uint32_t i2 = base + n1 + (uint32_t)__popcll(m2 & below);
+                store_child_ray(out_q, i2, E.tox, E.toy, E.toz, E.tdx, E.tdy, E.tdz, gen + 1u, child_base + i2);
+                E.N.b = child_base + i2;
+            }
+        }
+    }
+    store_tnode(A, (size_t)node_base + r, E.N);
 }
 
 template <bool COUNT>

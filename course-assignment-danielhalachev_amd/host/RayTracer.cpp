@@ -110,11 +110,25 @@ RayTracer::RayTracer(Scene &scene, int device, const crt_tuning *tuning)
   frame.assign((size_t)scene.sceneSettings.image.width * scene.sceneSettings.image.height * 3, 0.0f);
 }
 
-RayTracer::~RayTracer() { crt_destroy(ctx); }
+RayTracer::RayTracer(Scene &scene, const std::vector<int> &devices, const crt_tuning *tuning)
+    : accelerationStructure(scene), scene(scene), camera(scene.camera) {
+  flattenScene(scene, accelerationStructure, flat);
+  int rc = crt_multi_create(&flat.desc, devices.data(), (uint32_t)devices.size(), tuning, &multi);
+  if (rc != CRT_OK) throw std::runtime_error(std::string("crt_multi_create failed: ") + crt_multi_last_error(nullptr));
+  const float pos[3] = {camera.getPosition().x, camera.getPosition().y, camera.getPosition().z};
+  crt_multi_set_camera(multi, pos, &camera.getRotationMatrix().m[0][0]);
+  frame.assign((size_t)scene.sceneSettings.image.width * scene.sceneSettings.image.height * 3, 0.0f);
+}
+
+RayTracer::~RayTracer() {
+  crt_destroy(ctx);
+  crt_multi_destroy(multi);
+}
 
 crt_stats RayTracer::stats() const {
   crt_stats s{};
-  crt_get_stats(ctx, &s);
+  if (multi) crt_multi_get_stats(multi, &s);
+  else crt_get_stats(ctx, &s);
   return s;
 }
 
@@ -129,18 +143,19 @@ int RayTracer::renderFlat(const std::string &pathToImage, const RenderOptions &r
   o.collect_counters = counters;  // 0, 1 (counting build) or 2 (production kernels with tallies), see crt_hip.h
   const Matrix3 &m = camera.getRotationMatrix();
   const float pos[3] = {camera.getPosition().x, camera.getPosition().y, camera.getPosition().z};
-  int rc = crt_set_camera(ctx, pos, &m.m[0][0]);
+  int rc = multi ? crt_multi_set_camera(multi, pos, &m.m[0][0]) : crt_set_camera(ctx, pos, &m.m[0][0]);
   if (rc) return rc;
   // All ten modes render with the tree's semantics: the three BVH* modes are pixel-identical in the
   // reference, the non-tree modes differ from them in a handful of pixels and are not
   // part of this path.  The mode still selects the pixel coverage.
   std::vector<crt_rect> rects = bucketRectangles(W, H, scene.sceneSettings.bucketSize, ro.optimization,
                                                  std::thread::hardware_concurrency());
-  rc = crt_render(ctx, &o, rects.data(), (uint32_t)rects.size(), outRGB);
+  rc = multi ? crt_multi_render(multi, &o, rects.data(), (uint32_t)rects.size(), outRGB)
+             : crt_render(ctx, &o, rects.data(), (uint32_t)rects.size(), outRGB);
   if (rc) return rc;
   if (!pathToImage.empty()) {  // RayTracer.cpp:294-296; quantised on the device with the same rule
     std::vector<uint8_t> q((size_t)W * H * 3);
-    rc = crt_read_quantized(ctx, q.data());
+    rc = multi ? crt_multi_read_quantized(multi, q.data()) : crt_read_quantized(ctx, q.data());
     if (rc) return rc;
     writePPMQuantized(pathToImage, q.data(), W, H);
   }
@@ -150,7 +165,7 @@ int RayTracer::renderFlat(const std::string &pathToImage, const RenderOptions &r
 std::vector<std::vector<Color>> RayTracer::render(const std::string &pathToImage, RenderOptions ro) {
   const unsigned int W = scene.sceneSettings.image.width, H = scene.sceneSettings.image.height;
   int rc = renderFlat(pathToImage, ro, frame.data());
-  if (rc != CRT_OK) throw std::runtime_error(std::string("render failed: ") + crt_last_error(ctx));
+  if (rc != CRT_OK) throw std::runtime_error(std::string("render failed: ") + (multi ? crt_multi_last_error(multi) : crt_last_error(ctx)));
   std::vector<std::vector<Color>> colorBuffer(H, std::vector<Color>(W));
   for (unsigned int y = 0; y < H; y++)
     for (unsigned int x = 0; x < W; x++) {

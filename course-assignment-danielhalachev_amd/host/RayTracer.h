@@ -68,6 +68,9 @@ class RayTracer {
   // uploads scene + tree to the GPU.  Throws std::runtime_error when no usable GPU exists: there is no
   // CPU fallback.
   explicit RayTracer(Scene &scene, int device = 0, const crt_tuning *tuning = nullptr);
+  // The same on several GPUs of one node: the frame's 8x8 tiles are dealt over `devices`, gathered on devices[0]
+  // (crt_hip.h: crt_multi).  This is what replaces the reference's thread pool over buckets (RayTracer.cpp:141-158).
+  RayTracer(Scene &scene, const std::vector<int> &devices, const crt_tuning *tuning = nullptr);
   ~RayTracer();
   RayTracer(const RayTracer &) = delete;
   RayTracer &operator=(const RayTracer &) = delete;
@@ -79,7 +82,8 @@ class RayTracer {
 
   // flat access for callers that do not want the vector-of-vectors copy
   int renderFlat(const std::string &pathToImage, const RenderOptions &renderOptions, float *outRGB, unsigned int counters = 0);
-  crt_ctx *context() const { return ctx; }
+  crt_ctx *context() const { return multi ? crt_multi_context(multi, 0) : ctx; }
+  crt_multi *multiContext() const { return multi; }
   const FlatScene &flatScene() const { return flat; }
   const AccelerationStructure &acceleration() const { return accelerationStructure; }
   crt_stats stats() const;
@@ -90,6 +94,7 @@ class RayTracer {
   Camera camera;
   FlatScene flat;
   crt_ctx *ctx = nullptr;
+  crt_multi *multi = nullptr;  // set instead of ctx when the tracer was built for several devices
   std::vector<float> frame;  // persistent colorBuffer (RayTracer.h:69)
 };
 

@@ -174,12 +174,32 @@ extern "C" int crt_host_tracer_create_tuned(crt_host_scene *scene, int device, c
   });
 }
 
+extern "C" int crt_host_tracer_create_multi(crt_host_scene *scene, const int *devices, uint32_t n_devices, const crt_tuning *tuning,
+                                            crt_host_tracer **out) {
+  if (!scene || !out || !devices || n_devices == 0) return CRT_ERR_INVALID;
+  *out = nullptr;
+  int ndev = crt_device_count();
+  for (uint32_t i = 0; i < n_devices; i++)
+    if (ndev <= 0 || devices[i] < 0 || devices[i] >= ndev) {
+      g_error = "no usable HIP device (this library has no CPU fallback)";
+      return CRT_ERR_NO_DEVICE;
+    }
+  return guarded([&]() {
+    std::unique_ptr<crt_host_tracer> t(new crt_host_tracer());
+    t->scene = scene;
+    t->tracer.reset(new crt::RayTracer(scene->scene, std::vector<int>(devices, devices + n_devices), tuning));
+    *out = t.release();
+    return CRT_OK;
+  });
+}
+
 extern "C" void crt_host_tracer_free(crt_host_tracer *tracer) { delete tracer; }
 
 extern "C" int crt_host_tracer_set_camera(crt_host_tracer *t, const float position[3], const float matrix[9]) {
   if (!t || !position || !matrix) return CRT_ERR_INVALID;
   t->tracer->setCamera().setPosition() = crt::Vector(position[0], position[1], position[2]);
   memcpy(&t->tracer->setCamera().setRotationMatrix().m[0][0], matrix, 9 * sizeof(float));
+  if (t->tracer->multiContext()) return crt_multi_set_camera(t->tracer->multiContext(), position, matrix);
   return crt_set_camera(t->tracer->context(), position, matrix);  // also for callers of the device-level API
 }
 
@@ -190,12 +210,18 @@ extern "C" int crt_host_tracer_render(crt_host_tracer *t, const char *ppm_path, 
     crt::RenderOptions ro((crt::RenderOptimization)optimization, o->max_depth, o->use_gi != 0, 2, 1, o->shadow_bias,
                           o->reflection_bias, o->refraction_bias);
     int rc = t->tracer->renderFlat(ppm_path ? ppm_path : "", ro, out_rgb, o->collect_counters);
-    if (rc) g_error = crt_last_error(t->tracer->context());
+    if (rc) g_error = t->tracer->multiContext() ? crt_multi_last_error(t->tracer->multiContext()) : crt_last_error(t->tracer->context());
     return rc;
   });
 }
 
 extern "C" crt_ctx *crt_host_tracer_ctx(crt_host_tracer *t) { return t ? t->tracer->context() : nullptr; }
+
+extern "C" int crt_host_tracer_stats(crt_host_tracer *t, crt_stats *out) {
+  if (!t || !out) return CRT_ERR_INVALID;
+  *out = t->tracer->stats();
+  return CRT_OK;
+}
 
 extern "C" int crt_host_export_ppm(const char *path, const float *rgb, uint32_t width, uint32_t height) {
   if (!path || !rgb) return CRT_ERR_INVALID;

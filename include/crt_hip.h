@@ -185,12 +185,15 @@ typedef struct crt_tuning {
     uint32_t tiny_meshes;     /* 1: single-leaf meshes are tested in one step by the wave-per-ray kernels */
     uint32_t node_cap, ray_cap, shadow_cap; /* 0 = sized from the frame (4x / 3x / n_lights x 4x the pixels, at least 2^20);
                                              * smaller values make queue overflow -- and the fallback -- reachable in tests */
-    uint32_t deep;            /* 1: recursion levels >= 1 run as ONE persistent queue-driven launch (no level barriers);
-                               * 0: one launch triple per level */
+    uint32_t deep;            /* 0: one launch triple per recursion level; 1: recursion levels >= 1 run as ONE persistent
+                               * queue-driven launch (no level barriers) */
     uint32_t deep_blocks;     /* 0 (= 4 per CU): workgroups of that launch */
     uint32_t plan;            /* 1: the per-lane kernels evaluate a small top-level tree as a plan (its leaves tested in a
                                * wave-uniform loop) instead of walking it node by node per lane */
-    uint32_t reserved[5];
+    uint32_t deep_waves;      /* 5: register budget of that launch in waves per SIMD (4 or 5) */
+    uint32_t tri_gather;      /* 0: the planned shadow walk runs its triangle and its node block on every loop trip; N: one block
+                               * per trip, lanes wait at a leaf until N of them do (fewer, fuller triangle trips) */
+    uint32_t reserved[3];
 } crt_tuning;
 void crt_tuning_defaults(crt_tuning *tuning);
 
@@ -252,6 +255,23 @@ void crt_destroy(crt_ctx *ctx);
 /* last error text of a context (or of the last failed crt_create when ctx == NULL) */
 const char *crt_last_error(const crt_ctx *ctx);
 int crt_device_count(void);
+
+/* ---- one scene on several devices of one node, behind the same call (SURVEY.md section 8b "multi-GPU handled inside the
+ * context"; the reference's counterpart is the bucket thread pool, RayTracer.cpp:141-158).  One context, host thread and
+ * stream per listed device (a device may be listed more than once); the covered 8x8 tiles are dealt round-robin, every
+ * device copies its packed tiles to devices[0] over xGMI (peer copy, no collective) and devices[0] scatters them into its
+ * persistent colour buffer.  crt_multi_render has crt_render's contract: same pixels, bit for bit. */
+typedef struct crt_multi crt_multi;
+int crt_multi_create(const crt_scene_desc *scene, const int *devices, uint32_t n_devices, const crt_tuning *tuning, crt_multi **out);
+int crt_multi_set_camera(crt_multi *multi, const float position[3], const float matrix[9]);
+int crt_multi_render(crt_multi *multi, const crt_options *options, const crt_rect *rects, uint32_t n_rects, float *out_rgb);
+int crt_multi_read_quantized(crt_multi *multi, uint8_t *out_rgb8);
+/* counters summed over the devices, kernel_ms = the slowest device's, total_ms = wall time of the call */
+int crt_multi_get_stats(crt_multi *multi, crt_stats *out);
+uint32_t crt_multi_device_count(const crt_multi *multi);
+crt_ctx *crt_multi_context(crt_multi *multi, uint32_t part); /* part 0 holds the frame */
+const char *crt_multi_last_error(const crt_multi *multi);
+void crt_multi_destroy(crt_multi *multi);
 
 /* After a render with collect_counters == 2 on the default (ray-stream) path: out = {box tests, triangle tests} the
  * production kernels executed in the whole render, then the same two for shadow pass 0 alone (the largest kernel).  Fewer than crt_stats' box_tests / tri_tests, which are the reference's: the kernels leave

@@ -58,12 +58,17 @@ int crt_host_camera_apply(float position[3], float matrix[9], int op, const floa
 int crt_host_tracer_create(crt_host_scene *scene, int device, crt_host_tracer **out);
 /* the same with explicit kernel tuning (crt_hip.h: crt_tuning; NULL = defaults) */
 int crt_host_tracer_create_tuned(crt_host_scene *scene, int device, const crt_tuning *tuning, crt_host_tracer **out);
+/* the same on several GPUs of one node (crt_hip.h: crt_multi); devices[0] holds the frame */
+int crt_host_tracer_create_multi(crt_host_scene *scene, const int *devices, uint32_t n_devices, const crt_tuning *tuning,
+                                 crt_host_tracer **out);
 void crt_host_tracer_free(crt_host_tracer *tracer);
 int crt_host_tracer_set_camera(crt_host_tracer *tracer, const float position[3], const float matrix[9]);
 /* ppm_path may be NULL or "" (no file, RayTracer.cpp:294); out_rgb = H*W*3 floats or NULL */
 int crt_host_tracer_render(crt_host_tracer *tracer, const char *ppm_path, int optimization, const crt_options *options,
                            float *out_rgb);
 crt_ctx *crt_host_tracer_ctx(crt_host_tracer *tracer);
+/* statistics of the last render (summed over the devices of a multi-device tracer) */
+int crt_host_tracer_stats(crt_host_tracer *tracer, crt_stats *out);
 int crt_host_export_ppm(const char *path, const float *rgb, uint32_t width, uint32_t height);
 
 const char *crt_host_last_error(void);

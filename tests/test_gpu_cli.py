@@ -81,3 +81,19 @@ def test_crt_animation_renders_the_orbit_frames(pkg, scenes, oracle, tmp_path):
         assert data == open(ref, "rb").read(), path
         seen.add(data)
     assert len(seen) > 1                                   # the camera did move
+
+
+def test_crt_main_on_several_devices(scenes, oracle, tmp_path):
+    # --devices 0,0: the frame's tiles over two contexts (on a one-GPU box both on device 0), same PPM bytes
+    if not os.path.exists(EXE):
+        pytest.skip("crt_main not built")
+    scene, depth, _ = small_case(scenes, "hw11")
+    (tmp_path / "scene.crtscene").write_text(scenes.to_json(scene))
+    out = str(tmp_path / "out.ppm")
+    r = subprocess.run([EXE, "scene.crtscene", out, "--depth", str(depth), "--devices", "0,0"], capture_output=True, text=True,
+                       timeout=120, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    want, _ = oracle.OracleScene(scenes.to_blob(scene)).render(depth)
+    ref = str(tmp_path / "ref.ppm")
+    oracle.write_ppm(ref, want)
+    assert open(out, "rb").read() == open(ref, "rb").read()

@@ -71,6 +71,7 @@ KERNEL_PATHS = [
     dict(deep=0),                                                # one launch triple per recursion level (no persistent deep kernel)
     dict(deep=0, heavy_level=0),                                 # ... with the per-lane kernels at every level
     dict(deep=1, deep_blocks=3),                                 # persistent deep kernel on a tiny grid
+    dict(deep=1, deep_waves=4, deep_blocks=4096),                # ... with its natural register budget, on a grid larger than the chip
     dict(top_in_registers=0, tiny_meshes=0),                     # top-level tree and single-leaf meshes read from memory
     dict(fixed0=0, bundle=64),                                   # level 0's shadow rays queued; lanes refill one by one
 ]
@@ -102,6 +103,26 @@ def test_queue_overflow_hands_the_frame_to_the_fallback(pkg, scenes, oracle, cap
     roomy = make_tracer(pkg, scenes, scene)
     assert_same_floats(roomy.render(max_depth=depth), want, "default capacities")
     assert roomy.stats().fallback_frames == 0
+
+
+def test_deep_queue_overflow_hands_the_frame_to_the_fallback(pkg, scenes, oracle):
+    """The persistent deep kernel (kernel_deep.h) runs out of queue slots / ray-tree nodes in the middle of its work: every
+    wave must still leave (none may wait for a ray that will never be published) and the fallback redoes the frame."""
+    SC_DEEP_TAIL0, SC_LEVEL1_SLOTS = 332, 1                                # csrc/kernel_stream.h
+    scene, depth, _ = small_case(scenes, "hw11")
+    want, _ = oracle.OracleScene(scenes.to_blob(scene)).render(depth)
+    roomy = make_tracer(pkg, scenes, scene)
+    assert_same_floats(roomy.render(max_depth=depth), want, "roomy")
+    counts = roomy.stream_counts()
+    level1, slots = int(counts[SC_DEEP_TAIL0]), int(counts[SC_LEVEL1_SLOTS])
+    assert 0 < level1 < slots                                              # transmission rays were published behind level 1's
+    pixels = scene["settings"]["image_settings"]["width"] * scene["settings"]["image_settings"]["height"]
+    padded = ((scene["settings"]["image_settings"]["width"] + 7) // 8) * ((scene["settings"]["image_settings"]["height"] + 7) // 8) * 64
+    for caps in (dict(ray_cap=level1 + 7), dict(ray_cap=(level1 + slots) // 2), dict(node_cap=padded + level1 + 5)):
+        tracer = make_tracer(pkg, scenes, scene, tuning=dict(caps, deep=1))
+        assert_same_floats(tracer.render(max_depth=depth), want, "deep overflow %r" % (caps,))
+        assert tracer.stats().fallback_frames == 1, caps
+    assert pixels <= padded
 
 
 def test_depth_rule_and_bias_options(pkg, scenes, oracle):
@@ -326,3 +347,51 @@ def test_more_meshes_than_the_seen_mask_holds(pkg, scenes, oracle):
     assert tracer.stats().counters() == counters
     assert_same_floats(got, want, "72 meshes (counting build)")
     assert_same_floats(tracer.render(max_depth=4), want, "72 meshes (production kernels)")
+
+
+# ---------------------------------------------------------------------------------------------- several devices, one tracer
+@pytest.mark.parametrize("parts", [2, 3])
+def test_multi_device_tracer_renders_the_same_frame(pkg, scenes, oracle, parts):
+    """crt::RayTracer(scene, devices[]) / crt_multi_*: one context per listed device, tiles dealt round-robin, packed tiles
+    copied to devices[0] and scattered there.  A one-GPU box lists its device several times: same code path, peer copy onto
+    itself.  Same pixels as the single-device tracer, same work counters in total."""
+    scene, depth, _ = small_case(scenes, "hw14")
+    want, counters = oracle.OracleScene(scenes.to_blob(scene)).render(depth)
+    tracer = pkg.Tracer(pkg.Scene(json_text=scenes.to_json(scene)), devices=[0] * parts)
+    assert_same_floats(tracer.render(max_depth=depth), want, "%d parts" % parts)
+    assert np.array_equal(tracer.read_quantized().astype(np.uint16), oracle.quantize(want))
+    counted = tracer.render(max_depth=depth, counters=True)               # counting build on every part
+    assert_same_floats(counted, want, "%d parts, counting build" % parts)
+    st = tracer.stats()
+    assert st.counters_valid == 1 and st.counters() == counters and st.pixels == want.shape[0] * want.shape[1]
+    assert st.fallback_frames == 0
+    # a new camera reaches every part
+    pos, mat = pkg.camera_apply(scene["camera"]["position"], scene["camera"]["matrix"], "pan", 20.0)
+    tracer.set_camera(pos, mat)
+    o = oracle.OracleScene(scenes.to_blob(scene))
+    o.set_camera(pos, mat)
+    assert_same_floats(tracer.render(max_depth=depth), o.render(depth)[0], "%d parts, moved camera" % parts)
+
+
+def test_multi_device_tracer_keeps_uncovered_pixels(pkg, scenes, oracle):
+    # bucket_size 7 on 100x60 covers part of the frame only (SURVEY.md section 8 Q5): coverage masks travel with the tiles
+    scene = scenes.make("hw08", width=100, height=60, detail=0.3)
+    scene["settings"]["image_settings"]["bucket_size"] = 7
+    tracer = pkg.Tracer(pkg.Scene(json_text=scenes.to_json(scene)), devices=[0, 0])
+    o = oracle.OracleScene(scenes.to_blob(scene))
+    assert_same_floats(tracer.render(max_depth=1), o.render(1)[0], "partial coverage on two parts")
+    full = tracer.render(max_depth=1, optimization=pkg.OPT_BVH).copy()    # one rectangle: the whole frame
+    pos, mat = pkg.camera_apply(scene["camera"]["position"], scene["camera"]["matrix"], "pan", 25.0)
+    tracer.set_camera(pos, mat)
+    o.set_camera(pos, mat)
+    mixed = tracer.render(max_depth=1)                                    # partial again: uncovered pixels keep `full`
+    moved = o.render(1, buffer=np.ascontiguousarray(full.copy()))[0]
+    assert_same_floats(mixed, moved, "persistence on two parts")
+
+
+def test_multi_device_full_size(pkg, full_hw14):
+    scene, tracer = full_hw14
+    want = tracer.render(max_depth=8).copy()
+    multi = pkg.Tracer(tracer.scene, devices=[0, 0, 0, 0])
+    got = multi.render(max_depth=8)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))

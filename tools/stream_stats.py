@@ -19,3 +19,4 @@ print('rays per level   ', [out[g] for g in range(depth + 2)])
 print('evicted per level', [out[128 + g] for g in range(depth + 1)])
 print('todo tiles', out[328], 'todo shadow slots', out[329], 'split', out[326])
 print('shadow rays', out[320], 'evicted shadow', out[323], 'overflow', out[322], 'guard', out[325])
+print('deep queue: level-1 rays', out[332], 'slots', out[1], 'claimed', out[65], 'done', out[384], 'chained rays', out[333], 'nodes', out[416], 'claims that waited', out[448], 'fallback frames', tr.stats().fallback_frames)
