@@ -88,7 +88,7 @@ class Stats(C.Structure):
                 ("tri_tests", C.c_uint64), ("leaf_index_reads", C.c_uint64), ("shaded_hits", C.c_uint64),
                 ("light_evals", C.c_uint64), ("texel_fetches", C.c_uint64), ("primary_rays", C.c_uint64),
                 ("secondary_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("pixels", C.c_uint64),
-                ("counters_valid", C.c_uint32), ("fallback_frames", C.c_uint32)]
+                ("counters_valid", C.c_uint32), ("fallback_frames", C.c_uint32), ("queue_bytes", C.c_uint64)]
 
     def counters(self):
         return {k: int(getattr(self, k)) for k in ("box_tests", "tri_tests", "leaf_index_reads", "shaded_hits",
@@ -104,7 +104,7 @@ class Tuning(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "size", "mode", "step_budget", "shadow_budget", "pass1_budget", "heavy_level", "heavy_blocks", "side_blocks",
         "quad", "quad_stack", "prune", "bundle", "fixed0", "packet_budget", "path_mask", "top_in_registers",
-        "tiny_meshes", "node_cap", "ray_cap", "shadow_cap", "deep", "deep_blocks", "plan", "deep_waves", "tri_gather")] + [("reserved", C.c_uint32 * 3)]
+        "tiny_meshes", "node_cap", "ray_cap", "shadow_cap", "deep", "deep_blocks", "plan", "deep_waves", "tri_gather", "deep_heavy_every", "level0_budget")] + [("reserved", C.c_uint32 * 1)]
 
 
 def make_tuning(**fields):
@@ -133,9 +133,13 @@ DEVICE_SYMBOLS = ["crt_tuning_defaults", "crt_create_tuned", "crt_create", "crt_
                   "crt_unpack_tiles_device", "crt_quantize_device", "crt_read_quantized", "crt_kernel_elapsed_ms", "crt_kernel_times_ms",
                   "crt_get_stats", "crt_get_kernel_counters", "crt_synchronize", "crt_destroy", "crt_last_error", "crt_device_count", "crt_test_pow5",
                   "crt_debug_stream_counts", "crt_debug_packet_counters", "crt_get_executed_counters",
+                  "crt_render_async", "crt_wait", "crt_alloc_pinned", "crt_free_pinned",
+                  "crt_build_tree_device", "crt_built_tree_node_count", "crt_built_tree_index_total", "crt_built_tree_boxes",
+                  "crt_built_tree_links", "crt_built_tree_indexes", "crt_built_tree_free", "crt_build_last_error",
                   "crt_multi_create", "crt_multi_set_camera", "crt_multi_render", "crt_multi_read_quantized", "crt_multi_get_stats",
                   "crt_multi_device_count", "crt_multi_context", "crt_multi_last_error", "crt_multi_destroy"]
-HOST_SYMBOLS = ["crt_host_scene_parse_file", "crt_host_scene_parse_text", "crt_host_scene_free", "crt_host_scene_desc",
+HOST_SYMBOLS = ["crt_host_scene_parse_file", "crt_host_scene_parse_text", "crt_host_scene_parse_text_ex",
+                "crt_host_scene_build_seconds", "crt_host_scene_free", "crt_host_scene_desc",
                 "crt_host_scene_settings", "crt_host_scene_camera", "crt_host_scene_mesh_count",
                 "crt_host_tree_node_count", "crt_host_tree_index_total", "crt_host_tree_dump", "crt_host_mesh_sizes",
                 "crt_host_mesh_normals", "crt_host_bucket_rects", "crt_host_camera_apply", "crt_host_tracer_create", "crt_host_tracer_create_tuned",
@@ -160,6 +164,12 @@ def lib():
     L.crt_set_camera.argtypes = [vp, vp, vp]
     L.crt_render.argtypes = [vp, C.POINTER(Options), C.POINTER(Rect), u32, vp]
     L.crt_render_tiles_device.argtypes = [vp, C.POINTER(Options), u32, u32, vp, vp]
+    L.crt_render_async.argtypes = [vp, C.POINTER(Options), C.POINTER(Rect), u32, vp, vp]
+    L.crt_wait.argtypes = [vp]
+    L.crt_alloc_pinned.restype = vp
+    L.crt_alloc_pinned.argtypes = [C.c_size_t]
+    L.crt_free_pinned.restype = None
+    L.crt_free_pinned.argtypes = [vp]
     L.crt_packed_tile_count.restype = u32
     L.crt_packed_tile_count.argtypes = [vp, u32, u32]
     L.crt_unpack_tiles_device.argtypes = [vp, vp, u32, C.c_uint64, vp, vp]
@@ -176,6 +186,9 @@ def lib():
     L.crt_last_error.argtypes = [vp]
     L.crt_host_scene_parse_file.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp)]
     L.crt_host_scene_parse_text.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(vp)]
+    L.crt_host_scene_parse_text_ex.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, i32, C.POINTER(vp)]
+    L.crt_host_scene_build_seconds.restype = C.c_double
+    L.crt_host_scene_build_seconds.argtypes = [vp]
     L.crt_host_scene_free.argtypes = [vp]
     L.crt_host_scene_free.restype = None
     L.crt_host_scene_desc.restype = C.POINTER(SceneDesc)
@@ -235,18 +248,20 @@ def _host_check(rc):
 class Scene:
     """A parsed `.crtscene` with its tree built and flattened (host side only; no GPU needed)."""
 
-    def __init__(self, json_text=None, path=None, folder=""):
+    def __init__(self, json_text=None, path=None, folder="", build_device=-1):
+        """build_device >= 0: the big meshes' trees are built on that GPU (same trees, node for node)."""
         L = lib()
         h = C.c_void_p()
         if json_text is not None:
             data = json_text.encode() if isinstance(json_text, str) else json_text
-            _host_check(L.crt_host_scene_parse_text(data, len(data), folder.encode(), C.byref(h)))
+            _host_check(L.crt_host_scene_parse_text_ex(data, len(data), folder.encode(), build_device, C.byref(h)))
         else:
             _host_check(L.crt_host_scene_parse_file(path.encode(), folder.encode(), C.byref(h)))
         self._h = h
         w, hh, b = C.c_uint32(), C.c_uint32(), C.c_uint32()
         L.crt_host_scene_settings(h, C.byref(w), C.byref(hh), C.byref(b))
         self.width, self.height, self.bucket_size = w.value, hh.value, b.value
+        self.build_seconds = L.crt_host_scene_build_seconds(h)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -425,6 +440,18 @@ class Tracer:
         n = C.c_uint32()
         self._check(lib().crt_kernel_times_ms(self.ctx, a, max_count, C.byref(n)))
         return [tuple(a[5 * i + j] for j in range(5)) for i in range(n.value)]
+
+    # ---- a frame without waiting for it (crt_render_async / crt_wait), through the device-level ABI of the first context
+    def render_async(self, options, rgb=None, rgb8=None, optimization=OPT_BVH_BUCKETS_POOL):
+        """Enqueue a frame (coverage: the reference's bucket rectangles); rgb / rgb8 are numpy arrays the copies land in
+        once wait() has returned."""
+        r = bucket_rects(self.width, self.height, self.scene.bucket_size, optimization)
+        rects = (Rect * len(r))(*[Rect(*map(int, x)) for x in r])
+        self._check(lib().crt_render_async(self.ctx, C.byref(options), rects, len(r), _p(rgb) if rgb is not None else None,
+                                           _p(rgb8) if rgb8 is not None else None))
+
+    def wait(self):
+        self._check(lib().crt_wait(self.ctx))
 
     def stream_counts(self):
         """Diagnostics: the ray-stream pass's counter block of the last frame (SC_* layout of csrc/kernel_stream.h)."""

@@ -141,6 +141,15 @@ struct crt_ctx {
     hipEvent_t ev_fork[EV_RING] = {}, ev_s0[EV_RING] = {}, ev_s1[EV_RING] = {}, ev_s2[EV_RING] = {}, ev4[EV_RING] = {};
     float4 *d_hits = nullptr;         // their closest hits
     uint32_t *d_ready = nullptr;      // kernel_deep.h: publication flags of the deep queue's slots
+    uint32_t *d_ready2 = nullptr;     // ... and of the heavy queue's
+    // queue sizing (ensure_stream): capacities as multiples of the frame's pixels, adapted from frame to frame
+    double node_mult = 1.5, ray_mult = 0.5, shadow_extra = 0.25;
+    uint32_t *h_counts = nullptr;     // pinned copy of the last frame's counter block (d_scounts)
+    uint32_t sizing_seen_fallbacks = 0, last_items = 0;
+    uint64_t queue_bytes = 0;         // bytes of the per-frame buffers as allocated now
+    hipEvent_t ev_call0 = nullptr, ev_call1 = nullptr;  // around the last crt_render / crt_render_async call's device work
+    bool pending = false;             // a frame enqueued by crt_render_async has not been waited for
+    crt_options pending_options{};
     uint32_t epoch = 0;               // frames launched (the deep queue's tag)
     uint32_t heavy_cap = 0;
     uint32_t step_budget = 256;       // CRT_STEP_BUDGET: closest-hit walks are evicted to heavy_trace after this many steps (0 = never)
@@ -378,6 +387,8 @@ extern "C" void crt_tuning_defaults(crt_tuning *t) {
     t->plan = 1;
     t->deep_waves = 5;
     t->tri_gather = 0;
+    t->deep_heavy_every = 4;
+    t->level0_budget = 0;
 }
 
 extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) { return crt_create_tuned(s, device, nullptr, out); }
@@ -878,6 +889,8 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
     CK(hipMemset(ctx->d_scounts, 0, 512 * sizeof(uint32_t)));
     CK(hipHostMalloc((void **)&ctx->h_overflow, sizeof(uint32_t)));
     *ctx->h_overflow = 0;
+    CK(hipHostMalloc((void **)&ctx->h_counts, SC_ALLOC_WORDS * sizeof(uint32_t)));
+    memset(ctx->h_counts, 0, SC_ALLOC_WORDS * sizeof(uint32_t));
     CK(hipMalloc((void **)&ctx->d_fallback_total, sizeof(uint32_t)));
     CK(hipMemset(ctx->d_fallback_total, 0, sizeof(uint32_t)));
     ctx->n_lights = s->n_lights;
@@ -910,7 +923,9 @@ extern "C" void crt_destroy(crt_ctx *ctx) {
     if (ctx->d_todo_shadow) (void)hipFree(ctx->d_todo_shadow);
     if (ctx->d_hits) (void)hipFree(ctx->d_hits);
     if (ctx->d_ready) (void)hipFree(ctx->d_ready);
+    if (ctx->d_ready2) (void)hipFree(ctx->d_ready2);
     if (ctx->h_overflow) (void)hipHostFree(ctx->h_overflow);
+    if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     if (ctx->d_fallback_total) (void)hipFree(ctx->d_fallback_total);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_frames) (void)hipFree(ctx->d_frames);
@@ -925,6 +940,8 @@ extern "C" void crt_destroy(crt_ctx *ctx) {
         if (ctx->ev_s1[i]) (void)hipEventDestroy(ctx->ev_s1[i]);
         if (ctx->ev_s2[i]) (void)hipEventDestroy(ctx->ev_s2[i]);
     }
+    if (ctx->ev_call0) (void)hipEventDestroy(ctx->ev_call0);
+    if (ctx->ev_call1) (void)hipEventDestroy(ctx->ev_call1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
     delete ctx;
@@ -982,27 +999,75 @@ static int ensure_frames(crt_ctx *ctx, uint32_t max_depth) {
 // 4x the pixels, each level's ray queue 3x, shadow rays n_lights per node.  A frame that needs more (deep
 // refractive stacks can reach 2^(MAX_DEPTH+1)-1 rays per pixel) raises the overflow word and is redone by
 // render_lanes, which needs no queues.
+// Queues of the ray-stream pass.  What a frame needs depends on the scene and the camera -- a frame of diffuse surfaces
+// has no child rays at all, nested glass can reach 2^(MAX_DEPTH+1)-1 rays per pixel -- so the capacities FOLLOW the frames:
+// they start at px * {1.5 ray-tree nodes, 0.5 rays per level, n_lights * 1.25 shadow rays} (px = 64 pixels per work item),
+// grow by half when the previous frame used more than 70 % of one of them, and double (up to px * {4, 3, n_lights * 4})
+// after a frame that overflowed.  Such a frame is not lost: its queues raise the overflow word and render_lanes, which
+// needs no queues, redoes it in the same call (crt_stats::fallback_frames counts them).
+static void adapt_queue_sizing(crt_ctx *ctx) {
+    if (!ctx->h_counts) return;
+    const uint32_t *c = ctx->h_counts;  // the previous frame's counter block (pinned copy; zero before the first frame)
+    const uint32_t fallbacks = *ctx->h_overflow;
+    if (fallbacks != ctx->sizing_seen_fallbacks) {
+        ctx->sizing_seen_fallbacks = fallbacks;
+        ctx->node_mult = std::min(4.0, ctx->node_mult * 2.0);
+        ctx->ray_mult = std::min(3.0, ctx->ray_mult * 2.0);
+        ctx->shadow_extra = std::min(3.0, ctx->shadow_extra * 2.0);
+        return;
+    }
+    const KernelArgs &A = ctx->args;
+    if (!A.s_node_cap || !ctx->last_items) return;
+    const uint64_t px = (uint64_t)ctx->last_items * 64;
+    uint64_t rays = 0, nodes = px;
+    for (int g = 1; g < MAX_GENERATIONS; g++) { rays = std::max<uint64_t>(rays, c[SC_COUNT + g]); nodes += c[SC_COUNT + g]; }
+    if (c[SC_DEEP_NODES]) nodes = c[SC_DEEP_NODES];  // (the deep kernels allocate nodes from their own cursor)
+    rays = std::max<uint64_t>(rays, c[SC_DEEP_HQ_TAIL]);
+    const uint64_t shadow = c[SC_SHADOW];
+    // level 0 owns one node per pixel and n_lights fixed shadow slots per pixel: what can run out is the part beyond that
+    const uint64_t base_shadow = px * (ctx->n_lights ? ctx->n_lights : 1);
+    const uint64_t extra_nodes = nodes > px ? nodes - px : 0, extra_shadow = shadow > base_shadow ? shadow - base_shadow : 0;
+    if (A.s_node_cap > px && extra_nodes * 10 > ((uint64_t)A.s_node_cap - px) * 7) ctx->node_mult = std::min(4.0, ctx->node_mult * 1.5);
+    if (rays * 10 > (uint64_t)A.s_ray_cap * 7) ctx->ray_mult = std::min(3.0, ctx->ray_mult * 1.5);
+    if (A.s_shadow_cap > base_shadow && extra_shadow * 10 > ((uint64_t)A.s_shadow_cap - base_shadow) * 7)
+        ctx->shadow_extra = std::min(3.0, ctx->shadow_extra * 1.5);
+}
+
 static int ensure_stream(crt_ctx *ctx, uint32_t n_items) {
     KernelArgs &A = ctx->args;
-    if (n_items > ctx->stream_items) {
+    adapt_queue_sizing(ctx);
+    ctx->last_items = n_items;
+    const uint64_t px = (uint64_t)n_items * 64;
+    const uint64_t lights = ctx->n_lights ? ctx->n_lights : 1;
+    const uint64_t floor_cap = 1u << 16;
+    uint64_t node_cap = std::max<uint64_t>(floor_cap, (uint64_t)(px * ctx->node_mult));
+    uint64_t ray_cap = std::max<uint64_t>(floor_cap, (uint64_t)(px * ctx->ray_mult));
+    uint64_t shadow_cap = std::max<uint64_t>(floor_cap, (uint64_t)(px * lights * (1.0 + ctx->shadow_extra)));
+    // explicit capacities (crt_tuning): never below what level 0 itself needs, so that only the deeper levels can overflow
+    if (ctx->tuning.node_cap) node_cap = ctx->tuning.node_cap < px ? px : ctx->tuning.node_cap;
+    if (ctx->tuning.ray_cap) ray_cap = ctx->tuning.ray_cap;
+    if (ctx->tuning.shadow_cap) shadow_cap = ctx->tuning.shadow_cap;
+    node_cap = std::min<uint64_t>(node_cap, 0x7FFFFFF0ull);
+    ray_cap = std::min<uint64_t>(ray_cap, 0x7FFFFFF0ull);
+    shadow_cap = std::min<uint64_t>(shadow_cap, 0x7FFFFFF0ull);
+    if (px > node_cap) { ctx->error = "frame too large for the ray-stream buffers"; return CRT_ERR_INVALID; }
+    const bool fixed_caps = ctx->tuning.node_cap || ctx->tuning.ray_cap || ctx->tuning.shadow_cap;
+    const bool grow = node_cap > A.s_node_cap || ray_cap > A.s_ray_cap || shadow_cap > A.s_shadow_cap || n_items > ctx->stream_items ||
+                      (fixed_caps && (node_cap != A.s_node_cap || ray_cap != A.s_ray_cap || shadow_cap != A.s_shadow_cap));
+    if (grow) {
+        CRT_HIP_CHECK(ctx, hipDeviceSynchronize());  // nothing may still be using the old buffers
+        if (!fixed_caps) {  // never shrink: keep what is already there
+            node_cap = std::max<uint64_t>(node_cap, A.s_node_cap);
+            ray_cap = std::max<uint64_t>(ray_cap, A.s_ray_cap);
+            shadow_cap = std::max<uint64_t>(shadow_cap, A.s_shadow_cap);
+        }
         for (int i = 0; i < 2; i++) { if (ctx->d_rayq[i]) (void)hipFree(ctx->d_rayq[i]); ctx->d_rayq[i] = nullptr; }
         if (ctx->d_shadowq) (void)hipFree(ctx->d_shadowq);
         if (ctx->d_occluded) (void)hipFree(ctx->d_occluded);
         if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
         ctx->d_shadowq = nullptr; ctx->d_occluded = nullptr; ctx->d_nodes = nullptr;
         ctx->stream_items = 0;
-        const uint64_t px = (uint64_t)n_items * 64;
-        uint64_t node_cap = px * 4 < (1u << 20) ? (1u << 20) : px * 4;
-        uint64_t ray_cap = px * 3 < (1u << 20) ? (1u << 20) : px * 3;
-        uint64_t shadow_cap = node_cap * (ctx->n_lights ? ctx->n_lights : 1);
-        // explicit capacities (crt_tuning): never below what level 0 itself needs, so that only the deeper levels can overflow
-        if (ctx->tuning.node_cap) node_cap = ctx->tuning.node_cap < px ? px : ctx->tuning.node_cap;
-        if (ctx->tuning.ray_cap) ray_cap = ctx->tuning.ray_cap;
-        if (ctx->tuning.shadow_cap) shadow_cap = ctx->tuning.shadow_cap;
-        if (node_cap > 0x7FFFFFF0ull) node_cap = 0x7FFFFFF0ull;
-        if (ray_cap > 0x7FFFFFF0ull) ray_cap = 0x7FFFFFF0ull;
-        if (shadow_cap > 0x7FFFFFF0ull) shadow_cap = 0x7FFFFFF0ull;
-        if (px > node_cap) { ctx->error = "frame too large for the ray-stream buffers"; return CRT_ERR_INVALID; }
+        A.s_node_cap = A.s_ray_cap = A.s_shadow_cap = 0;
         for (int i = 0; i < 2; i++) CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_rayq[i], ray_cap * 2 * sizeof(float4)));
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_shadowq, shadow_cap * 2 * sizeof(float4)));
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_occluded, shadow_cap));
@@ -1011,6 +1076,10 @@ static int ensure_stream(crt_ctx *ctx, uint32_t n_items) {
         ctx->d_ready = nullptr;
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_ready, ray_cap * sizeof(uint32_t)));
         CRT_HIP_CHECK(ctx, hipMemset(ctx->d_ready, 0, ray_cap * sizeof(uint32_t)));  // no epoch is 0
+        if (ctx->d_ready2) (void)hipFree(ctx->d_ready2);
+        ctx->d_ready2 = nullptr;
+        CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_ready2, ray_cap * sizeof(uint32_t)));
+        CRT_HIP_CHECK(ctx, hipMemset(ctx->d_ready2, 0, ray_cap * sizeof(uint32_t)));
         if (ctx->d_heavy) (void)hipFree(ctx->d_heavy);
         if (ctx->d_sheavy) (void)hipFree(ctx->d_sheavy);
         if (ctx->d_hits) (void)hipFree(ctx->d_hits);
@@ -1018,19 +1087,23 @@ static int ensure_stream(crt_ctx *ctx, uint32_t n_items) {
         if (ctx->d_todo_shadow) (void)hipFree(ctx->d_todo_shadow);
         ctx->d_heavy = nullptr; ctx->d_sheavy = nullptr; ctx->d_hits = nullptr; ctx->d_todo_tiles = nullptr; ctx->d_todo_shadow = nullptr;
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_todo_tiles, ((size_t)n_items + 1) * sizeof(uint32_t)));
-        CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_todo_shadow, (size_t)shadow_cap * sizeof(uint32_t)));
-        ctx->heavy_cap = (uint32_t)(px < (1u << 20) ? (1u << 20) : px);
+        // (the list of abandoned shadow walks is only written when level 0 runs as packets)
+        CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_todo_shadow, (ctx->packet_budget ? (size_t)shadow_cap : 1) * sizeof(uint32_t)));
+        ctx->heavy_cap = (uint32_t)std::max<uint64_t>(floor_cap, std::max<uint64_t>(px, ray_cap));
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_heavy, (size_t)ctx->heavy_cap * sizeof(uint32_t)));
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_sheavy, (size_t)ctx->heavy_cap * sizeof(uint32_t)));
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_hits, (size_t)ctx->heavy_cap * sizeof(float4)));
         A.s_ray_cap = (uint32_t)ray_cap; A.s_shadow_cap = (uint32_t)shadow_cap; A.s_node_cap = (uint32_t)node_cap;
         ctx->stream_items = n_items;
+        ctx->queue_bytes = ray_cap * 64 + shadow_cap * 33 + node_cap * 32 + ray_cap * 8 + (size_t)ctx->heavy_cap * 24 +
+                           (ctx->packet_budget ? shadow_cap * 4 : 4) + ((size_t)n_items + 1) * 4;
     }
     A.s_rayq[0] = ctx->d_rayq[0]; A.s_rayq[1] = ctx->d_rayq[1];
     A.s_shadowq = ctx->d_shadowq; A.s_occluded = ctx->d_occluded; A.s_nodes = ctx->d_nodes;
     A.s_heavy = ctx->d_heavy; A.s_sheavy = ctx->d_sheavy; A.s_hits = ctx->d_hits; A.s_heavy_cap = ctx->heavy_cap;
     A.s_todo_tiles = ctx->d_todo_tiles; A.s_todo_shadow = ctx->d_todo_shadow;
     A.s_ready = ctx->d_ready;
+    A.s_ready2 = ctx->d_ready2;
     return CRT_OK;
 }
 
@@ -1136,7 +1209,8 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         }
         // the same reasoning for level 0 (one launch over all primary rays, ~70 steps per ray)
         const uint64_t est0 = (uint64_t)n_items * 64u * 70u / ((uint64_t)lane_blocks * BLOCK);
-        const uint32_t budget0 = est0 >= ctx->step_budget ? ctx->step_budget : (est0 < 64u ? 64u : (uint32_t)est0);
+        uint32_t budget0 = est0 >= ctx->step_budget ? ctx->step_budget : (est0 < 64u ? 64u : (uint32_t)est0);
+        if (ctx->tuning.level0_budget && ctx->tuning.level0_budget < budget0) budget0 = ctx->tuning.level0_budget;
         // the recursion levels >= 1: one persistent queue-driven launch (kernel_deep.h), or a launch triple per level
         const bool deep = heavy && ctx->tuning.deep && o->max_depth >= 1;
         ctx->epoch = ctx->epoch == 0xFFFFFFFFu ? 1u : ctx->epoch + 1u;
@@ -1178,7 +1252,12 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
             A.step_budget = ctx->step_budget;
             hipLaunchKernelGGL(deep_begin, dim3(1), dim3(64), 0, stream, A);
             const uint32_t deep_blocks = ctx->tuning.deep_blocks ? ctx->tuning.deep_blocks : (uint32_t)ctx->num_cus * 4u;
-            if (ctx->tuning.deep_waves == 4u) launch(deep_trace<4>, deep_blocks, stream, A);
+            A.deep_heavy_every = ctx->tuning.deep_heavy_every > 4u ? 4u : (ctx->tuning.deep_heavy_every < 2u ? 2u : ctx->tuning.deep_heavy_every);
+            if (ctx->tuning.deep == 2u && A.plan_ok) {  // one ray per lane, heavy waves for the long walks
+                if (ctx->tuning.deep_waves == 4u) launch_lds(deep_lanes<4>, deep_blocks, plds, stream, A);
+                else launch_lds(deep_lanes<3>, deep_blocks, plds, stream, A);
+            }
+            else if (ctx->tuning.deep_waves == 4u) launch(deep_trace<4>, deep_blocks, stream, A);
             else launch(deep_trace<5>, deep_blocks, stream, A);
         }
         CRT_HIP_CHECK(ctx, hipGetLastError());
@@ -1222,6 +1301,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         else launch(render_lanes<false>, lane_blocks, stream, A);
         CRT_HIP_CHECK(ctx, hipGetLastError());
         CRT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_overflow, ctx->d_fallback_total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        CRT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_scounts, SC_ALLOC_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         if (timed) CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev3[slot], stream));
     } else {
         if (ctx->mode == crt_ctx::MODE_PACKETS) {
@@ -1257,6 +1337,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
 static void note_overflow(crt_ctx *ctx) {
     if (ctx->h_overflow) ctx->overflows = *ctx->h_overflow;
     ctx->stats.fallback_frames = (uint32_t)ctx->overflows;
+    ctx->stats.queue_bytes = ctx->queue_bytes;
 }
 
 static int fetch_counters(crt_ctx *ctx, const crt_options *o, uint64_t pixels) {
@@ -1309,7 +1390,8 @@ static uint64_t coverage_items(uint32_t width, uint32_t height, const crt_rect *
     return pixels;
 }
 
-extern "C" int crt_render(crt_ctx *ctx, const crt_options *o, const crt_rect *rects, uint32_t n_rects, float *out_rgb) {
+// first half of crt_render / crt_render_async: everything up to (not including) the wait for the device
+static int render_enqueue(crt_ctx *ctx, const crt_options *o, const crt_rect *rects, uint32_t n_rects, float *out_rgb, uint8_t *out_rgb8) {
     if (!ctx) return CRT_ERR_INVALID;
     int rc = check_options(ctx, o);
     if (rc) return rc;
@@ -1330,29 +1412,72 @@ extern "C" int crt_render(crt_ctx *ctx, const crt_options *o, const crt_rect *re
         ctx->cached_n_items = (uint32_t)items.size();
         ctx->cached_pixels = pixels;
     }
-    hipEvent_t t0, t1;
-    CRT_HIP_CHECK(ctx, hipEventCreate(&t0));
-    CRT_HIP_CHECK(ctx, hipEventCreate(&t1));
-    CRT_HIP_CHECK(ctx, hipEventRecord(t0, ctx->stream));
+    if (!ctx->ev_call0) {
+        CRT_HIP_CHECK(ctx, hipEventCreate(&ctx->ev_call0));
+        CRT_HIP_CHECK(ctx, hipEventCreate(&ctx->ev_call1));
+    }
+    CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_call0, ctx->stream));
     rc = launch_render(ctx, o, ctx->cached_n_items, ctx->d_frame, 0, ctx->stream, true);
     if (rc) return rc;
-    if (out_rgb)
-        CRT_HIP_CHECK(ctx, hipMemcpyAsync(out_rgb, ctx->d_frame, (size_t)ctx->width * ctx->height * 3 * sizeof(float),
-                                          hipMemcpyDeviceToHost, ctx->stream));
-    CRT_HIP_CHECK(ctx, hipEventRecord(t1, ctx->stream));
+    const size_t values = (size_t)ctx->width * ctx->height * 3;
+    if (out_rgb) CRT_HIP_CHECK(ctx, hipMemcpyAsync(out_rgb, ctx->d_frame, values * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (out_rgb8) {  // PPMColor on the device (Color.cpp:12-16), a quarter of the bytes to copy
+        rc = crt_quantize_device(ctx, ctx->d_frame, values, ctx->d_quant, ctx->stream);
+        if (rc) return rc;
+        CRT_HIP_CHECK(ctx, hipMemcpyAsync(out_rgb8, ctx->d_quant, values, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_call1, ctx->stream));
+    ctx->pending = true;
+    ctx->pending_options = *o;
+    return CRT_OK;
+}
+
+// second half of crt_render / crt_wait: the frame enqueued by render_enqueue has to be finished before its statistics exist
+static int render_finish(crt_ctx *ctx) {
+    if (!ctx->pending) return CRT_OK;
+    CRT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     CRT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pending = false;
     float ms = 0;
     if (ctx->cached_n_items) {
         const int slot = (int)((ctx->launches - 1) % crt_ctx::EV_RING);
         CRT_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev0[slot], ctx->ev4[slot]));
         ctx->stats.kernel_ms = ms;
     } else ctx->stats.kernel_ms = 0;
-    CRT_HIP_CHECK(ctx, hipEventElapsedTime(&ms, t0, t1));
+    CRT_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev_call0, ctx->ev_call1));
     ctx->stats.total_ms = ms;
     note_overflow(ctx);
-    (void)hipEventDestroy(t0);
-    (void)hipEventDestroy(t1);
-    return fetch_counters(ctx, o, ctx->cached_pixels);
+    return fetch_counters(ctx, &ctx->pending_options, ctx->cached_pixels);
+}
+
+extern "C" int crt_render(crt_ctx *ctx, const crt_options *o, const crt_rect *rects, uint32_t n_rects, float *out_rgb) {
+    int rc = render_enqueue(ctx, o, rects, n_rects, out_rgb, nullptr);
+    if (rc) return rc;
+    return render_finish(ctx);
+}
+
+extern "C" int crt_render_async(crt_ctx *ctx, const crt_options *o, const crt_rect *rects, uint32_t n_rects, float *out_rgb,
+                                uint8_t *out_rgb8) {
+    if (ctx && ctx->pending) {  // one frame per context at a time: finish the previous one first
+        int rc = render_finish(ctx);
+        if (rc) return rc;
+    }
+    return render_enqueue(ctx, o, rects, n_rects, out_rgb, out_rgb8);
+}
+
+// pinned host memory for crt_render_async's outputs (callers of the C ABI need no HIP headers for it)
+extern "C" void *crt_alloc_pinned(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+extern "C" void crt_free_pinned(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
+extern "C" int crt_wait(crt_ctx *ctx) {
+    if (!ctx) return CRT_ERR_INVALID;
+    return render_finish(ctx);
 }
 
 extern "C" uint32_t crt_packed_tile_count(const crt_ctx *ctx, uint32_t first, uint32_t stride) {
@@ -1776,6 +1901,7 @@ extern "C" int crt_multi_render(crt_multi *M, const crt_options *o, const crt_re
         total.shaded_hits += c->stats.shaded_hits; total.light_evals += c->stats.light_evals; total.texel_fetches += c->stats.texel_fetches;
         total.primary_rays += c->stats.primary_rays; total.secondary_rays += c->stats.secondary_rays; total.shadow_rays += c->stats.shadow_rays;
         total.fallback_frames += c->stats.fallback_frames;
+        total.queue_bytes += c->stats.queue_bytes;
     }
     total.pixels = M->pixels;
     total.total_ms = wall_ms;

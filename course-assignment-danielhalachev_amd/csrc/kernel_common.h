@@ -138,6 +138,8 @@ struct KernelArgs {
     // kernel_deep.h: the level-free queue of the recursion levels >= 1
     uint32_t tri_gather;          // kernel_plan.h shadow walk: lanes wait at a leaf until this many do (0: every trip runs both blocks)
     uint32_t *s_ready;            // one word per slot of s_rayq[1]: == epoch once the slot's record has been published
+    uint32_t *s_ready2;           // the same for the heavy queue (s_rayq[0] during the deep launch)
+    uint32_t deep_heavy_every;    // deep_lanes: every n-th wave of a workgroup is a heavy wave
     uint32_t epoch;               // this frame's tag (never 0; s_ready starts zeroed and is not cleared between frames)
 };
 

@@ -44,7 +44,8 @@ enum : int { SC_COUNT = 0, SC_FETCH = MAX_GENERATIONS, SC_HEAVY = 2 * MAX_GENERA
              SC_DEEP_TAIL0, SC_DEEP_CHAINED,  // kernel_deep.h
              SC_WORDS,
              // kernel_deep.h's hot counters, each on a 128-byte line of its own (atomics on one line are served one by one)
-             SC_DEEP_DONE = 384, SC_DEEP_NODES = 416, SC_DEEP_WAITS = 448, SC_ALLOC_WORDS = 512 };
+             SC_DEEP_HQ_HEAD = 352, SC_DEEP_DONE = 384, SC_DEEP_NODES = 416, SC_DEEP_WAITS = 448, SC_DEEP_HQ_TAIL = 480,
+             SC_ALLOC_WORDS = 512 };
 static_assert(SC_WORDS <= 352, "the deep kernel's counters start at word 384");
 
 static_assert(SC_OVERFLOW == SC_OVERFLOW_WORD, "kernel_common.h SC_OVERFLOW_WORD must match");

@@ -4,6 +4,7 @@
 #include <limits>
 #include <numeric>
 #include <stdexcept>
+#include <string>
 
 namespace crt {
 
@@ -87,7 +88,35 @@ void KDTree::build(const std::vector<BoundingBox> &elementBoxes, const BoundingB
   }
 }
 
-AccelerationStructure::AccelerationStructure(const Scene &scene) {
+void KDTree::buildOnDevice(int device, const std::vector<BoundingBox> &elementBoxes, const BoundingBox &rootBox, unsigned short maxDepth,
+                           unsigned short maxElementsInLeaf) {
+  std::vector<float> flat(elementBoxes.size() * 6);
+  for (size_t i = 0; i < elementBoxes.size(); i++)
+    for (unsigned short a = 0; a < 3; a++) { flat[6 * i + a] = elementBoxes[i].minPoint[a]; flat[6 * i + 3 + a] = elementBoxes[i].maxPoint[a]; }
+  const float root[6] = {rootBox.minPoint.x, rootBox.minPoint.y, rootBox.minPoint.z, rootBox.maxPoint.x, rootBox.maxPoint.y, rootBox.maxPoint.z};
+  crt_built_tree *t = nullptr;
+  if (crt_build_tree_device(device, flat.data(), (uint32_t)elementBoxes.size(), root, maxDepth, maxElementsInLeaf, &t) != CRT_OK)
+    throw std::runtime_error(std::string("crt_build_tree_device failed: ") + crt_build_last_error());
+  const uint32_t n = crt_built_tree_node_count(t);
+  const float *boxes = crt_built_tree_boxes(t);
+  const uint32_t *links = crt_built_tree_links(t), *idx = crt_built_tree_indexes(t);
+  nodes.clear();
+  nodes.resize(n);
+  size_t at = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    TreeNode &N = nodes[i];
+    N.box.minPoint = Vector(boxes[6 * (size_t)i], boxes[6 * (size_t)i + 1], boxes[6 * (size_t)i + 2]);
+    N.box.maxPoint = Vector(boxes[6 * (size_t)i + 3], boxes[6 * (size_t)i + 4], boxes[6 * (size_t)i + 5]);
+    N.children[0] = links[4 * (size_t)i];
+    N.children[1] = links[4 * (size_t)i + 1];
+    N.parent = links[4 * (size_t)i + 2];
+    N.indexes.assign(idx + at, idx + at + links[4 * (size_t)i + 3]);
+    at += links[4 * (size_t)i + 3];
+  }
+  crt_built_tree_free(t);
+}
+
+AccelerationStructure::AccelerationStructure(const Scene &scene, int buildDevice) {
   // reference: AccelerationStructure.cpp:27-50
   const size_t n = scene.objects.size();
   meshTrees.resize(n);
@@ -104,7 +133,9 @@ AccelerationStructure::AccelerationStructure(const Scene &scene) {
         meshBox.include(p);
         sceneBox.include(p);
       }
-    meshTrees[m].build(triBoxes, meshBox, 25, 8);  // TriangleKDTree defaults, AccelerationStructure.h:10-11
+    // TriangleKDTree defaults, AccelerationStructure.h:10-11
+    if (buildDevice >= 0 && triBoxes.size() >= 4096) meshTrees[m].buildOnDevice(buildDevice, triBoxes, meshBox, 25, 8);
+    else meshTrees[m].build(triBoxes, meshBox, 25, 8);
     meshBoxes[m] = meshTrees[m].nodes[0].box;       // ObjectKDTreeSubTree::getBoundingBox, AccelerationStructure.cpp:21-23
   }
   objectTree.build(meshBoxes, sceneBox, 25, 4);  // ObjectKDTree defaults, AccelerationStructure.h:25-26

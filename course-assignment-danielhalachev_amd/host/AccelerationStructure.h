@@ -36,6 +36,9 @@ struct KDTree {
   // elementBoxes[i] = box of element i; rootBox = box of the root node
   void build(const std::vector<BoundingBox> &elementBoxes, const BoundingBox &rootBox, unsigned short maxDepth,
              unsigned short maxElementsInLeaf);
+  // The same tree, built on GPU `device` (crt_hip.h: crt_build_tree_device) -- identical node for node.
+  void buildOnDevice(int device, const std::vector<BoundingBox> &elementBoxes, const BoundingBox &rootBox, unsigned short maxDepth,
+                     unsigned short maxElementsInLeaf);
 };
 
 // reference: AccelerationStructure.h:6-33 -- TriangleKDTree per mesh (depth 25, leaf 8) under an
@@ -43,7 +46,9 @@ struct KDTree {
 struct AccelerationStructure {
   std::vector<KDTree> meshTrees;
   KDTree objectTree;
-  explicit AccelerationStructure(const Scene &scene);
+  // buildDevice >= 0: the mesh trees are built on that GPU (meshes of fewer than 4096 triangles, and the tiny tree over the
+  // meshes, stay on the host: a launch sequence per level costs more than building them here)
+  explicit AccelerationStructure(const Scene &scene, int buildDevice = -1);
 };
 
 // Flat, device-ready copy of a scene and its tree; `desc` points into the vectors below.

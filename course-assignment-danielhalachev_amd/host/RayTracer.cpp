@@ -103,6 +103,8 @@ RayTracer::RayTracer(Scene &scene, int device, const crt_tuning *tuning)
   flattenScene(scene, accelerationStructure, flat);
   int rc = crt_create_tuned(&flat.desc, device, tuning, &ctx);
   if (rc != CRT_OK) throw std::runtime_error(std::string("crt_create failed: ") + crt_last_error(nullptr));
+  deviceIndex = device;
+  if (tuning) { tuningCopy = *tuning; haveTuning = true; }
   {  // the context starts with the scene's camera, as RayTracer::RayTracer copies scene.camera (RayTracer.cpp:46)
     const float pos[3] = {camera.getPosition().x, camera.getPosition().y, camera.getPosition().z};
     crt_set_camera(ctx, pos, &camera.getRotationMatrix().m[0][0]);
@@ -121,8 +123,62 @@ RayTracer::RayTracer(Scene &scene, const std::vector<int> &devices, const crt_tu
 }
 
 RayTracer::~RayTracer() {
+  for (size_t i = 0; i < ring.size(); i++) {
+    if (ring[i].busy) crt_wait(ring[i].ctx);
+    crt_free_pinned(ring[i].rgb8);
+    if (i > 0) crt_destroy(ring[i].ctx);
+  }
   crt_destroy(ctx);
   crt_multi_destroy(multi);
+}
+
+void RayTracer::setFramesInFlight(unsigned int k) {
+  if (multi) throw std::runtime_error("frames in flight: not available on a multi-device tracer");
+  if (k < 1) k = 1;
+  if (k > 8) k = 8;
+  const size_t bytes = (size_t)scene.sceneSettings.image.width * scene.sceneSettings.image.height * 3;
+  while (ring.size() < k) {
+    InFlight f;
+    if (ring.empty()) f.ctx = ctx;
+    else if (crt_create_tuned(&flat.desc, deviceIndex, haveTuning ? &tuningCopy : nullptr, &f.ctx) != CRT_OK)
+      throw std::runtime_error(std::string("crt_create failed: ") + crt_last_error(nullptr));
+    f.rgb8 = static_cast<uint8_t *>(crt_alloc_pinned(bytes));
+    if (!f.rgb8) { if (!ring.empty()) crt_destroy(f.ctx); throw std::runtime_error("out of pinned host memory"); }
+    ring.push_back(f);
+  }
+}
+
+int RayTracer::renderAsync(const RenderOptions &ro) {
+  if (ring.empty()) setFramesInFlight(2);
+  const int slot = (int)(ringNext % ring.size());
+  ringNext++;
+  InFlight &f = ring[(size_t)slot];
+  if (f.busy) { crt_wait(f.ctx); f.busy = false; }  // the slot's previous frame (its pixels are overwritten from here on)
+  crt_options o{};
+  o.max_depth = ro.MAX_DEPTH;
+  o.shadow_bias = ro.SHADOW_BIAS;
+  o.reflection_bias = ro.REFLECTION_BIAS;
+  o.refraction_bias = ro.REFRACTION_BIAS;
+  o.use_gi = ro.USE_GI ? 1u : 0u;
+  const Matrix3 &m = camera.getRotationMatrix();
+  const float pos[3] = {camera.getPosition().x, camera.getPosition().y, camera.getPosition().z};
+  int rc = crt_set_camera(f.ctx, pos, &m.m[0][0]);
+  const unsigned int W = scene.sceneSettings.image.width, H = scene.sceneSettings.image.height;
+  std::vector<crt_rect> rects = bucketRectangles(W, H, scene.sceneSettings.bucketSize, ro.optimization, std::thread::hardware_concurrency());
+  if (rc == CRT_OK) rc = crt_render_async(f.ctx, &o, rects.data(), (uint32_t)rects.size(), nullptr, f.rgb8);
+  if (rc != CRT_OK) throw std::runtime_error(std::string("renderAsync failed: ") + crt_last_error(f.ctx));
+  f.busy = true;
+  return slot;
+}
+
+const uint8_t *RayTracer::finishFrame(int slot) {
+  if (slot < 0 || (size_t)slot >= ring.size()) throw std::runtime_error("finishFrame: no such slot");
+  InFlight &f = ring[(size_t)slot];
+  if (f.busy) {
+    if (crt_wait(f.ctx) != CRT_OK) throw std::runtime_error(std::string("finishFrame failed: ") + crt_last_error(f.ctx));
+    f.busy = false;
+  }
+  return f.rgb8;
 }
 
 crt_stats RayTracer::stats() const {

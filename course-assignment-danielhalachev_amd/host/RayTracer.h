@@ -80,6 +80,16 @@ class RayTracer {
   std::vector<std::vector<Color>> render(const std::string &pathToImage, RenderOptions renderOptions = RenderOptions());
   void exportPPM(const std::string &pathToImage, const std::vector<std::vector<Color>> &colorBuffer);
 
+  // ---- frames in flight (animation: app/animation.cpp:24-38 renders frame after frame with a new camera each).
+  // setFramesInFlight(k) keeps the scene resident in k contexts; renderAsync() enqueues a frame with the CURRENT camera on
+  // the next one and returns its slot at once; finishFrame(slot) waits for that frame and returns its quantised pixels
+  // (H*W*3 bytes, PPMColor rule, valid until the slot is used again).  The GPU then works on frame k+1's primary rays while
+  // frame k's deepest recursion levels and its copy to the host drain.  render() is unaffected.
+  void setFramesInFlight(unsigned int k);
+  unsigned int framesInFlight() const { return (unsigned int)ring.size(); }
+  int renderAsync(const RenderOptions &renderOptions);
+  const uint8_t *finishFrame(int slot);
+
   // flat access for callers that do not want the vector-of-vectors copy
   int renderFlat(const std::string &pathToImage, const RenderOptions &renderOptions, float *outRGB, unsigned int counters = 0);
   crt_ctx *context() const { return multi ? crt_multi_context(multi, 0) : ctx; }
@@ -95,6 +105,12 @@ class RayTracer {
   FlatScene flat;
   crt_ctx *ctx = nullptr;
   crt_multi *multi = nullptr;  // set instead of ctx when the tracer was built for several devices
+  struct InFlight { crt_ctx *ctx = nullptr; uint8_t *rgb8 = nullptr; bool busy = false; };
+  std::vector<InFlight> ring;  // ring[0].ctx == ctx
+  unsigned int ringNext = 0;
+  int deviceIndex = 0;
+  crt_tuning tuningCopy{};
+  bool haveTuning = false;
   std::vector<float> frame;  // persistent colorBuffer (RayTracer.h:69)
 };
 

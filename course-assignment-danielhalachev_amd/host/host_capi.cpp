@@ -1,4 +1,5 @@
 // extern "C" wrappers of include/crt_host.h over the C++ host layer.  No exception leaves this file.
+#include <chrono>
 #include <cstring>
 #include <exception>
 #include <memory>
@@ -12,6 +13,7 @@
 #include "SceneParser.h"
 
 struct crt_host_scene {
+  double build_seconds = 0;  // tree build alone (AccelerationStructure's constructor)
   crt::Scene scene;
   std::unique_ptr<crt::AccelerationStructure> accel;
   crt::FlatScene flat;
@@ -43,8 +45,10 @@ static int guarded(F &&f) {
   }
 }
 
-static int finishScene(std::unique_ptr<crt_host_scene> hs, crt_host_scene **out) {
-  hs->accel.reset(new crt::AccelerationStructure(hs->scene));
+static int finishScene(std::unique_ptr<crt_host_scene> hs, crt_host_scene **out, int build_device = -1) {
+  const auto t0 = std::chrono::steady_clock::now();
+  hs->accel.reset(new crt::AccelerationStructure(hs->scene, build_device));
+  hs->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   crt::flattenScene(hs->scene, *hs->accel, hs->flat);
   *out = hs.release();
   return CRT_OK;
@@ -73,6 +77,19 @@ extern "C" int crt_host_scene_parse_text(const char *json, size_t length, const 
     return finishScene(std::move(hs), out);
   });
 }
+
+extern "C" int crt_host_scene_parse_text_ex(const char *json, size_t length, const char *folder, int build_device, crt_host_scene **out) {
+  if (!json || !out) return CRT_ERR_INVALID;
+  *out = nullptr;
+  return guarded([&]() {
+    std::unique_ptr<crt_host_scene> hs(new crt_host_scene());
+    crt::SceneParser parser;
+    hs->scene = parser.parseSceneText(std::string(json, length), folder ? folder : "");
+    return finishScene(std::move(hs), out, build_device);
+  });
+}
+
+extern "C" double crt_host_scene_build_seconds(const crt_host_scene *scene) { return scene ? scene->build_seconds : 0.0; }
 
 extern "C" void crt_host_scene_free(crt_host_scene *scene) { delete scene; }
 

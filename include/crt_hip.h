@@ -157,6 +157,8 @@ typedef struct crt_stats {
     uint32_t fallback_frames;  /* frames since crt_create whose ray queues overflowed and that were redone by the
                                 * queue-less kernel (same pixels, much slower): raise crt_tuning's *_cap if this grows.
                                 * Updated by the synchronous calls (crt_render, crt_kernel_times_ms, crt_synchronize). */
+    uint64_t queue_bytes;      /* device memory of the per-frame ray queues as allocated now (they follow the frames: they
+                                * grow when a frame came close to a capacity, and double after one that overflowed) */
 } crt_stats;
 
 typedef struct crt_ctx crt_ctx;
@@ -186,14 +188,17 @@ typedef struct crt_tuning {
     uint32_t node_cap, ray_cap, shadow_cap; /* 0 = sized from the frame (4x / 3x / n_lights x 4x the pixels, at least 2^20);
                                              * smaller values make queue overflow -- and the fallback -- reachable in tests */
     uint32_t deep;            /* 0: one launch triple per recursion level; 1: recursion levels >= 1 run as ONE persistent
-                               * queue-driven launch (no level barriers) */
+                               * queue-driven launch (no level barriers), one ray per wave; 2: the same with one ray per lane
+                               * and heavy waves for the long walks */
     uint32_t deep_blocks;     /* 0 (= 4 per CU): workgroups of that launch */
     uint32_t plan;            /* 1: the per-lane kernels evaluate a small top-level tree as a plan (its leaves tested in a
                                * wave-uniform loop) instead of walking it node by node per lane */
     uint32_t deep_waves;      /* 5: register budget of that launch in waves per SIMD (4 or 5) */
     uint32_t tri_gather;      /* 0: the planned shadow walk runs its triangle and its node block on every loop trip; N: one block
                                * per trip, lanes wait at a leaf until N of them do (fewer, fuller triangle trips) */
-    uint32_t reserved[3];
+    uint32_t deep_heavy_every; /* 4: deep == 2 only: every n-th wave of a workgroup (n = 2..4) takes the long walks, one ray per wave */
+    uint32_t level0_budget;   /* 0 (= step_budget): steps after which a PRIMARY ray's walk goes to the wave-per-ray kernel */
+    uint32_t reserved[1];
 } crt_tuning;
 void crt_tuning_defaults(crt_tuning *tuning);
 
@@ -213,6 +218,18 @@ int crt_set_camera(crt_ctx *ctx, const float position[3], const float matrix[9])
  * covered keep their previous value) and copies the whole H*W*3 float buffer (row 0 = top) to
  * `out_rgb` (host memory, may be NULL to skip the copy). */
 int crt_render(crt_ctx *ctx, const crt_options *options, const crt_rect *rects, uint32_t n_rects, float *out_rgb);
+
+/* The same without waiting for the device: the frame (and the copies to out_rgb -- float, H*W*3 -- and / or out_rgb8 --
+ * quantised bytes, PPMColor rule; either may be NULL; pinned host memory keeps the copies asynchronous) is enqueued and the
+ * call returns.  crt_wait finishes it and fills the statistics.  One frame per context at a time: a second crt_render_async
+ * first waits for the previous frame.  Frames IN FLIGHT together need one context each (the reference's animation driver,
+ * app/animation.cpp:24-38, renders frame after frame; crt::RayTracer::renderAsync alternates two contexts). */
+int crt_render_async(crt_ctx *ctx, const crt_options *options, const crt_rect *rects, uint32_t n_rects, float *out_rgb,
+                     uint8_t *out_rgb8);
+int crt_wait(crt_ctx *ctx);
+/* page-locked host memory for those outputs (NULL when it cannot be had) */
+void *crt_alloc_pinned(size_t bytes);
+void crt_free_pinned(void *p);
 
 /* Device-resident variants used by the multi-GPU tile partition.
  * The frame is cut into 8x8 pixel tiles, numbered row-major; this call renders tiles
@@ -272,6 +289,23 @@ uint32_t crt_multi_device_count(const crt_multi *multi);
 crt_ctx *crt_multi_context(crt_multi *multi, uint32_t part); /* part 0 holds the frame */
 const char *crt_multi_last_error(const crt_multi *multi);
 void crt_multi_destroy(crt_multi *multi);
+
+/* ---- the reference's tree built on the GPU (KDTree<T>::build, KDTree.cpp:10-46 / :89-125; BoundingBox.h:60-83): level by
+ * level, one thread per (node, element) entry, the same float operations as the reference's split and overlap test, so the
+ * result is the reference's tree node for node: same creation-order numbering, same boxes, same leaf lists.
+ * element_boxes: 6 floats per element (min xyz, max xyz); root_box likewise.  The built tree is read back through the
+ * accessors: boxes 6 floats per node, links 4 words per node (children[0], children[1], parent, number of leaf indexes; none
+ * = 0xFFFFFFFF), indexes = the leaves' lists concatenated in node order (the layout of crt_host_tree_dump, crt_host.h). */
+typedef struct crt_built_tree crt_built_tree;
+int crt_build_tree_device(int device, const float *element_boxes, uint32_t n_elements, const float root_box[6],
+                          uint32_t max_depth, uint32_t max_leaf, crt_built_tree **out);
+uint32_t crt_built_tree_node_count(const crt_built_tree *tree);
+uint64_t crt_built_tree_index_total(const crt_built_tree *tree);
+const float *crt_built_tree_boxes(const crt_built_tree *tree);
+const uint32_t *crt_built_tree_links(const crt_built_tree *tree);
+const uint32_t *crt_built_tree_indexes(const crt_built_tree *tree);
+void crt_built_tree_free(crt_built_tree *tree);
+const char *crt_build_last_error(void);
 
 /* After a render with collect_counters == 2 on the default (ray-stream) path: out = {box tests, triangle tests} the
  * production kernels executed in the whole render, then the same two for shadow pass 0 alone (the largest kernel).  Fewer than crt_stats' box_tests / tri_tests, which are the reference's: the kernels leave

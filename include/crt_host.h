@@ -29,6 +29,10 @@ enum {
 /* replaces SceneParser::parseScene (SceneParser.cpp:39-66); also builds and flattens the tree */
 int crt_host_scene_parse_file(const char *path_to_scene, const char *scene_folder, crt_host_scene **out);
 int crt_host_scene_parse_text(const char *json, size_t length, const char *scene_folder, crt_host_scene **out);
+/* the same with the big meshes' trees built on GPU `build_device` (crt_hip.h: crt_build_tree_device; < 0: on the host);
+ * crt_host_scene_build_seconds = the time the tree build took (the reference reports ~0.19 s, Images/HW14/README.md:11) */
+int crt_host_scene_parse_text_ex(const char *json, size_t length, const char *scene_folder, int build_device, crt_host_scene **out);
+double crt_host_scene_build_seconds(const crt_host_scene *scene);
 void crt_host_scene_free(crt_host_scene *scene);
 /* the flattened scene, ready for crt_create (owned by the scene handle) */
 const crt_scene_desc *crt_host_scene_desc(const crt_host_scene *scene);

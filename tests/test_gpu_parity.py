@@ -72,6 +72,10 @@ KERNEL_PATHS = [
     dict(deep=0, heavy_level=0),                                 # ... with the per-lane kernels at every level
     dict(deep=1, deep_blocks=3),                                 # persistent deep kernel on a tiny grid
     dict(deep=1, deep_waves=4, deep_blocks=4096),                # ... with its natural register budget, on a grid larger than the chip
+    dict(deep=2),                                                # persistent deep kernel, one ray per lane + heavy waves
+    dict(deep=2, step_budget=8),                                 # ... nearly every walk handed to the heavy waves
+    dict(deep=2, deep_blocks=2, deep_heavy_every=2, bundle=64),  # ... two workgroups, half the waves heavy, lanes refill one by one
+    dict(deep=2, deep_waves=4, deep_blocks=4096, bundle=0),      # ... a grid larger than the chip; lanes refill only when the wave is empty
     dict(top_in_registers=0, tiny_meshes=0),                     # top-level tree and single-leaf meshes read from memory
     dict(fixed0=0, bundle=64),                                   # level 0's shadow rays queued; lanes refill one by one
 ]
@@ -94,7 +98,7 @@ def test_queue_overflow_hands_the_frame_to_the_fallback(pkg, scenes, oracle, cap
     whole frame without queues.  Same pixels, and crt_stats says that the fallback ran."""
     scene, depth, _ = small_case(scenes, "hw11")
     want, _ = oracle.OracleScene(scenes.to_blob(scene)).render(depth)
-    for deep in (0, 1):
+    for deep in (0, 1, 2):
         tracer = make_tracer(pkg, scenes, scene, tuning=dict(caps, deep=deep))
         assert_same_floats(tracer.render(max_depth=depth), want, "overflow %r deep=%d" % (caps, deep))
         assert tracer.stats().fallback_frames == 1
@@ -111,17 +115,19 @@ def test_deep_queue_overflow_hands_the_frame_to_the_fallback(pkg, scenes, oracle
     SC_DEEP_TAIL0, SC_LEVEL1_SLOTS = 332, 1                                # csrc/kernel_stream.h
     scene, depth, _ = small_case(scenes, "hw11")
     want, _ = oracle.OracleScene(scenes.to_blob(scene)).render(depth)
-    roomy = make_tracer(pkg, scenes, scene)
+    roomy = make_tracer(pkg, scenes, scene, tuning=dict(deep=1))
     assert_same_floats(roomy.render(max_depth=depth), want, "roomy")
+    assert roomy.stats().fallback_frames == 0
     counts = roomy.stream_counts()
     level1, slots = int(counts[SC_DEEP_TAIL0]), int(counts[SC_LEVEL1_SLOTS])
     assert 0 < level1 < slots                                              # transmission rays were published behind level 1's
     pixels = scene["settings"]["image_settings"]["width"] * scene["settings"]["image_settings"]["height"]
     padded = ((scene["settings"]["image_settings"]["width"] + 7) // 8) * ((scene["settings"]["image_settings"]["height"] + 7) // 8) * 64
-    for caps in (dict(ray_cap=level1 + 7), dict(ray_cap=(level1 + slots) // 2), dict(node_cap=padded + level1 + 5)):
-        tracer = make_tracer(pkg, scenes, scene, tuning=dict(caps, deep=1))
-        assert_same_floats(tracer.render(max_depth=depth), want, "deep overflow %r" % (caps,))
-        assert tracer.stats().fallback_frames == 1, caps
+    for deep in (1, 2):
+        for caps in (dict(ray_cap=level1 + 7), dict(ray_cap=(level1 + slots) // 2), dict(node_cap=padded + level1 + 5)):
+            tracer = make_tracer(pkg, scenes, scene, tuning=dict(caps, deep=deep))
+            assert_same_floats(tracer.render(max_depth=depth), want, "deep overflow %r" % (caps,))
+            assert tracer.stats().fallback_frames == 1, (deep, caps)
     assert pixels <= padded
 
 
@@ -395,3 +401,58 @@ def test_multi_device_full_size(pkg, full_hw14):
     multi = pkg.Tracer(tracer.scene, devices=[0, 0, 0, 0])
     got = multi.render(max_depth=8)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_queue_capacities_follow_the_frames(pkg, scenes, oracle):
+    """Three of the room's walls are mirrors: more than two secondary rays per pixel, far more ray-tree nodes than the
+    queues are first sized for.  The first frames overflow and are redone by the queue-less kernel (same pixels); the
+    capacities double after each such frame, and from then on the frames fit."""
+    scene = scenes.make("hw11", width=256, height=192, detail=0.15)
+    kinds = [m["type"] for m in scene["materials"]]
+    mirror = kinds.index("reflective")
+    for o in scene["objects"][0:3]:                                       # three of the room's walls become mirrors
+        o["material_index"] = mirror
+    want, counters = oracle.OracleScene(scenes.to_blob(scene)).render(8)
+    assert counters["secondary_rays"] > 2 * 256 * 192                     # > 3 nodes per pixel: beyond the starting capacity
+    tracer = make_tracer(pkg, scenes, scene)
+    fallbacks, sizes = [], []
+    for frame in range(6):
+        assert_same_floats(tracer.render(max_depth=8), want, "frame %d" % frame)
+        st = tracer.stats()
+        fallbacks.append(st.fallback_frames)
+        sizes.append(st.queue_bytes)
+    assert fallbacks[0] == 1                                              # the first frame did not fit ...
+    assert fallbacks[-1] == fallbacks[-3] <= 3                            # ... the capacities grew, the later ones do
+    assert sizes == sorted(sizes) and sizes[-1] > sizes[0]
+
+
+def test_async_frames_equal_synchronous_ones(pkg, scenes, oracle):
+    """crt_render_async / crt_wait: frames enqueued without waiting, two contexts alternating (two frames in flight), give
+    the synchronous call's pixels; the quantised copy follows PPMColor."""
+    scene, depth, _ = small_case(scenes, "hw14")
+    hs = pkg.Scene(json_text=scenes.to_json(scene))
+    o = oracle.OracleScene(scenes.to_blob(scene))
+    ring = [pkg.Tracer(hs), pkg.Tracer(hs)]
+    opts = pkg.make_options(depth)
+    H, W = hs.height, hs.width
+    bufs = [(np.zeros((H, W, 3), np.float32), np.zeros((H, W, 3), np.uint8)) for _ in ring]
+    cams = [pkg.camera_apply(scene["camera"]["position"], scene["camera"]["matrix"], "pan", 7.0 * k) for k in range(5)]
+    pending = []
+    for k, (pos, mat) in enumerate(cams):
+        t = ring[k % 2]
+        if len(pending) == 2:                                             # the ring is full: collect the oldest frame first
+            j = pending.pop(0)
+            ring[j % 2].wait()
+            o.set_camera(*cams[j])
+            want, _ = o.render(depth)
+            assert_same_floats(bufs[j % 2][0], want, "async frame %d" % j)
+            assert np.array_equal(bufs[j % 2][1].astype(np.uint16), oracle.quantize(want))
+        t.set_camera(pos, mat)
+        t.render_async(opts, rgb=bufs[k % 2][0], rgb8=bufs[k % 2][1])
+        pending.append(k)
+    for j in pending:
+        ring[j % 2].wait()
+        o.set_camera(*cams[j])
+        want, _ = o.render(depth)
+        assert_same_floats(bufs[j % 2][0], want, "async frame %d" % j)
+    assert ring[0].stats().pixels == H * W and ring[0].stats().kernel_ms > 0
