@@ -389,6 +389,8 @@ extern "C" void crt_tuning_defaults(crt_tuning *t) {
     t->tri_gather = 0;
     t->deep_heavy_every = 4;
     t->level0_budget = 0;
+    t->node_repeat = 2;
+    t->heavy_waves = 5;
 }
 
 extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) { return crt_create_tuned(s, device, nullptr, out); }
@@ -1192,6 +1194,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
             hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, stream, A, (uint32_t)SC_SHADOW_SPLIT, (uint32_t)SC_SHADOW);
         }
         A.tri_gather = ctx->tuning.tri_gather > 64u ? 64u : ctx->tuning.tri_gather;
+        A.node_repeat = ctx->tuning.node_repeat < 1u ? 1u : (ctx->tuning.node_repeat > 8u ? 8u : ctx->tuning.node_repeat);
         KernelArgs S = A;  // argument block of the shadow passes
         S.counters = ctx->d_counters + C_N;
         S.bundle = ctx->bundle;
@@ -1210,7 +1213,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         // the same reasoning for level 0 (one launch over all primary rays, ~70 steps per ray)
         const uint64_t est0 = (uint64_t)n_items * 64u * 70u / ((uint64_t)lane_blocks * BLOCK);
         uint32_t budget0 = est0 >= ctx->step_budget ? ctx->step_budget : (est0 < 64u ? 64u : (uint32_t)est0);
-        if (ctx->tuning.level0_budget && ctx->tuning.level0_budget < budget0) budget0 = ctx->tuning.level0_budget;
+        if (ctx->tuning.level0_budget) budget0 = ctx->tuning.level0_budget;
         // the recursion levels >= 1: one persistent queue-driven launch (kernel_deep.h), or a launch triple per level
         const bool deep = heavy && ctx->tuning.deep && o->max_depth >= 1;
         ctx->epoch = ctx->epoch == 0xFFFFFFFFu ? 1u : ctx->epoch + 1u;
@@ -1224,7 +1227,8 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
             else if (lean) launch(stream_trace_shade_lean<false>, lane_blocks, stream, A, g);
             else launch(stream_trace_shade<false>, lane_blocks, stream, A, g);
             if (heavy) {
-                launch(heavy_trace_closest, heavy_blocks, stream, A, g);
+                if (ctx->tuning.heavy_waves == 7u && g > 0) launch(heavy_trace_closest<7>, heavy_blocks, stream, A, g);
+                else launch(heavy_trace_closest<5>, heavy_blocks, stream, A, g);
                 launch(stream_shade_evicted<false>, 256u, stream, A, g);
             }
             if (g == 0 && !packets) hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, stream, A, (uint32_t)SC_SHADOW_SPLIT, (uint32_t)SC_SHADOW);

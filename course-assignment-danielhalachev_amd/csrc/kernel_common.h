@@ -136,6 +136,7 @@ struct KernelArgs {
     const float4 *pnodes;
     uint32_t plan_list_words;     // LDS words per lane of a closest-hit ray's mesh list: ceil(meshes / 4)
     // kernel_deep.h: the level-free queue of the recursion levels >= 1
+    uint32_t node_repeat;         // kernel_plan.h shadow walk: node steps per loop trip (>= 1)
     uint32_t tri_gather;          // kernel_plan.h shadow walk: lanes wait at a leaf until this many do (0: every trip runs both blocks)
     uint32_t *s_ready;            // one word per slot of s_rayq[1]: == epoch once the slot's record has been published
     uint32_t *s_ready2;           // the same for the heavy queue (s_rayq[0] during the deep launch)

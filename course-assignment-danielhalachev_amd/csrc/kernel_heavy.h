@@ -371,7 +371,9 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const TopRegs &T
 __device__ __forceinline__ float uniform_f(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
 
 // closest hits of the rays evicted from stream_trace_shade(gen); results go to s_hits[k] for list entry k
-__global__ __launch_bounds__(BLOCK) void heavy_trace_closest(const KernelArgs A, const uint32_t gen) {
+template <int WAVES_PER_SIMD>  // register budget: 5 = what the compiler takes by itself (91 VGPRs); 7 = 72 VGPRs with spills, which
+                               // lets three of these waves per SIMD (not two) sit beside the bulk shadow pass's four
+__global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void heavy_trace_closest(const KernelArgs A, const uint32_t gen) {
     const uint32_t lane = threadIdx.x & 63u;
     if (A.s_counts[SC_OVERFLOW]) return;
     const uint32_t count = stream_level_count(A, gen);

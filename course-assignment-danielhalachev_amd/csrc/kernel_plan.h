@@ -104,6 +104,25 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shadow_plan(const KernelAr
         if (!__ballot(state != ST_DONE)) break;
         if (state == ST_TRAVERSE) {
             bool done = false, occluded = false;
+            // one mesh-tree node (KDTree.cpp:53-74, BoundingBox.h:85-108), branch-free, the step to the next mesh folded in;
+            // false: no mesh is left, the walk is complete
+            auto node_step = [&]() -> bool {
+                if (wn == END) {
+                    if ((mlo | mhi) == 0u) return false;
+                    const uint32_t bit = mlo ? (uint32_t)__builtin_ctz(mlo) : 32u + (uint32_t)__builtin_ctz(mhi);
+                    if (mlo) mlo &= mlo - 1u; else mhi &= mhi - 1u;
+                    wn = root_of_bit[bit];
+                }
+                const float4 *N = reinterpret_cast<const float4 *>(nodes_b + (size_t)(uint32_t)(wn << 5));
+                const float4 q0 = N[0], q1 = N[1];
+                if (A.exec_count) nbox++;
+                const uint32_t miss = __float_as_uint(q0.w), link = __float_as_uint(q1.w);
+                const bool hit = slab_test_no_parallel(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
+                const bool leaf = is_leaf_link(link);
+                we = (hit && leaf) ? (link & ~LEAF) : NONE;
+                wn = (hit && !leaf) ? link : miss;
+                return true;
+            };
             for (int it = 0; it < 64; ++it) {
                 // What a trip costs the wave is its vector-memory instructions (a divergent gather occupies the vector L1 for
                 // ~64 cycles however few lanes take part): 4 for the triangle block, 2 for the node block.  With tri_gather
@@ -146,22 +165,18 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shadow_plan(const KernelAr
                     if (ok && t < INFINITY && shadow_hit_occludes(R, px, py, pz, light_dist)) { occluded = true; done = true; break; }
                 } else if (run_node) {
                     steps++;
-                    if (wn == END) {  // the next mesh, or the end of the walk
-                        if ((mlo | mhi) == 0u) { done = true; break; }
-                        const uint32_t bit = mlo ? (uint32_t)__builtin_ctz(mlo) : 32u + (uint32_t)__builtin_ctz(mhi);
-                        if (mlo) mlo &= mlo - 1u; else mhi &= mhi - 1u;
-                        wn = root_of_bit[bit];
-                    }
-                    // ---- one mesh-tree node (KDTree.cpp:53-74, BoundingBox.h:85-108), branch-free
-                    const float4 *N = reinterpret_cast<const float4 *>(nodes_b + (size_t)(uint32_t)(wn << 5));
-                    const float4 q0 = N[0], q1 = N[1];
-                    if (A.exec_count) nbox++;
-                    const uint32_t miss = __float_as_uint(q0.w), link = __float_as_uint(q1.w);
-                    const bool hit = slab_test_no_parallel(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
-                    const bool leaf = is_leaf_link(link);
-                    we = (hit && leaf) ? (link & ~LEAF) : NONE;
-                    wn = (hit && !leaf) ? link : miss;
+                    if (!node_step()) { done = true; break; }
                 }
+                // Further node steps in the same trip for the lanes that are (still) between leaves: a ray takes about two
+                // node steps per triangle step, and a node step costs the wave a third of a triangle step, so a trip of
+                // [triangle, node, node] keeps more lanes busy in the expensive block than [triangle, node] does.
+                for (uint32_t rep = 1; rep < A.node_repeat; rep++) {
+                    if (we == NONE && !(A.tri_gather && !run_node)) {
+                        steps++;
+                        if (!node_step()) { done = true; break; }
+                    }
+                }
+                if (done) break;
             }
             if (done) {
                 A.s_occluded[r] = occluded ? 1 : 0;

@@ -197,8 +197,11 @@ typedef struct crt_tuning {
     uint32_t tri_gather;      /* 0: the planned shadow walk runs its triangle and its node block on every loop trip; N: one block
                                * per trip, lanes wait at a leaf until N of them do (fewer, fuller triangle trips) */
     uint32_t deep_heavy_every; /* 4: deep == 2 only: every n-th wave of a workgroup (n = 2..4) takes the long walks, one ray per wave */
-    uint32_t level0_budget;   /* 0 (= step_budget): steps after which a PRIMARY ray's walk goes to the wave-per-ray kernel */
-    uint32_t reserved[1];
+    uint32_t level0_budget;   /* 0 (= min(step_budget, what a lane gets through in the launch)): steps after which a PRIMARY ray's
+                               * walk goes to the wave-per-ray kernel */
+    uint32_t node_repeat;     /* 2: node steps per loop trip of the planned shadow walk (one triangle step per trip) */
+    uint32_t heavy_waves;     /* 5: register budget of the deeper levels' wave-per-ray launches in waves per SIMD (5 or 7) */
+    uint32_t reserved[3];
 } crt_tuning;
 void crt_tuning_defaults(crt_tuning *tuning);
 

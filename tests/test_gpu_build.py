@@ -19,10 +19,10 @@ def _trees(scene_handle):
     return out
 
 
-@pytest.mark.parametrize("name", ["hw07", "hw08", "hw11", "hw14", "hw12"])
-def test_device_built_trees_equal_the_host_builders(pkg, scenes, name, tmp_path):
-    # mid-size instances: every mesh above the 4096-triangle threshold goes through the GPU builder
-    scene = scenes.make(name, detail=0.3, **({"bitmap_size": 64} if name == "hw12" else {}))
+@pytest.mark.parametrize("name,detail", [("hw07", 1.0), ("hw08", 1.0), ("hw11", 1.0), ("hw14", 0.3), ("hw12", 0.5)])
+def test_device_built_trees_equal_the_host_builders(pkg, scenes, name, detail, tmp_path):
+    # every mesh of 4096 triangles and more goes through the GPU builder, the small ones (and HW07 / HW08 whole) stay on the host
+    scene = scenes.make(name, detail=detail, **({"bitmap_size": 64} if name == "hw12" else {}))
     folder = str(tmp_path)
     if scene.get("textures"):
         scenes.write_bitmaps(scene, folder)

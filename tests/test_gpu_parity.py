@@ -78,6 +78,8 @@ KERNEL_PATHS = [
     dict(deep=2, deep_waves=4, deep_blocks=4096, bundle=0),      # ... a grid larger than the chip; lanes refill only when the wave is empty
     dict(top_in_registers=0, tiny_meshes=0),                     # top-level tree and single-leaf meshes read from memory
     dict(fixed0=0, bundle=64),                                   # level 0's shadow rays queued; lanes refill one by one
+    dict(node_repeat=1), dict(node_repeat=4, tri_gather=24),     # shadow walk: node steps per trip, exclusive triangle trips
+    dict(heavy_waves=7),                                         # deeper levels' wave-per-ray launches on a 72-register budget
 ]
 
 
