@@ -242,17 +242,19 @@ def main():
         rs_ms = sum(t[3] + t[4] for t in kernel_ms) / n_k   # second shadow pass + wave-per-ray tail + resolve
         # SURVEY.md section 8(d) prices a box test at 32 B (24 B box + two 4 B links), a triangle test at 48 B
         # (three positions + the face normal) plus the 4 B leaf index entry that led to it.
-        def test_bytes(box, tri):
-            return 32 * box + 52 * tri
+        # A box test of a plan loop (kernel_plan.h: the ray against a top-level leaf whose box sits in scalar registers)
+        # fetches nothing per ray -- the 64-byte leaf record is loaded once per wave: 1 byte per test.
+        def test_bytes(box, tri, plan=0):
+            return 32 * box + 52 * tri + plan
         other = algorithmic_bytes(dict(counters, box_tests=0, tri_tests=0, leaf_index_reads=0), 0, 0, textured) + 12 * my_pixels
         b_ref_all = algorithmic_bytes(counters, 0, 0, textured) + 12 * my_pixels   # the REFERENCE's work for this frame
         b_ref_dom = algorithmic_bytes(ln_counters, 0, 0, textured)                  # ... and for the dominant kernel's rays
-        b_exec_dom = test_bytes(executed["shadow_pass0_box_tests"], executed["shadow_pass0_tri_tests"])
-        b_exec_all = test_bytes(executed["box_tests"], executed["tri_tests"]) + other
-        # The roofline object is for the DOMINANT KERNEL: the bulk shadow pass, one launch per frame that walks the
-        # level-0 shadow rays.  achieved = the bytes of the tests it EXECUTES (tallied by the kernel itself in the
+        b_exec_dom = test_bytes(executed["shadow_pass0_box_tests"], executed["shadow_pass0_tri_tests"], executed["shadow_pass0_plan_tests"])
+        b_exec_all = test_bytes(executed["box_tests"], executed["tri_tests"], executed["plan_tests"]) + other
+        # The roofline object is for the DOMINANT KERNEL: the bulk shadow pass (kernel_plan.h: stream_trace_shadow_plan<0>
+        # on the default path), one launch per frame that walks the level-0 shadow rays.  achieved = the bytes of the tests it EXECUTES (tallied by the kernel itself in the
         # collect_counters == 2 launch above) over its own duration from HIP events on the stream it runs on.
-        dom, dom_ms = "stream_trace_shadow_lean<0, false>", ln_ms
+        dom, dom_ms = tracer.kernels().get("shadow0", "stream_trace_shadow"), ln_ms
         achieved = b_exec_dom / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = None
         tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -282,9 +284,11 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": dom, "kernel_ms": round(dom_ms, 4),
                          "executed_bytes_per_launch": int(b_exec_dom),
-                         "executed": {"box_tests": executed["shadow_pass0_box_tests"], "tri_tests": executed["shadow_pass0_tri_tests"]},
+                         "executed": {"box_tests": executed["shadow_pass0_box_tests"], "tri_tests": executed["shadow_pass0_tri_tests"],
+                                      "plan_tests": executed["shadow_pass0_plan_tests"]},
                          "bound_note": "nominal: SURVEY.md section 8(d) prices this path against HBM bandwidth, and `achieved` is the "
-                                       "bytes of the box / triangle tests the kernel executes (32 B / 52 B each) over its duration.  The "
+                                       "bytes of the box / triangle tests the kernel executes (32 B / 52 B each; the tests of the plan "
+                                       "loop against wave-uniform top-level leaf boxes 1 B each) over its duration.  The "
                                        "kernel's real limiter is vector-instruction issue and the vector L1's handling of divergent 16-byte "
                                        "gathers, not HBM: the scene (a few MB) lives in L2 / Infinity Cache and `traffic` (PMC, fabric side) "
                                        "is a small fraction of the executed bytes -- see profiles/ and DESIGN.md section 4",
@@ -297,7 +301,8 @@ def main():
                          "whole_frame": {"executed_bytes": int(b_exec_all), "kernels_ms": round(avg_kernel_ms, 4),
                                          "achieved": round(b_exec_all / (avg_kernel_ms * 1e-3) / 1e9, 2),
                                          "frac": round(b_exec_all / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                         "executed": {"box_tests": executed["box_tests"], "tri_tests": executed["tri_tests"]},
+                                         "executed": {"box_tests": executed["box_tests"], "tri_tests": executed["tri_tests"],
+                                                      "plan_tests": executed["plan_tests"]},
                                          "reference_work_bytes": int(b_ref_all),
                                          "reference_work_rate_gbs": round(b_ref_all / (avg_kernel_ms * 1e-3) / 1e9, 2),
                                          "reference_counters": counters}},

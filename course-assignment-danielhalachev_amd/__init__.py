@@ -104,7 +104,7 @@ class Tuning(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "size", "mode", "step_budget", "shadow_budget", "pass1_budget", "heavy_level", "heavy_blocks", "side_blocks",
         "quad", "quad_stack", "prune", "bundle", "fixed0", "packet_budget", "path_mask", "top_in_registers",
-        "tiny_meshes", "node_cap", "ray_cap", "shadow_cap", "deep", "deep_blocks", "plan", "deep_waves", "tri_gather", "deep_heavy_every", "level0_budget", "node_repeat", "heavy_waves")] + [("reserved", C.c_uint32 * 3)]
+        "tiny_meshes", "node_cap", "ray_cap", "shadow_cap", "deep", "deep_blocks", "plan", "deep_waves", "tri_gather", "deep_heavy_every", "level0_budget", "node_repeat", "heavy_waves", "level_shadows", "pool", "pool_refill", "pool_switch")]
 
 
 def make_tuning(**fields):
@@ -132,7 +132,7 @@ def tuning_from_string(text):
 DEVICE_SYMBOLS = ["crt_tuning_defaults", "crt_create_tuned", "crt_create", "crt_set_camera", "crt_render", "crt_render_tiles_device", "crt_packed_tile_count",
                   "crt_unpack_tiles_device", "crt_quantize_device", "crt_read_quantized", "crt_kernel_elapsed_ms", "crt_kernel_times_ms",
                   "crt_get_stats", "crt_get_kernel_counters", "crt_synchronize", "crt_destroy", "crt_last_error", "crt_device_count", "crt_test_pow5",
-                  "crt_debug_stream_counts", "crt_debug_packet_counters", "crt_get_executed_counters",
+                  "crt_describe_kernels", "crt_debug_stream_counts", "crt_debug_packet_counters", "crt_get_executed_counters", "crt_get_executed_plan_tests",
                   "crt_render_async", "crt_wait", "crt_alloc_pinned", "crt_free_pinned",
                   "crt_build_tree_device", "crt_built_tree_node_count", "crt_built_tree_index_total", "crt_built_tree_boxes",
                   "crt_built_tree_links", "crt_built_tree_indexes", "crt_built_tree_free", "crt_build_last_error",
@@ -397,7 +397,12 @@ class Tracer:
         """{box_tests, tri_tests} the production kernels executed in the last render made with counters=2."""
         a = (C.c_uint64 * 4)()
         self._check(lib().crt_get_executed_counters(self.ctx, a))
-        return {"box_tests": int(a[0]), "tri_tests": int(a[1]), "shadow_pass0_box_tests": int(a[2]), "shadow_pass0_tri_tests": int(a[3])}
+        b = (C.c_uint64 * 2)()
+        L = lib()
+        L.crt_get_executed_plan_tests.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        self._check(L.crt_get_executed_plan_tests(self.ctx, b))
+        return {"box_tests": int(a[0]), "tri_tests": int(a[1]), "shadow_pass0_box_tests": int(a[2]), "shadow_pass0_tri_tests": int(a[3]),
+                "plan_tests": int(b[0]), "shadow_pass0_plan_tests": int(b[1])}
 
     def kernel_counters(self):
         """(packet-kernel counters, lane-kernel counters) of the last counted render, as dicts."""
@@ -453,12 +458,20 @@ class Tracer:
     def wait(self):
         self._check(lib().crt_wait(self.ctx))
 
+    def kernels(self):
+        """{'level0': ..., 'shadow0': ..., 'levels': ...}: the kernels a production frame runs (names as rocprofv3 prints them)."""
+        buf = C.create_string_buffer(512)
+        L = lib()
+        L.crt_describe_kernels.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        self._check(L.crt_describe_kernels(self.ctx, buf, 512))
+        return dict(kv.split("=", 1) for kv in buf.value.decode().split(";"))
+
     def stream_counts(self):
         """Diagnostics: the ray-stream pass's counter block of the last frame (SC_* layout of csrc/kernel_stream.h)."""
-        out = (C.c_uint32 * 512)()
+        out = (C.c_uint32 * 1024)()
         L = lib()
         L.crt_debug_stream_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]
-        self._check(L.crt_debug_stream_counts(self.ctx, out, 512))
+        self._check(L.crt_debug_stream_counts(self.ctx, out, 1024))
         return np.array(out[:], dtype=np.uint32)
 
     def read_quantized(self):

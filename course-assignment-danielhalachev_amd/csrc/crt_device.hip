@@ -52,6 +52,7 @@ namespace {
 #include "kernel_heavy.h"
 #include "kernel_plan.h"
 #include "kernel_deep.h"
+#include "kernel_pool.h"
 
 // scatter gathered packed tiles into the row-major frame
 __global__ void unpack_kernel(const float *packed, uint32_t n_parts, uint64_t part_stride, float *frame, uint32_t width,
@@ -130,7 +131,7 @@ struct crt_ctx {
     float4 *d_nodes = nullptr;
     uint32_t *d_scounts = nullptr;
     unsigned long long *d_exec = nullptr;           // executed-test tallies of a collect_counters == 2 render
-    unsigned long long exec_counters[4] = {0, 0, 0, 0};
+    unsigned long long exec_counters[6] = {0, 0, 0, 0, 0, 0};  // {box, tri} x {all but shadow pass 0, shadow pass 0}, plan tests x the same
     uint32_t *h_overflow = nullptr;   // pinned copy of d_fallback_total, refreshed after every frame
     uint32_t *d_fallback_total = nullptr;  // frames redone by the queue-less kernel since crt_create
     uint32_t *d_heavy = nullptr;      // evicted ray ids
@@ -147,6 +148,7 @@ struct crt_ctx {
     uint32_t *h_counts = nullptr;     // pinned copy of the last frame's counter block (d_scounts)
     uint32_t sizing_seen_fallbacks = 0, last_items = 0;
     uint64_t queue_bytes = 0;         // bytes of the per-frame buffers as allocated now
+    hipEvent_t ev_level[MAX_GENERATIONS] = {};  // level g is done (its shadow rays may start on the side stream)
     hipEvent_t ev_call0 = nullptr, ev_call1 = nullptr;  // around the last crt_render / crt_render_async call's device work
     bool pending = false;             // a frame enqueued by crt_render_async has not been waited for
     crt_options pending_options{};
@@ -391,6 +393,8 @@ extern "C" void crt_tuning_defaults(crt_tuning *t) {
     t->level0_budget = 0;
     t->node_repeat = 2;
     t->heavy_waves = 5;
+    t->level_shadows = 0;
+    t->pool = 0; t->pool_refill = 48; t->pool_switch = 24;
 }
 
 extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) { return crt_create_tuned(s, device, nullptr, out); }
@@ -885,10 +889,10 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
     ctx->quad_stack_depth = tune.quad_stack < 4 ? 4 : (tune.quad_stack > 60 ? 60 : tune.quad_stack);  // 60 KB of the workgroup's 64 KB
     ctx->side_blocks_per_cu = tune.side_blocks;
     ctx->shadow_budget = tune.shadow_budget;
-    CK(hipMalloc((void **)&ctx->d_exec, 4 * sizeof(unsigned long long)));
-    CK(hipMemset(ctx->d_exec, 0, 4 * sizeof(unsigned long long)));
-    CK(hipMalloc((void **)&ctx->d_scounts, 512 * sizeof(uint32_t)));
-    CK(hipMemset(ctx->d_scounts, 0, 512 * sizeof(uint32_t)));
+    CK(hipMalloc((void **)&ctx->d_exec, 6 * sizeof(unsigned long long)));
+    CK(hipMemset(ctx->d_exec, 0, 6 * sizeof(unsigned long long)));
+    CK(hipMalloc((void **)&ctx->d_scounts, SC_ALLOC_WORDS * sizeof(uint32_t)));
+    CK(hipMemset(ctx->d_scounts, 0, SC_ALLOC_WORDS * sizeof(uint32_t)));
     CK(hipHostMalloc((void **)&ctx->h_overflow, sizeof(uint32_t)));
     *ctx->h_overflow = 0;
     CK(hipHostMalloc((void **)&ctx->h_counts, SC_ALLOC_WORDS * sizeof(uint32_t)));
@@ -942,6 +946,7 @@ extern "C" void crt_destroy(crt_ctx *ctx) {
         if (ctx->ev_s1[i]) (void)hipEventDestroy(ctx->ev_s1[i]);
         if (ctx->ev_s2[i]) (void)hipEventDestroy(ctx->ev_s2[i]);
     }
+    for (int g = 0; g < MAX_GENERATIONS; g++) if (ctx->ev_level[g]) (void)hipEventDestroy(ctx->ev_level[g]);
     if (ctx->ev_call0) (void)hipEventDestroy(ctx->ev_call0);
     if (ctx->ev_call1) (void)hipEventDestroy(ctx->ev_call1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1171,7 +1176,8 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         A.prune = ctx->prune;
         A.exec_count = exec_count ? 1u : 0u;
         A.exec_counters = ctx->d_exec;
-        if (exec_count) CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_exec, 0, 4 * sizeof(unsigned long long), stream));
+        A.exec_plan = ctx->d_exec + 4;
+        if (exec_count) CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_exec, 0, 6 * sizeof(unsigned long long), stream));
         // the plan kernels (kernel_plan.h) pay a wave-uniform loop per refill, whatever the number of new rays: refill in bundles
         A.bundle = (A.plan_ok && ctx->bundle < 64u) ? ctx->bundle : 64u;
         A.fixed0 = 0;
@@ -1193,12 +1199,15 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
             launch(stream_packets_gen0, need < ctx->grid_blocks ? need : ctx->grid_blocks, stream, A);
             hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, stream, A, (uint32_t)SC_SHADOW_SPLIT, (uint32_t)SC_SHADOW);
         }
+        A.pool_refill = ctx->tuning.pool_refill < 1u ? 1u : (ctx->tuning.pool_refill > 64u ? 64u : ctx->tuning.pool_refill);
+        A.pool_switch = ctx->tuning.pool_switch > 64u ? 64u : ctx->tuning.pool_switch;
         A.tri_gather = ctx->tuning.tri_gather > 64u ? 64u : ctx->tuning.tri_gather;
         A.node_repeat = ctx->tuning.node_repeat < 1u ? 1u : (ctx->tuning.node_repeat > 8u ? 8u : ctx->tuning.node_repeat);
         KernelArgs S = A;  // argument block of the shadow passes
         S.counters = ctx->d_counters + C_N;
         S.bundle = ctx->bundle;
         S.exec_counters = ctx->d_exec + 2;  // shadow pass 0 tallies on its own
+        S.exec_plan = ctx->d_exec + 5;
         {
             // Pass 0 is one persistent launch: it ends when its longest walk ends, so the budget after which a walk is
             // handed to heavy_trace_shadow should be about the steps one lane gets through in the whole launch --
@@ -1218,6 +1227,19 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         const bool deep = heavy && ctx->tuning.deep && o->max_depth >= 1;
         ctx->epoch = ctx->epoch == 0xFFFFFFFFu ? 1u : ctx->epoch + 1u;
         A.epoch = ctx->epoch;
+        // the deeper levels' shadow rays level by level on the side stream (plan kernels only), or all at once at the end
+        const bool level_shadows = lean && A.plan_ok && !(quad & 4u) && ctx->side_blocks_per_cu && !deep && !packets && ctx->tuning.level_shadows;
+        const uint32_t level_shadow_blocks = (uint32_t)ctx->num_cus * 2u;
+        KernelArgs SL = S;  // their argument block: the second pass's budget (few rays, all tail)
+        {
+            const uint64_t est1 = (uint64_t)n_items * 16u * 130u / ((uint64_t)lane_blocks * BLOCK);
+            const uint32_t env1 = ctx->pass1_budget ? ctx->pass1_budget : ctx->step_budget;
+            SL.step_budget = heavy ? (est1 >= env1 ? env1 : (est1 < 64u ? 64u : (uint32_t)est1)) : 0u;
+            SL.counters = ctx->d_counters + 2 * C_N;
+            SL.bundle = A.bundle;
+            SL.exec_counters = ctx->d_exec;
+            SL.exec_plan = ctx->d_exec + 4;
+        }
         for (uint32_t g = 0; g <= (deep ? 0u : o->max_depth); g++) {
             A.step_budget = heavy ? (g == 0 ? budget0 : ctx->step_budget) : 0u;
             if (count) launch(stream_trace_shade<true>, lane_blocks, stream, A, g);
@@ -1232,6 +1254,17 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
                 launch(stream_shade_evicted<false>, 256u, stream, A, g);
             }
             if (g == 0 && !packets) hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, stream, A, (uint32_t)SC_SHADOW_SPLIT, (uint32_t)SC_SHADOW);
+            if (level_shadows) {
+                // where level g's shadow rays end; from level 1 on they are walked on the side stream while the next level runs
+                hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, stream, A, (uint32_t)(SC_LSPLIT + g + 1), (uint32_t)SC_SHADOW);
+                if (g >= 1) {
+                    if (!ctx->ev_level[g]) CRT_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_level[g], hipEventDisableTiming));
+                    CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_level[g], stream));
+                    CRT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_level[g], 0));
+                    if (ctx->tuning.pool & 2u) launch_lds(stream_trace_shadow_pool_level, level_shadow_blocks, POOL_LDS_BYTES, ctx->side, SL, g);
+                    else launch(stream_trace_shadow_level, level_shadow_blocks, ctx->side, SL, g);
+                }
+            }
             if (g == 0 && ctx->side_blocks_per_cu) {
                 // 2a) the shadow rays level 0 queued (the bulk of them) start now, beside the deeper levels
                 CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork[slot], stream));
@@ -1241,6 +1274,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
                 const uint32_t side_blocks = (uint32_t)ctx->num_cus * ctx->side_blocks_per_cu;
                 if (count) launch(stream_trace_shadow<true>, side_blocks, ctx->side, S, 0u);
                 else if (lean && (quad & 2u)) launch_lds(stream_trace_shadow_lean<0, true>, side_blocks, qlds, ctx->side, S);
+                else if (lean && A.plan_ok && ctx->tuning.pool) launch_lds(stream_trace_shadow_pool<0>, side_blocks, POOL_LDS_BYTES, ctx->side, S);
                 else if (lean && A.plan_ok) launch(stream_trace_shadow_plan<0>, side_blocks, ctx->side, S);
                 else if (lean) launch(stream_trace_shadow_lean<0, false>, side_blocks, ctx->side, S);
                 else launch(stream_trace_shadow<false>, side_blocks, ctx->side, S, 0u);
@@ -1270,6 +1304,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
             CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s0[slot], stream));
             if (count) launch(stream_trace_shadow<true>, ctx->grid_blocks, stream, S, 0u);
             else if (lean && (quad & 2u)) launch_lds(stream_trace_shadow_lean<0, true>, ctx->grid_blocks, qlds, stream, S);
+            else if (lean && A.plan_ok && ctx->tuning.pool) launch_lds(stream_trace_shadow_pool<0>, ctx->grid_blocks, POOL_LDS_BYTES, stream, S);
             else if (lean && A.plan_ok) launch(stream_trace_shadow_plan<0>, ctx->grid_blocks, stream, S);
             else if (lean) launch(stream_trace_shadow_lean<0, false>, ctx->grid_blocks, stream, S);
             else launch(stream_trace_shadow<false>, ctx->grid_blocks, stream, S, 0u);
@@ -1280,6 +1315,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         S.counters = ctx->d_counters + 2 * C_N;
         S.bundle = A.bundle;
         S.exec_counters = ctx->d_exec;
+        S.exec_plan = ctx->d_exec + 4;
         {
             // few rays, all tail: the short budget of the levels, or less when this launch is small (the deeper levels
             // queue about a quarter of a shadow ray per pixel on the benchmark scenes)
@@ -1287,8 +1323,13 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
             const uint32_t env1 = ctx->pass1_budget ? ctx->pass1_budget : ctx->step_budget;
             S.step_budget = heavy ? (est1 >= env1 ? env1 : (est1 < 64u ? 64u : (uint32_t)est1)) : 0u;
         }
-        if (count) launch(stream_trace_shadow<true>, lane_blocks, stream, S, 1u);
+        if (level_shadows) {
+            // every level's shadow rays are on the side stream already: wait for the last of them
+            CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s2[slot], ctx->side));
+        }
+        else if (count) launch(stream_trace_shadow<true>, lane_blocks, stream, S, 1u);
         else if (lean && (quad & 4u)) launch_lds(stream_trace_shadow_lean<1, true>, lane_blocks, qlds, stream, S);
+        else if (lean && A.plan_ok && (ctx->tuning.pool & 2u)) launch_lds(stream_trace_shadow_pool<1>, lane_blocks, POOL_LDS_BYTES, stream, S);
         else if (lean && A.plan_ok) launch(stream_trace_shadow_plan<1>, lane_blocks, stream, S);
         else if (lean) launch(stream_trace_shadow_lean<1, false>, lane_blocks, stream, S);
         else launch(stream_trace_shadow<false>, lane_blocks, stream, S, 1u);
@@ -1622,12 +1663,19 @@ extern "C" int crt_get_executed_counters(crt_ctx *ctx, uint64_t out[4]) {
     return CRT_OK;
 }
 
+extern "C" int crt_get_executed_plan_tests(crt_ctx *ctx, uint64_t out[2]) {
+    if (!ctx || !out) return CRT_ERR_INVALID;
+    out[0] = ctx->exec_counters[4] + ctx->exec_counters[5];  // the whole render
+    out[1] = ctx->exec_counters[5];                          // of which shadow pass 0
+    return CRT_OK;
+}
+
 // diagnostics: the ray-stream pass's counters of the last frame (SC_* layout of kernel_stream.h)
 extern "C" int crt_debug_stream_counts(crt_ctx *ctx, uint32_t *out, uint32_t max_words) {
     if (!ctx || !out) return CRT_ERR_INVALID;
     CRT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     CRT_HIP_CHECK(ctx, hipDeviceSynchronize());
-    const uint32_t n = max_words < 512u ? max_words : 512u;
+    const uint32_t n = max_words < (uint32_t)SC_ALLOC_WORDS ? max_words : (uint32_t)SC_ALLOC_WORDS;
     CRT_HIP_CHECK(ctx, hipMemcpy(out, ctx->d_scounts, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return CRT_OK;
 }
@@ -1636,6 +1684,30 @@ extern "C" int crt_debug_stream_counts(crt_ctx *ctx, uint32_t *out, uint32_t max
 extern "C" int crt_debug_packet_counters(crt_ctx *ctx, uint64_t out[3]) {
     if (!ctx || !out) return CRT_ERR_INVALID;
     out[0] = ctx->packet_counters[C_WAVE_NODES]; out[1] = ctx->packet_counters[C_WAVE_TRIS]; out[2] = ctx->packet_counters[C_WAVE_WALKS];
+    return CRT_OK;
+}
+
+// Which kernels a production frame of this context runs (bench.py names the roofline's kernel with it).
+extern "C" int crt_describe_kernels(const crt_ctx *ctx, char *out, size_t size) {
+    if (!ctx || !out || size == 0) return CRT_ERR_INVALID;
+    const KernelArgs &A = ctx->args;
+    std::string d;
+    if (ctx->mode == crt_ctx::MODE_LANES) d = "all=render_lanes<false>";
+    else if (ctx->mode == crt_ctx::MODE_PACKETS) d = "all=render_packets<false>+render_lanes<false>";
+    else {
+        const bool heavy = ctx->step_budget && A.nested_boxes;
+        const bool lean = heavy && ctx->lean_ok && !(ctx->debug_skip & 256u);
+        const uint32_t quad = lean ? ctx->use_quads : 0u;
+        d = "level0=";
+        d += !lean ? "stream_trace_shade<false>" : (A.plan_ok ? ((quad & 1u) ? "stream_trace_shade_plan<true>" : "stream_trace_shade_plan<false>")
+                                                              : ((quad & 1u) ? "stream_trace_shade_lean<true>" : "stream_trace_shade_lean<false>"));
+        d += ";shadow0=";
+        d += !lean ? "stream_trace_shadow<false>" : ((quad & 2u) ? "stream_trace_shadow_lean<0u, true>" : (A.plan_ok ? "stream_trace_shadow_plan<0u>" : "stream_trace_shadow_lean<0u, false>"));
+        d += ";levels=";
+        d += !heavy ? "stream_trace_shade<false>" : (ctx->tuning.deep == 1u ? "deep_trace" : (ctx->tuning.deep == 2u && A.plan_ok ? "deep_lanes" :
+             (ctx->tuning.heavy_waves == 7u ? "heavy_trace_closest<7>" : "heavy_trace_closest<5>")));
+    }
+    snprintf(out, size, "%s", d.c_str());
     return CRT_OK;
 }
 

@@ -105,6 +105,7 @@ struct KernelArgs {
     // crt_options::collect_counters == 2: the production kernels tally the box and triangle tests they EXECUTE (the exact
     // shortcuts make that fewer than the reference's, which the counting build tallies): {box tests, triangle tests}
     unsigned long long *exec_counters;
+    unsigned long long *exec_plan;  // ... and the plan loops' box tests (wave-uniform boxes: no per-lane fetch), one word
     uint32_t exec_count;
     uint32_t bundle;              // shadow passes: refill a wave when at most this many of its lanes are still walking (>= 64: at once)
     // single-leaf meshes (walls, floors: a root that is a leaf): the wave-per-ray kernels test them all in one step at the
@@ -136,6 +137,7 @@ struct KernelArgs {
     const float4 *pnodes;
     uint32_t plan_list_words;     // LDS words per lane of a closest-hit ray's mesh list: ceil(meshes / 4)
     // kernel_deep.h: the level-free queue of the recursion levels >= 1
+    uint32_t pool_refill, pool_switch;  // kernel_pool.h: lanes with a free place that make a refill round worth it; lanes below which the wave changes mode
     uint32_t node_repeat;         // kernel_plan.h shadow walk: node steps per loop trip (>= 1)
     uint32_t tri_gather;          // kernel_plan.h shadow walk: lanes wait at a leaf until this many do (0: every trip runs both blocks)
     uint32_t *s_ready;            // one word per slot of s_rayq[1]: == epoch once the slot's record has been published

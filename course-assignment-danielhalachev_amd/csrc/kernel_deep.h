@@ -289,7 +289,7 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void deep_lanes(const Kernel
     float mmin = INFINITY, mt = 0, tmin = INFINITY, bt = 0;
     bool mhave = false, have = false;
     bool chain_fresh = false;      // the lane goes on with the reflection child it has just made
-    uint32_t nbox = 0, ntri = 0, steps = 0;
+    uint32_t nbox = 0, ntri = 0, nplan = 0, steps = 0;
     uint32_t finished = 0;         // wave-uniform: chains ended here and not yet added to `done`
     int state = ST_FETCH;
     for (uint32_t trip = 0;; trip++) {
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void deep_lanes(const Kernel
             ray_prepare(R);
             if (R.parmask != 0) to_heavy = true;  // BoundingBox.h:90-93 needs the general box test, which the wave-per-ray walk has
             else {
-                plan_closest_meshes(A, R, PL, nbox);
+                plan_closest_meshes(A, R, PL, nplan);
                 wn = END; we = NONE; mesh = NONE;
                 mhave = false; mmin = INFINITY; mt = 0; mtri = 0;
                 have = false; tmin = INFINITY; bt = 0; btri = 0; bmesh = 0;
@@ -475,5 +475,5 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void deep_lanes(const Kernel
         if (!__ballot(state != ST_DONE)) break;
     }
     if (lane == 0 && finished) atomicAdd(done, finished);
-    exec_counters_flush(A, nbox, ntri, lane);
+    exec_counters_flush(A, nbox, ntri, lane, nplan);
 }

@@ -43,17 +43,13 @@ __device__ __forceinline__ uint32_t leaf_cursor_entry(uint32_t c) { return c & 0
 __device__ __forceinline__ uint32_t leaf_cursor_next(uint32_t c) { return (c >> 24) ? c + 1u - (1u << 24) : NONE; }
 
 // ---------------------------------------------------------------------------------------------------------------- shadow
-template <uint32_t pass>
-__global__ __launch_bounds__(BLOCK) void stream_trace_shadow_plan(const KernelArgs A) {
+// the shadow rays [first, first + total) of the queue; `cursor` hands them out
+__device__ __forceinline__ void shadow_plan_walks(const KernelArgs &A, const uint32_t first, const uint32_t total, uint32_t *cursor) {
     __shared__ uint32_t root_of_bit[64];  // shadow order -> root node of the mesh's tree
     if (threadIdx.x < 64u) root_of_bit[threadIdx.x] = threadIdx.x < A.plan_shadow_bits ? A.meshes[A.plan_shadow_mesh[threadIdx.x]].root : END;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     if (A.s_counts[SC_OVERFLOW]) return;
-    const uint32_t split = A.s_counts[SC_SHADOW_SPLIT];
-    const uint32_t first = pass == 0 ? 0u : split;
-    const uint32_t total = pass == 0 ? split : A.s_counts[SC_SHADOW] - split;
-    uint32_t *cursor = A.s_counts + (pass == 0 ? SC_SHADOW_FETCH : SC_SHADOW_FETCH2);
     const char *nodes_b = reinterpret_cast<const char *>(A.pnodes);
     const char *ptris_b = reinterpret_cast<const char *>(A.ptris);
 
@@ -61,7 +57,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shadow_plan(const KernelAr
     uint32_t wn = END, we = NONE;   // next mesh-tree node, leaf cursor
     uint32_t mlo = 0, mhi = 0;      // meshes still to walk, bits of the shadow order
     float light_dist = 0;
-    uint32_t nbox = 0, ntri = 0;
+    uint32_t nbox = 0, ntri = 0, nplan = 0;
     int state = ST_FETCH;
     uint32_t r = 0, steps = 0;
     for (;;) {
@@ -97,7 +93,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shadow_plan(const KernelAr
                     lo |= hit ? __float_as_uint(L[8]) : 0u;
                     hi |= hit ? __float_as_uint(L[9]) : 0u;
                 }
-                if (A.exec_count) nbox += A.plan_leaves;
+                if (A.exec_count) nplan += A.plan_leaves;
                 mlo = lo; mhi = hi; wn = END; we = NONE;
             }
         }
@@ -188,7 +184,23 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shadow_plan(const KernelAr
             }
         }
     }
-    exec_counters_flush(A, nbox, ntri, lane);
+    exec_counters_flush(A, nbox, ntri, lane, nplan);
+}
+
+// pass 0: the level-0 shadow rays (queue slots below the split mark); pass 1: all the deeper levels' at once
+template <uint32_t pass>  // (a template parameter so that the passes are separate kernels in a profile)
+__global__ __launch_bounds__(BLOCK) void stream_trace_shadow_plan(const KernelArgs A) {
+    const uint32_t split = A.s_counts[SC_SHADOW_SPLIT];
+    shadow_plan_walks(A, pass == 0 ? 0u : split, pass == 0 ? split : A.s_counts[SC_SHADOW] - split,
+                      A.s_counts + (pass == 0 ? SC_SHADOW_FETCH : SC_SHADOW_FETCH2));
+}
+
+// the shadow rays recursion level `gen` queued, alone: slots [SC_LSPLIT + gen, SC_LSPLIT + gen + 1).  Launched on the side
+// stream as soon as that level is done, beside the next levels, so that only the last level's shadow rays are left for the
+// end of the frame.
+__global__ __launch_bounds__(BLOCK) void stream_trace_shadow_level(const KernelArgs A, const uint32_t gen) {
+    const uint32_t begin = A.s_counts[SC_LSPLIT + gen], end = A.s_counts[SC_LSPLIT + gen + 1];
+    shadow_plan_walks(A, begin, end > begin ? end - begin : 0u, A.s_counts + SC_LFETCH + gen);
 }
 
 // ---------------------------------------------------------------------------------------------------------- closest hit
@@ -203,7 +215,7 @@ struct PlanList {
 // Appends, for every top-level leaf the ray reaches, the meshes it lists that the ray has not met before -- in leaf visit
 // order and list order, i.e. in the order the reference collects their hits (KDTree.cpp:132-155).  Wave-uniform loops:
 // leaf boxes and entries come through scalar loads.
-__device__ __forceinline__ void plan_closest_meshes(const KernelArgs &A, const Ray &R, PlanList &PL, uint32_t &nbox) {
+__device__ __forceinline__ void plan_closest_meshes(const KernelArgs &A, const Ray &R, PlanList &PL, uint32_t &nplan) {
     const ku32p entries = (ku32p)A.leaf_meshes;
     uint32_t seen_lo = 0, seen_hi = 0, acc = 0, cnt = 0;
     for (uint32_t k = 0; k < A.plan_leaves; k++) {
@@ -226,7 +238,7 @@ __device__ __forceinline__ void plan_closest_meshes(const KernelArgs &A, const R
         }
     }
     if (cnt & 3u) PL.words[(cnt >> 2) * BLOCK] = acc;
-    if (A.exec_count) nbox += A.plan_leaves;
+    if (A.exec_count) nplan += A.plan_leaves;
     PL.count = cnt;
     PL.next = 0;
 }
@@ -268,7 +280,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArg
     uint32_t mesh = NONE, mtri = 0, btri = 0, bmesh = 0;
     float mmin = INFINITY, mt = 0, tmin = INFINITY, bt = 0;
     bool mhave = false, have = false;
-    uint32_t nbox = 0, ntri = 0;
+    uint32_t nbox = 0, ntri = 0, nplan = 0;
     int state = ST_FETCH;
     uint32_t r = 0, steps = 0;
     for (;;) {
@@ -306,7 +318,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArg
                 state = ST_TRAVERSE;
             }
             if (fresh) {
-                plan_closest_meshes(A, R, PL, nbox);
+                plan_closest_meshes(A, R, PL, nplan);
                 if (QUAD) prune_prepare(prune, R, A.scene_scale);
                 wq = QUAD ? NONE : END; we = NONE; sp = 0; top = NONE; mesh = NONE;
                 mhave = false; mmin = INFINITY; mt = 0; mtri = 0;
@@ -440,5 +452,5 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArg
             }
         }
     }
-    exec_counters_flush(A, nbox, ntri, lane);
+    exec_counters_flush(A, nbox, ntri, lane, nplan);
 }

@@ -387,9 +387,11 @@ __device__ __forceinline__ int quad_walk(LeanWalk &W, const Ray &R, const bool p
 }
 
 // End of a kernel: the lanes' executed-test tallies go to KernelArgs::exec_counters (collect_counters == 2 only).
-__device__ __forceinline__ void exec_counters_flush(const KernelArgs &A, uint32_t nbox, uint32_t ntri, uint32_t lane) {
+// `nplan`: box tests of the plan loops (kernel_plan.h) -- executed per lane, but their operands are scalar registers loaded once
+// per wave, so they are tallied apart from the tests that fetch a node per lane.
+__device__ __forceinline__ void exec_counters_flush(const KernelArgs &A, uint32_t nbox, uint32_t ntri, uint32_t lane, uint32_t nplan = 0) {
     if (!A.exec_count) return;
-    unsigned long long b = nbox, t = ntri;
-    for (int off = 32; off > 0; off >>= 1) { b += __shfl_down(b, off); t += __shfl_down(t, off); }
-    if (lane == 0) { atomicAdd(&A.exec_counters[0], b); atomicAdd(&A.exec_counters[1], t); }
+    unsigned long long b = nbox, t = ntri, p = nplan;
+    for (int off = 32; off > 0; off >>= 1) { b += __shfl_down(b, off); t += __shfl_down(t, off); p += __shfl_down(p, off); }
+    if (lane == 0) { atomicAdd(&A.exec_counters[0], b); atomicAdd(&A.exec_counters[1], t); if (p) atomicAdd(A.exec_plan, p); }
 }

@@ -201,7 +201,11 @@ typedef struct crt_tuning {
                                * walk goes to the wave-per-ray kernel */
     uint32_t node_repeat;     /* 2: node steps per loop trip of the planned shadow walk (one triangle step per trip) */
     uint32_t heavy_waves;     /* 5: register budget of the deeper levels' wave-per-ray launches in waves per SIMD (5 or 7) */
-    uint32_t reserved[3];
+    uint32_t level_shadows;   /* 0: all the deeper levels' shadow rays in one pass at the end of the frame; 1: a deeper level's shadow
+                               * rays are queued on the side stream as soon as the level is done */
+    uint32_t pool;            /* shadow walks with three rays per lane (kernel_pool.h): bit 0 the bulk pass, bit 1 the deeper levels' */
+    uint32_t pool_refill;     /* 48: lanes with a free place that make a refill round of that kernel worth it */
+    uint32_t pool_switch;     /* 24: lanes below which its wave changes between node and triangle mode */
 } crt_tuning;
 void crt_tuning_defaults(crt_tuning *tuning);
 
@@ -314,6 +318,10 @@ const char *crt_build_last_error(void);
  * production kernels executed in the whole render, then the same two for shadow pass 0 alone (the largest kernel).  Fewer than crt_stats' box_tests / tri_tests, which are the reference's: the kernels leave
  * out work that cannot change the result (shadow early exit, one walk per mesh and ray). */
 int crt_get_executed_counters(crt_ctx *ctx, uint64_t out[4]);
+/* ... and the box tests of the plan loops (csrc/kernel_plan.h: a ray against the top-level leaves, whose boxes sit in scalar
+ * registers loaded once per wave -- executed per ray, but with no per-ray fetch): {whole render, of which shadow pass 0}.
+ * They are NOT part of the counts above. */
+int crt_get_executed_plan_tests(crt_ctx *ctx, uint64_t out[2]);
 
 /* Test hook: out[i] = the device build of the restated glibc powf(x[i], 5) (the Fresnel term, RayTracer.cpp:407). */
 int crt_test_pow5(int device, const float *x, float *out, uint64_t n);
@@ -323,6 +331,9 @@ int crt_test_pow5(int device, const float *x, float *out, uint64_t n);
  * wave-per-ray kernels, ...: the SC_* layout of csrc/kernel_stream.h, at most 512 words), and the packet kernel's
  * wave-level visit counts {nodes, triangles, walks} of the last counted render. */
 int crt_debug_stream_counts(crt_ctx *ctx, uint32_t *out_words, uint32_t max_words);
+/* which kernels a production frame of this context runs, e.g. "level0=stream_trace_shade_plan<true>;shadow0=stream_trace_shadow_plan<0u>;
+ * levels=heavy_trace_closest<5>" (names as rocprofv3 prints them) */
+int crt_describe_kernels(const crt_ctx *ctx, char *out, size_t size);
 int crt_debug_packet_counters(crt_ctx *ctx, uint64_t out[3]);
 
 #ifdef __cplusplus

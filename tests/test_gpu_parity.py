@@ -79,6 +79,9 @@ KERNEL_PATHS = [
     dict(top_in_registers=0, tiny_meshes=0),                     # top-level tree and single-leaf meshes read from memory
     dict(fixed0=0, bundle=64),                                   # level 0's shadow rays queued; lanes refill one by one
     dict(node_repeat=1), dict(node_repeat=4, tri_gather=24),     # shadow walk: node steps per trip, exclusive triangle trips
+    dict(pool=3), dict(pool=1, pool_refill=1, pool_switch=64),   # shadow walks with three rays per lane (kernel_pool.h)
+    dict(pool=3, pool_refill=64, pool_switch=1, level_shadows=1),
+    dict(level_shadows=1),                                       # the deeper levels' shadow rays in one pass at the end
     dict(heavy_waves=7),                                         # deeper levels' wave-per-ray launches on a 72-register budget
 ]
 

@@ -8,13 +8,13 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "gpurun_out", "profiles_" + tag)
 os.makedirs(out, exist_ok=True)
 env = dict(os.environ, TMPDIR="/tmp")
-DOM = "stream_trace_shadow_lean<0"
+DOM = "stream_trace_shadow_plan<0"
 
 
 def run(args, name):
     d = os.path.join(out, name)
     cmd = ["rocprofv3"] + args + ["-d", d, "--output-format", "csv", "--", "python3", os.path.join(root, "bench.py"),
-                                  "--steps", "5", "--warmup", "2", "--no-cpu-baseline"]
+                                  "--steps", "10", "--warmup", "2", "--no-cpu-baseline"]
     with open(os.path.join(out, name + ".log"), "w") as log:
         rc = subprocess.run(cmd, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT, timeout=400).returncode
     print(name, "rc", rc, flush=True)
@@ -37,7 +37,8 @@ for line in open(os.path.join(out, "stats.log")):
 
 pmc = {}
 for counters in (["FETCH_SIZE"], ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"], ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum"],
-                 ["SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD", "SQ_WAVES"], ["SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU"]):
+                 ["SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD", "SQ_WAVES", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU"],
+                 ["SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES"]):
     name = "pmc_" + "_".join(c.replace("_sum", "") for c in counters)
     d = run(["--pmc"] + counters, name)
     f = find(d, "counter_collection.csv")
