@@ -144,7 +144,7 @@ struct crt_ctx {
     uint32_t *d_ready = nullptr;      // kernel_deep.h: publication flags of the deep queue's slots
     uint32_t *d_ready2 = nullptr;     // ... and of the heavy queue's
     // queue sizing (ensure_stream): capacities as multiples of the frame's pixels, adapted from frame to frame
-    double node_mult = 1.5, ray_mult = 0.5, shadow_extra = 0.25;
+    double node_mult = 1.25, ray_mult = 0.5, shadow_extra = 0.125;
     uint32_t *h_counts = nullptr;     // pinned copy of the last frame's counter block (d_scounts)
     uint32_t sizing_seen_fallbacks = 0, last_items = 0;
     uint64_t queue_bytes = 0;         // bytes of the per-frame buffers as allocated now
@@ -395,6 +395,7 @@ extern "C" void crt_tuning_defaults(crt_tuning *t) {
     t->heavy_waves = 5;
     t->level_shadows = 0;
     t->pool = 0; t->pool_refill = 48; t->pool_switch = 24;
+    t->early_shadow = 0;
 }
 
 extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) { return crt_create_tuned(s, device, nullptr, out); }
@@ -564,6 +565,7 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
             for (uint32_t i = 0; i < s->n_nodes; i++)
                 if (is_top[i]) { lo = i < lo ? i : lo; hi = i > hi ? i : hi; cnt++; }
             A.top_fast = (tune.top_in_registers && cnt > 0 && hi - lo + 1 == cnt && cnt <= 64u && s->n_leaf_meshes <= 128u && s->n_meshes <= 64u) ? 1u : 0u;
+            A.top_lds = (tune.top_in_registers && cnt > 0 && hi - lo + 1 == cnt && cnt <= 256u && s->n_leaf_meshes <= 1024u && s->n_meshes <= 256u) ? 1u : 0u;
             A.top_first = cnt ? lo : 0u;
             A.top_count = cnt;
             A.top_leaf_entries = s->n_leaf_meshes;
@@ -1008,7 +1010,7 @@ static int ensure_frames(crt_ctx *ctx, uint32_t max_depth) {
 // render_lanes, which needs no queues.
 // Queues of the ray-stream pass.  What a frame needs depends on the scene and the camera -- a frame of diffuse surfaces
 // has no child rays at all, nested glass can reach 2^(MAX_DEPTH+1)-1 rays per pixel -- so the capacities FOLLOW the frames:
-// they start at px * {1.5 ray-tree nodes, 0.5 rays per level, n_lights * 1.25 shadow rays} (px = 64 pixels per work item),
+// they start at px * {1.25 ray-tree nodes, 0.5 rays per level, n_lights * 1.125 shadow rays} (px = 64 pixels per work item),
 // grow by half when the previous frame used more than 70 % of one of them, and double (up to px * {4, 3, n_lights * 4})
 // after a frame that overflowed.  Such a frame is not lost: its queues raise the overflow word and render_lanes, which
 // needs no queues, redoes it in the same call (crt_stats::fallback_frames counts them).
@@ -1096,7 +1098,7 @@ static int ensure_stream(crt_ctx *ctx, uint32_t n_items) {
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_todo_tiles, ((size_t)n_items + 1) * sizeof(uint32_t)));
         // (the list of abandoned shadow walks is only written when level 0 runs as packets)
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_todo_shadow, (ctx->packet_budget ? (size_t)shadow_cap : 1) * sizeof(uint32_t)));
-        ctx->heavy_cap = (uint32_t)std::max<uint64_t>(floor_cap, std::max<uint64_t>(px, ray_cap));
+        ctx->heavy_cap = (uint32_t)std::max<uint64_t>(floor_cap, ray_cap);  // (a full list only keeps a long walk where it is)
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_heavy, (size_t)ctx->heavy_cap * sizeof(uint32_t)));
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_sheavy, (size_t)ctx->heavy_cap * sizeof(uint32_t)));
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_hits, (size_t)ctx->heavy_cap * sizeof(float4)));
@@ -1181,11 +1183,18 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         // the plan kernels (kernel_plan.h) pay a wave-uniform loop per refill, whatever the number of new rays: refill in bundles
         A.bundle = (A.plan_ok && ctx->bundle < 64u) ? ctx->bundle : 64u;
         A.fixed0 = 0;
+        A.early_shadow = 0;
         if (ctx->fixed0) {  // level 0 owns the first n_items * 64 * n_lights slots of the shadow queue; the deeper levels append
             const uint64_t n0 = (uint64_t)n_items * 64u * ctx->n_lights;
             if (n0 <= A.s_shadow_cap) {
                 A.fixed0 = 1;
                 CRT_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->d_scounts + SC_SHADOW), (int)(uint32_t)n0, 1, stream));
+                // early_shadow: the bulk shadow pass is launched straight after the level-0 kernel and reads exactly the fixed region
+                if (lean && A.plan_ok && !(lean ? (ctx->use_quads & 2u) : 0u) && ctx->side_blocks_per_cu && ctx->tuning.early_shadow && !count &&
+                    ctx->packet_budget == 0) {
+                    A.early_shadow = 1;
+                    CRT_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->d_scounts + SC_SHADOW_SPLIT), (int)(uint32_t)n0, 1, stream));
+                }
             }
         }
         const uint32_t qlds = ctx->quad_stack_depth * BLOCK * (uint32_t)sizeof(uint32_t);
@@ -1227,6 +1236,29 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         const bool deep = heavy && ctx->tuning.deep && o->max_depth >= 1;
         ctx->epoch = ctx->epoch == 0xFFFFFFFFu ? 1u : ctx->epoch + 1u;
         A.epoch = ctx->epoch;
+        // 2a) the shadow rays level 0 queued (the bulk of them), on the side stream beside the deeper levels: launched after level 0
+        //     is complete, or -- early_shadow -- straight after its per-lane kernel
+        auto fork_shadow0 = [&]() -> int {
+            // 2a) the shadow rays level 0 queued (the bulk of them) start now, beside the deeper levels
+            CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork[slot], stream));
+            CRT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork[slot], 0));
+            CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s0[slot], ctx->side));
+            // its persistent waves must leave wave slots on every CU for the level kernels running beside it
+            const uint32_t side_blocks = (uint32_t)ctx->num_cus * ctx->side_blocks_per_cu;
+            if (count) launch(stream_trace_shadow<true>, side_blocks, ctx->side, S, 0u);
+            else if (lean && (quad & 2u)) launch_lds(stream_trace_shadow_lean<0, true>, side_blocks, qlds, ctx->side, S);
+            else if (lean && A.plan_ok && ctx->tuning.pool) launch_lds(stream_trace_shadow_pool<0>, side_blocks, POOL_LDS_BYTES, ctx->side, S);
+            else if (lean && A.plan_ok) launch(stream_trace_shadow_plan<0>, side_blocks, ctx->side, S);
+            else if (lean) launch(stream_trace_shadow_lean<0, false>, side_blocks, ctx->side, S);
+            else launch(stream_trace_shadow<false>, side_blocks, ctx->side, S, 0u);
+            // the walks it gave up follow at once, still beside the levels; the mark comes before the event the
+            // caller's stream waits for, so nothing the later pass appends is below it
+            if (heavy && !count) hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, ctx->side, S, (uint32_t)SC_SHEAVY_SPLIT, (uint32_t)SC_SHEAVY);
+            CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s1[slot], ctx->side));
+            if (heavy && !count) launch(heavy_trace_shadow, heavy_blocks, ctx->side, S, 0u);
+            CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s2[slot], ctx->side));
+            return CRT_OK;
+        };
         // the deeper levels' shadow rays level by level on the side stream (plan kernels only), or all at once at the end
         const bool level_shadows = lean && A.plan_ok && !(quad & 4u) && ctx->side_blocks_per_cu && !deep && !packets && ctx->tuning.level_shadows;
         const uint32_t level_shadow_blocks = (uint32_t)ctx->num_cus * 2u;
@@ -1248,12 +1280,19 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
             else if (lean && (quad & 1u)) launch_lds(stream_trace_shade_lean<true>, lane_blocks, qlds, stream, A, g);
             else if (lean) launch(stream_trace_shade_lean<false>, lane_blocks, stream, A, g);
             else launch(stream_trace_shade<false>, lane_blocks, stream, A, g);
+            if (g == 0 && A.early_shadow) { rc = fork_shadow0(); if (rc) return rc; }
             if (heavy) {
                 if (ctx->tuning.heavy_waves == 7u && g > 0) launch(heavy_trace_closest<7>, heavy_blocks, stream, A, g);
                 else launch(heavy_trace_closest<5>, heavy_blocks, stream, A, g);
-                launch(stream_shade_evicted<false>, 256u, stream, A, g);
+                if (g == 0 && A.early_shadow) {  // the fixed shadow slots are being read already: queue these pixels' shadow rays
+                    KernelArgs AE = A;
+                    AE.fixed0 = 0u;
+                    launch(stream_shade_evicted<false>, 256u, stream, AE, g);
+                } else {
+                    launch(stream_shade_evicted<false>, 256u, stream, A, g);
+                }
             }
-            if (g == 0 && !packets) hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, stream, A, (uint32_t)SC_SHADOW_SPLIT, (uint32_t)SC_SHADOW);
+            if (g == 0 && !packets && !A.early_shadow) hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, stream, A, (uint32_t)SC_SHADOW_SPLIT, (uint32_t)SC_SHADOW);
             if (level_shadows) {
                 // where level g's shadow rays end; from level 1 on they are walked on the side stream while the next level runs
                 hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, stream, A, (uint32_t)(SC_LSPLIT + g + 1), (uint32_t)SC_SHADOW);
@@ -1265,26 +1304,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
                     else launch(stream_trace_shadow_level, level_shadow_blocks, ctx->side, SL, g);
                 }
             }
-            if (g == 0 && ctx->side_blocks_per_cu) {
-                // 2a) the shadow rays level 0 queued (the bulk of them) start now, beside the deeper levels
-                CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork[slot], stream));
-                CRT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork[slot], 0));
-                CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s0[slot], ctx->side));
-                // its persistent waves must leave wave slots on every CU for the level kernels running beside it
-                const uint32_t side_blocks = (uint32_t)ctx->num_cus * ctx->side_blocks_per_cu;
-                if (count) launch(stream_trace_shadow<true>, side_blocks, ctx->side, S, 0u);
-                else if (lean && (quad & 2u)) launch_lds(stream_trace_shadow_lean<0, true>, side_blocks, qlds, ctx->side, S);
-                else if (lean && A.plan_ok && ctx->tuning.pool) launch_lds(stream_trace_shadow_pool<0>, side_blocks, POOL_LDS_BYTES, ctx->side, S);
-                else if (lean && A.plan_ok) launch(stream_trace_shadow_plan<0>, side_blocks, ctx->side, S);
-                else if (lean) launch(stream_trace_shadow_lean<0, false>, side_blocks, ctx->side, S);
-                else launch(stream_trace_shadow<false>, side_blocks, ctx->side, S, 0u);
-                // the walks it gave up follow at once, still beside the levels; the mark comes before the event the
-                // caller's stream waits for, so nothing the later pass appends is below it
-                if (heavy && !count) hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, ctx->side, S, (uint32_t)SC_SHEAVY_SPLIT, (uint32_t)SC_SHEAVY);
-                CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s1[slot], ctx->side));
-                if (heavy && !count) launch(heavy_trace_shadow, heavy_blocks, ctx->side, S, 0u);
-                CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s2[slot], ctx->side));
-            }
+            if (g == 0 && ctx->side_blocks_per_cu && !A.early_shadow) { rc = fork_shadow0(); if (rc) return rc; }
         }
         if (deep) {
             A.step_budget = ctx->step_budget;

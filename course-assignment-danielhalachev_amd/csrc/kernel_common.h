@@ -114,6 +114,7 @@ struct KernelArgs {
     // the top-level tree held in registers by the wave-per-ray kernels (kernel_heavy.h: TopRegs) when it is small:
     // its nodes are [top_first, top_first + top_count), top_count <= 64, leaf_meshes has <= 128 entries and there are <= 64 meshes
     uint32_t top_fast, top_first, top_count, top_leaf_entries, top_meshes;
+    uint32_t top_lds;             // the top-level tree fits the per-lane kernels' LDS copy (kernel_walk.h: TopLds): <= 256 nodes, 1024 entries, 256 meshes
     const uint32_t *tiny_at, *tiny_flags;
     uint32_t tiny_count;
     uint32_t fixed0;              // level 0's shadow rays go to fixed, tile-ordered slots (kernel_stream.h: level0_shadow_slot)
@@ -137,6 +138,7 @@ struct KernelArgs {
     const float4 *pnodes;
     uint32_t plan_list_words;     // LDS words per lane of a closest-hit ray's mesh list: ceil(meshes / 4)
     // kernel_deep.h: the level-free queue of the recursion levels >= 1
+    uint32_t early_shadow;        // level 0: the bulk shadow pass starts before the evicted primary walks are finished (kernel_plan.h)
     uint32_t pool_refill, pool_switch;  // kernel_pool.h: lanes with a free place that make a refill round worth it; lanes below which the wave changes mode
     uint32_t node_repeat;         // kernel_plan.h shadow walk: node steps per loop trip (>= 1)
     uint32_t tri_gather;          // kernel_plan.h shadow walk: lanes wait at a leaf until this many do (0: every trip runs both blocks)
@@ -185,13 +187,16 @@ __device__ __forceinline__ void ray_prepare(Ray &R) {
 // can no longer change anything: the scene-level rule only takes a strictly smaller distance (KDTree.cpp:162; the first
 // walk's own distance is not smaller than itself, and the running minimum only decreases), and a shadow ray's verdict is
 // an OR over the walks.  So the production kernels walk every mesh once per ray, at its first occurrence in visit order,
-// which is also where the reference first collects its hit.  (Meshes 64 and up are simply walked again; the counting
+// which is also where the reference first collects its hit.  (Meshes 128 and up are simply walked again; the counting
 // build repeats everything, as its counters are the reference's.)
-__device__ __forceinline__ bool mesh_walk_is_repeat(unsigned long long &seen, uint32_t mesh) {
-    if (mesh >= 64u) return false;
-    const unsigned long long bit = 1ull << mesh;
-    const bool repeat = (seen & bit) != 0;
-    seen |= bit;
+struct SeenMeshes { unsigned long long lo, hi; };   // meshes 0..127 already walked for this ray
+__device__ __forceinline__ void seen_clear(SeenMeshes &seen) { seen.lo = 0; seen.hi = 0; }
+__device__ __forceinline__ bool mesh_walk_is_repeat(SeenMeshes &seen, uint32_t mesh) {
+    if (mesh >= 128u) return false;
+    const unsigned long long bit = 1ull << (mesh & 63u);
+    unsigned long long &word = mesh < 64u ? seen.lo : seen.hi;
+    const bool repeat = (word & bit) != 0;
+    word |= bit;
     return repeat;
 }
 

@@ -292,15 +292,17 @@ __device__ __forceinline__ TopRegs heavy_top_load(const KernelArgs &A, const uin
 }
 
 // The two-level walk for one ray per wave.  SHADOW: AccelerationStructure.cpp:56-94, else KDTree.cpp:127-167.
+// `TL`: the workgroup's LDS copy of a top-level tree that is too large for the registers (kernel_walk.h: TopLds), or null.
 template <bool SHADOW>
 __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const TopRegs &TR, const Ray &R, const bool primary, const float light_dist,
                                            bool &have, float &bt, uint32_t &btri, uint32_t &bmesh, bool &occluded,
-                                           const uint32_t lane) {
+                                           const uint32_t lane, const TopLds *TL = nullptr) {
     have = false;
     occluded = false;
     float tmin = INFINITY;
     uint32_t ti = A.top_root;
-    unsigned long long seen = 0;
+    SeenMeshes seen;
+    seen_clear(seen);
     HeavyState H;
     H.guard = 1u << 18;
     H.stop = false;
@@ -322,6 +324,10 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const TopRegs &T
             miss = lane_value(__float_as_uint(TR.q0.w), i);
             link = lane_value(__float_as_uint(TR.q1.w), i);
             hit = ((top_hits >> i) & 1ull) != 0;
+        } else if (TL && TL->fast) {  // (every lane reads the same words: a broadcast, no bank conflicts)
+            const lds_v4f a = TL->nodes[2 * (ti - TL->first)], b = TL->nodes[2 * (ti - TL->first) + 1];
+            miss = __builtin_amdgcn_readfirstlane(__float_as_uint(a[3])); link = __builtin_amdgcn_readfirstlane(__float_as_uint(b[3]));
+            hit = __builtin_amdgcn_readfirstlane(slab_test(R, a[0], a[1], a[2], b[0], b[1], b[2]) ? 1 : 0) != 0;
         } else {
             const float4 q0 = A.nodes[2 * (size_t)ti], q1 = A.nodes[2 * (size_t)ti + 1];
             miss = __float_as_uint(q0.w); link = __float_as_uint(q1.w);
@@ -332,11 +338,17 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const TopRegs &T
         if (!is_leaf_link(link)) { ti = link; continue; }
         uint32_t e = link & ~LEAF;
         for (;;) {
-            const uint32_t ent = !fast ? A.leaf_meshes[e] : (e < 64u ? lane_value(TR.entry, (int)e) : lane_value(TR.entry2, (int)(e - 64u)));
+            const uint32_t ent = fast ? (e < 64u ? lane_value(TR.entry, (int)e) : lane_value(TR.entry2, (int)(e - 64u)))
+                                      : ((TL && TL->fast) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)TL->entries[e]) : A.leaf_meshes[e]);
             e++;
             const uint32_t mi = ent & ~LAST;
             crt_mesh m;
             if (fast) { m.flags = lane_value(TR.mflags, (int)mi); m.pad = lane_value(TR.mpad, (int)mi); m.root = 0; m.material = 0; }
+            else if (TL && TL->fast) {
+                const lds_v4u v = TL->meshes[mi];  // {flags, tree root, quad root, pad}
+                m.flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[0]); m.pad = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[3]);
+                m.root = 0; m.material = 0;
+            }
             else m = A.meshes[mi];
             if (!(SHADOW && (m.flags & 1u)) && !mesh_walk_is_repeat(seen, mi)) {  // (kernel_common.h: every mesh once per ray)
                 if (m.pad) {  // a single-leaf mesh: its result has been waiting in lane pad - 1 since the start of the ray
@@ -374,6 +386,10 @@ __device__ __forceinline__ float uniform_f(float v) { return __uint_as_float(__b
 template <int WAVES_PER_SIMD>  // register budget: 5 = what the compiler takes by itself (91 VGPRs); 7 = 72 VGPRs with spills, which
                                // lets three of these waves per SIMD (not two) sit beside the bulk shadow pass's four
 __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void heavy_trace_closest(const KernelArgs A, const uint32_t gen) {
+    __shared__ TopLdsStorage top_storage;  // used when the top-level tree is too large for the registers and small enough for this
+    TopLds TL;
+    TL.fast = false;
+    if (!A.top_fast && A.top_lds) TL = top_lds_load(A, top_storage);  // (a barrier inside: before any return; the condition is uniform)
     const uint32_t lane = threadIdx.x & 63u;
     if (A.s_counts[SC_OVERFLOW]) return;
     const uint32_t count = stream_level_count(A, gen);
@@ -408,7 +424,7 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void heavy_trace_closest(con
         bool have = false, occluded = false;
         float bt = 0;
         uint32_t btri = 0, bmesh = 0;
-        heavy_walk<false>(A, TR, R, primary, 0.0f, have, bt, btri, bmesh, occluded, lane);
+        heavy_walk<false>(A, TR, R, primary, 0.0f, have, bt, btri, bmesh, occluded, lane, &TL);
         if (lane == 0) A.s_hits[k] = make_float4(bt, __uint_as_float(btri), __uint_as_float(bmesh), __uint_as_float(have ? 1u : 0u));
     }
 }
@@ -416,6 +432,10 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void heavy_trace_closest(con
 // part 0: the walks shadow pass 0 gave up (list entries below the SC_SHEAVY_SPLIT mark), on the side stream right
 // after that pass; part 1: the rest, after the last pass.
 __global__ __launch_bounds__(BLOCK) void heavy_trace_shadow(const KernelArgs A, const uint32_t part) {
+    __shared__ TopLdsStorage top_storage;
+    TopLds TL;
+    TL.fast = false;
+    if (!A.top_fast && A.top_lds) TL = top_lds_load(A, top_storage);
     const uint32_t lane = threadIdx.x & 63u;
     if (A.s_counts[SC_OVERFLOW]) return;
     uint32_t total = A.s_counts[SC_SHEAVY], split = A.s_counts[SC_SHEAVY_SPLIT];
@@ -439,7 +459,7 @@ __global__ __launch_bounds__(BLOCK) void heavy_trace_shadow(const KernelArgs A, 
         bool have, occluded;
         float bt = 0;
         uint32_t btri = 0, bmesh = 0;
-        heavy_walk<true>(A, TR, R, false, uniform_f(q0.w), have, bt, btri, bmesh, occluded, lane);
+        heavy_walk<true>(A, TR, R, false, uniform_f(q0.w), have, bt, btri, bmesh, occluded, lane, &TL);
         if (lane == 0) A.s_occluded[r] = occluded ? 1 : 0;
     }
 }

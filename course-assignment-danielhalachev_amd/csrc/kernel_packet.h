@@ -55,7 +55,8 @@ __device__ __forceinline__ void packet_walk_impl(const KernelArgs &A, const Ray 
     occluded = false;
     if (COUNT && (threadIdx.x & 63u) == 0) cnt[C_WAVE_WALKS]++;
     float tmin = INFINITY;
-    unsigned long long seen = 0;    // per lane: meshes already walked for this ray (kernel_common.h: mesh_walk_is_repeat)
+    SeenMeshes seen;                // per lane: meshes already walked for this ray (kernel_common.h: mesh_walk_is_repeat)
+    seen_clear(seen);
     uint32_t tres = on ? 0u : END;  // TRACK: the lane takes part in the top-level walk from node index `tres` on
     uint32_t ti = A.top_root;
     while (ti != END && budget >= 0) {

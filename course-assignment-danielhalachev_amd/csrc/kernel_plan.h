@@ -248,6 +248,13 @@ __device__ __forceinline__ uint32_t plan_list_pop(PlanList &PL) {
     return (PL.words[(i >> 2) * BLOCK] >> (8u * (i & 3u))) & 255u;
 }
 
+// early_shadow: the bulk shadow pass starts right after this kernel, before the wave-per-ray kernel has finished the primary
+// walks handed to it.  A primary ray that leaves here therefore gives its fixed shadow slots back (the pass skips them);
+// stream_shade_evicted queues that pixel's shadow rays behind the fixed region, where the later shadow pass finds them.
+__device__ __forceinline__ void early_shadow_release(const KernelArgs &A, const uint32_t gen, const uint32_t r) {
+    if (gen == 0u && A.early_shadow) level0_release_shadow_slots(A, r);
+}
+
 // Every ray of recursion level `gen`, one per lane: plan, walk of the listed meshes (quad or binary nodes), material
 // dispatch.  Same results and same queues as stream_trace_shade_lean; rays with a parallel axis, walks longer than the
 // step budget and (QUAD) walks that outgrow the LDS stack go to heavy_trace_closest.
@@ -309,7 +316,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArg
                     ray_prepare(R);
                 }
                 if (R.parmask != 0) {
-                    if (evict_ray(A.s_heavy, A.s_heavy_cap, A.s_counts + SC_HEAVY + gen, r, lane)) continue;
+                    if (evict_ray(A.s_heavy, A.s_heavy_cap, A.s_counts + SC_HEAVY + gen, r, lane)) { early_shadow_release(A, gen, r); continue; }
                     A.s_counts[SC_OVERFLOW] = 1;  // cannot walk it here: let the fallback redo the frame
                     continue;
                 }
@@ -445,9 +452,10 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArg
                 state = ST_FETCH;
             } else if (stack_full) {  // restart it in the wave-per-ray kernel, which needs no stack
                 if (!evict_ray(A.s_heavy, A.s_heavy_cap, A.s_counts + SC_HEAVY + gen, r, lane)) A.s_counts[SC_OVERFLOW] = 1;
+                else early_shadow_release(A, gen, r);
                 state = ST_FETCH;
             } else if (steps >= A.step_budget) {
-                if (evict_ray(A.s_heavy, A.s_heavy_cap, A.s_counts + SC_HEAVY + gen, r, lane)) state = ST_FETCH;
+                if (evict_ray(A.s_heavy, A.s_heavy_cap, A.s_counts + SC_HEAVY + gen, r, lane)) { early_shadow_release(A, gen, r); state = ST_FETCH; }
                 steps = 0;
             }
         }

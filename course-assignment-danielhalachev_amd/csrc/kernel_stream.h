@@ -568,6 +568,8 @@ __global__ __launch_bounds__(BLOCK) void stream_packets_gen0(const KernelArgs A)
 // Shading of the rays stream_trace_shade(gen) evicted, after heavy_trace_closest(gen) has found their hits.
 template <bool COUNT>
 __global__ __launch_bounds__(BLOCK) void stream_shade_evicted(const KernelArgs A, const uint32_t gen) {
+    // (early_shadow, kernel_plan.h: level 0's fixed shadow slots are being read already, so the host passes level 0's launch
+    // a copy of the arguments with fixed0 = 0 and this pixel's shadow rays are queued)
     const uint32_t lane = threadIdx.x & 63u;
     if (A.s_counts[SC_OVERFLOW]) return;
     const uint32_t count = stream_level_count(A, gen);

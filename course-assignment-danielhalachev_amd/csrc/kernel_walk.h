@@ -28,13 +28,13 @@ __device__ __forceinline__ bool shadow_hit_occludes(const Ray &R, float hx, floa
 // The top-level tree for the per-lane walks, in LDS.  A ray spends about as many steps in the few dozen top-level nodes as in
 // the mesh trees (HW14: 17 of 31 box tests of a shadow ray), and every one of them is a divergent gather through the vector
 // L1 for a table of a kilobyte: when crt_create finds the table small (KernelArgs::top_fast) each workgroup copies it to LDS
-// and the walks read nodes, leaf entries and mesh records from there.
+// and the walks read nodes, leaf entries and mesh records from there (up to 256 nodes, 1024 leaf entries, 256 meshes).
 typedef float lds_v4f __attribute__((ext_vector_type(4)));       // plain vector types: LDS pointers cannot bind to the float4 class
 typedef uint32_t lds_v4u __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) lds_v4f *lds_f4;
 typedef const __attribute__((address_space(3))) lds_v4u *lds_u4;
 typedef const __attribute__((address_space(3))) uint32_t *lds_u32;
-constexpr int TOP_LDS_NODES = 64, TOP_LDS_ENTRIES = 128, TOP_LDS_MESHES = 64;
+constexpr int TOP_LDS_NODES = 256, TOP_LDS_ENTRIES = 1024, TOP_LDS_MESHES = 256;  // 16 KB per workgroup (KernelArgs::top_lds)
 struct TopLdsStorage {
     lds_v4f nodes[TOP_LDS_NODES * 2];
     lds_v4u meshes[TOP_LDS_MESHES];    // {flags, tree root, quad root, -}
@@ -50,7 +50,7 @@ struct TopLds {
 // Called by every thread of the workgroup before anything else (it holds a barrier).
 __device__ __forceinline__ TopLds top_lds_load(const KernelArgs &A, TopLdsStorage &S) {
     TopLds T;
-    T.fast = A.top_fast != 0;
+    T.fast = A.top_lds != 0;
     T.first = A.top_first;
     T.nodes = (lds_f4)S.nodes;
     T.meshes = (lds_u4)S.meshes;
@@ -63,7 +63,7 @@ __device__ __forceinline__ TopLds top_lds_load(const KernelArgs &A, TopLdsStorag
         for (uint32_t i = threadIdx.x; i < A.top_leaf_entries; i += blockDim.x) S.entries[i] = A.leaf_meshes[i];
         for (uint32_t i = threadIdx.x; i < A.top_meshes; i += blockDim.x) {
             const crt_mesh m = A.meshes[i];
-            S.meshes[i] = lds_v4u{m.flags, m.root, A.quad_roots[i], 0u};
+            S.meshes[i] = lds_v4u{m.flags, m.root, A.quad_roots[i], m.pad};  // (pad: index + 1 among the single-leaf meshes, kernel_heavy.h)
         }
         __syncthreads();
     }
@@ -83,7 +83,7 @@ struct LeanWalk {
     uint32_t btri, bmesh;
     bool have, occluded;
     float light_dist;
-    unsigned long long seen;  // meshes 0..63 already walked for this ray (mesh_walk_is_repeat)
+    SeenMeshes seen;          // meshes 0..127 already walked for this ray (mesh_walk_is_repeat)
     uint32_t nbox, ntri;      // tests executed by this lane since the kernel started (KernelArgs::exec_count; not reset per ray)
 };
 
@@ -91,7 +91,7 @@ __device__ __forceinline__ void lean_begin(LeanWalk &W, uint32_t top_root) {
     W.n = END; W.e = NONE; W.tnode = top_root; W.tleaf = NONE; W.mesh = NONE;
     W.mhave = false; W.mmin = INFINITY; W.mt = 0; W.mtri = 0;
     W.have = false; W.occluded = false; W.tmin = INFINITY; W.bt = 0; W.btri = 0; W.bmesh = 0;
-    W.seen = 0;
+    seen_clear(W.seen);
 }
 
 // Runs up to `iterations` steps of the walk for this lane.  Returns true when the ray's walk is complete.
@@ -225,7 +225,7 @@ struct QuadWalk {
     bool have, occluded;
     float light_dist;
     Prune prune;       // closest-hit walks (kernel_common.h: distance pruning)
-    unsigned long long seen;  // meshes 0..63 already walked for this ray (mesh_walk_is_repeat)
+    SeenMeshes seen;          // meshes 0..127 already walked for this ray (mesh_walk_is_repeat)
     uint32_t nbox, ntri;      // tests executed by this lane since the kernel started (KernelArgs::exec_count; not reset per ray)
 };
 
@@ -233,7 +233,7 @@ __device__ __forceinline__ void lean_begin(QuadWalk &W, uint32_t top_root) {
     W.q = NONE; W.e = NONE; W.sp = 0; W.top = NONE; W.tnode = top_root; W.tleaf = NONE; W.mesh = NONE;
     W.mhave = false; W.mmin = INFINITY; W.mt = 0; W.mtri = 0;
     W.have = false; W.occluded = false; W.tmin = INFINITY; W.bt = 0; W.btri = 0; W.bmesh = 0;
-    W.seen = 0;
+    seen_clear(W.seen);
 }
 
 enum : int { WALK_MORE = 0, WALK_DONE = 1, WALK_STACK_FULL = 2 };

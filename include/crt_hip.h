@@ -206,6 +206,8 @@ typedef struct crt_tuning {
     uint32_t pool;            /* shadow walks with three rays per lane (kernel_pool.h): bit 0 the bulk pass, bit 1 the deeper levels' */
     uint32_t pool_refill;     /* 48: lanes with a free place that make a refill round of that kernel worth it */
     uint32_t pool_switch;     /* 24: lanes below which its wave changes between node and triangle mode */
+    uint32_t early_shadow;    /* 0; 1: the bulk shadow pass starts straight after level 0's per-lane kernel, and the primary walks handed to
+                               * the wave-per-ray kernel queue their shadow rays for the later pass instead of using their fixed slots */
 } crt_tuning;
 void crt_tuning_defaults(crt_tuning *tuning);
 

@@ -81,6 +81,7 @@ KERNEL_PATHS = [
     dict(node_repeat=1), dict(node_repeat=4, tri_gather=24),     # shadow walk: node steps per trip, exclusive triangle trips
     dict(pool=3), dict(pool=1, pool_refill=1, pool_switch=64),   # shadow walks with three rays per lane (kernel_pool.h)
     dict(pool=3, pool_refill=64, pool_switch=1, level_shadows=1),
+    dict(early_shadow=1), dict(early_shadow=1, level0_budget=16, shadow_cap=1 << 20),  # bulk shadow pass after / before the evicted primary walks
     dict(level_shadows=1),                                       # the deeper levels' shadow rays in one pass at the end
     dict(heavy_waves=7),                                         # deeper levels' wave-per-ray launches on a 72-register budget
 ]
@@ -339,14 +340,16 @@ def test_executed_work_is_a_subset_of_the_reference_work(pkg, scenes, name):
     assert 0 < ex["box_tests"] <= 8 * ref["box_tests"]   # boxes: the wide kernels test 4 / 64 at a time, so not necessarily fewer
 
 
-def test_more_meshes_than_the_seen_mask_holds(pkg, scenes, oracle):
-    """72 objects: the one-walk-per-mesh shortcut keeps a 64-bit mask per ray, meshes 64.. are simply walked at every listed
-    occurrence like the reference does; the top-level tree is several levels deep and lists meshes in many leaves."""
+@pytest.mark.parametrize("n_objects", [72, 140, 280])
+def test_more_meshes_than_the_seen_mask_holds(pkg, scenes, oracle, n_objects):
+    """Many objects: the top-level tree is several levels deep and lists meshes in many leaves.  72: beyond the 64 top-level
+    nodes / meshes the register and plan forms hold (the LDS copy takes over); 140: beyond the 128-bit one-walk-per-mesh mask
+    (meshes 128.. are simply walked at every listed occurrence, like the reference does); 280: beyond the LDS copy as well."""
     base = scenes.make("hw11", width=96, height=64, detail=0.15)
     rng = np.random.default_rng(7)
     objects = list(base["objects"])
     n_mat = len(base["materials"])
-    while len(objects) < 72:                                               # small tetrahedra scattered through the room
+    while len(objects) < n_objects:                                        # small tetrahedra scattered through the room
         c = rng.uniform([-1.6, -0.8, -5.5], [1.6, 1.2, -2.0]).astype(np.float32)
         v = (c + rng.uniform(-0.25, 0.25, (4, 3))).astype(np.float32)
         objects.append({"material_index": int(rng.integers(0, n_mat)), "vertices": v,
@@ -356,8 +359,10 @@ def test_more_meshes_than_the_seen_mask_holds(pkg, scenes, oracle):
     want, counters = oracle.OracleScene(scenes.to_blob(scene)).render(4)
     got = tracer.render(max_depth=4, counters=True)
     assert tracer.stats().counters() == counters
-    assert_same_floats(got, want, "72 meshes (counting build)")
-    assert_same_floats(tracer.render(max_depth=4), want, "72 meshes (production kernels)")
+    assert_same_floats(got, want, "%d meshes (counting build)" % n_objects)
+    assert_same_floats(tracer.render(max_depth=4), want, "%d meshes (production kernels)" % n_objects)
+    heavy = make_tracer(pkg, scenes, scene, tuning=dict(step_budget=8, shadow_budget=8))   # nearly every walk by the wave-per-ray kernels
+    assert_same_floats(heavy.render(max_depth=4), want, "%d meshes (wave-per-ray kernels)" % n_objects)
 
 
 # ---------------------------------------------------------------------------------------------- several devices, one tracer
