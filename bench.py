@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tuning", default="", help="development: crt_tuning fields as 'name=value ...' (default: the library's defaults)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="development only: N processes share GPU 0 and gather through gloo on host buffers "
                          "(exercises the multi-rank code path on a one-GPU box; its numbers mean nothing)")
@@ -135,7 +136,7 @@ def main():
         folder = tempfile.mkdtemp(prefix="crt_bench_")
         sc.write_bitmaps(scene, folder)
     hs = pkg.Scene(json_text=sc.to_json(scene), folder=folder)
-    tracer = pkg.Tracer(hs, device=local_rank)
+    tracer = pkg.Tracer(hs, device=local_rank, tuning=pkg.tuning_from_string(args.tuning))
 
     n_tiles = tracer.packed_tile_count(0, 1)
     per_rank = (n_tiles + world - 1) // world            # tiles per rank, padded to the same count
@@ -275,7 +276,7 @@ def main():
             "config": {"workload": "%s, %d triangles, %dx%d, depth %d, 8x8 tiles dealt round-robin over %d GPU(s)"
                                    % (sc.DESCRIPTIONS.get(args.scene, args.scene), sc.triangle_count(scene), W, H, depth, world),
                        "scene": args.scene, "width": W, "height": H, "max_depth": depth,
-                       "parallelism": "tiles8x8-roundrobin-%d" % world},
+                       "parallelism": "tiles8x8-roundrobin-%d" % world, "tuning": args.tuning or "defaults"},
             "frame_matches_counting_build": frame_ok,
             "value_incl_d2h": round(W * H / d2h_elapsed / 1e6, 3),
             "kernel_ms": {"first_to_last": round(avg_kernel_ms, 4), "recursion_levels": round(pk_ms, 4),

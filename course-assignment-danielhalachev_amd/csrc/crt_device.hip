@@ -149,6 +149,8 @@ struct crt_ctx {
     uint32_t sizing_seen_fallbacks = 0, last_items = 0;
     uint64_t queue_bytes = 0;         // bytes of the per-frame buffers as allocated now
     hipEvent_t ev_level[MAX_GENERATIONS] = {};  // level g is done (its shadow rays may start on the side stream)
+    hipStream_t side2 = nullptr;      // crt_tuning::level_shadows >= 2: the first deeper levels' shadow rays, beside the bulk pass
+    hipEvent_t ev_side2 = nullptr;
     hipEvent_t ev_call0 = nullptr, ev_call1 = nullptr;  // around the last crt_render / crt_render_async call's device work
     bool pending = false;             // a frame enqueued by crt_render_async has not been waited for
     crt_options pending_options{};
@@ -396,6 +398,10 @@ extern "C" void crt_tuning_defaults(crt_tuning *t) {
     t->level_shadows = 0;
     t->pool = 0; t->pool_refill = 48; t->pool_switch = 24;
     t->early_shadow = 0;
+    t->deep_first = 1;
+    t->level_grid = 1;
+    t->wave_priority = 3;
+    t->side_priority = 1;
 }
 
 extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) { return crt_create_tuned(s, device, nullptr, out); }
@@ -446,7 +452,13 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
     CK(hipGetDeviceProperties(&prop, device));
     ctx->num_cus = prop.multiProcessorCount;
     CK(hipStreamCreate(&ctx->stream));
-    CK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    if (tune.side_priority) {
+        int least = 0, greatest = 0;
+        CK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        CK(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, least));
+    } else {
+        CK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    }
     for (int i = 0; i < crt_ctx::EV_RING; i++) {
         CK(hipEventCreate(&ctx->ev0[i]));
         CK(hipEventCreate(&ctx->ev1[i]));
@@ -949,6 +961,8 @@ extern "C" void crt_destroy(crt_ctx *ctx) {
         if (ctx->ev_s2[i]) (void)hipEventDestroy(ctx->ev_s2[i]);
     }
     for (int g = 0; g < MAX_GENERATIONS; g++) if (ctx->ev_level[g]) (void)hipEventDestroy(ctx->ev_level[g]);
+    if (ctx->ev_side2) (void)hipEventDestroy(ctx->ev_side2);
+    if (ctx->side2) (void)hipStreamDestroy(ctx->side2);
     if (ctx->ev_call0) (void)hipEventDestroy(ctx->ev_call0);
     if (ctx->ev_call1) (void)hipEventDestroy(ctx->ev_call1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1163,6 +1177,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
     const uint32_t lane_blocks = lane_need < ctx->grid_blocks ? lane_need : ctx->grid_blocks;
     if (timed) CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0[slot], stream));
     if (ctx->mode == crt_ctx::MODE_STREAM) {
+        const uint32_t prev_items = ctx->last_items;  // (the previous frame's counter block describes a frame of this many work items)
         rc = ensure_stream(ctx, n_items);
         if (rc) return rc;
         CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_scounts, 0, SC_ALLOC_WORDS * sizeof(uint32_t), stream));
@@ -1184,6 +1199,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         A.bundle = (A.plan_ok && ctx->bundle < 64u) ? ctx->bundle : 64u;
         A.fixed0 = 0;
         A.early_shadow = 0;
+        A.wave_prio = ctx->tuning.wave_priority > 3u ? 3u : ctx->tuning.wave_priority;
         if (ctx->fixed0) {  // level 0 owns the first n_items * 64 * n_lights slots of the shadow queue; the deeper levels append
             const uint64_t n0 = (uint64_t)n_items * 64u * ctx->n_lights;
             if (n0 <= A.s_shadow_cap) {
@@ -1213,6 +1229,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         A.tri_gather = ctx->tuning.tri_gather > 64u ? 64u : ctx->tuning.tri_gather;
         A.node_repeat = ctx->tuning.node_repeat < 1u ? 1u : (ctx->tuning.node_repeat > 8u ? 8u : ctx->tuning.node_repeat);
         KernelArgs S = A;  // argument block of the shadow passes
+        S.wave_prio = 0u;
         S.counters = ctx->d_counters + C_N;
         S.bundle = ctx->bundle;
         S.exec_counters = ctx->d_exec + 2;  // shadow pass 0 tallies on its own
@@ -1233,7 +1250,9 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         uint32_t budget0 = est0 >= ctx->step_budget ? ctx->step_budget : (est0 < 64u ? 64u : (uint32_t)est0);
         if (ctx->tuning.level0_budget) budget0 = ctx->tuning.level0_budget;
         // the recursion levels >= 1: one persistent queue-driven launch (kernel_deep.h), or a launch triple per level
-        const bool deep = heavy && ctx->tuning.deep && o->max_depth >= 1;
+        const uint32_t deep_first = ctx->tuning.deep_first < 1u ? 1u : ctx->tuning.deep_first;
+        const bool deep = heavy && ctx->tuning.deep && o->max_depth >= deep_first;
+        A.deep_first = deep_first;
         ctx->epoch = ctx->epoch == 0xFFFFFFFFu ? 1u : ctx->epoch + 1u;
         A.epoch = ctx->epoch;
         // 2a) the shadow rays level 0 queued (the bulk of them), on the side stream beside the deeper levels: launched after level 0
@@ -1251,8 +1270,11 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
             else if (lean && A.plan_ok) launch(stream_trace_shadow_plan<0>, side_blocks, ctx->side, S);
             else if (lean) launch(stream_trace_shadow_lean<0, false>, side_blocks, ctx->side, S);
             else launch(stream_trace_shadow<false>, side_blocks, ctx->side, S, 0u);
-            // the walks it gave up follow at once, still beside the levels; the mark comes before the event the
-            // caller's stream waits for, so nothing the later pass appends is below it
+            return CRT_OK;
+        };
+        // ... and, queued behind it on the side stream once the level loop has been issued: the walks it gave up, still beside
+        // the levels; the mark comes before the event the caller's stream waits for, so nothing the later pass appends is below it
+        auto finish_shadow0 = [&]() -> int {
             if (heavy && !count) hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, ctx->side, S, (uint32_t)SC_SHEAVY_SPLIT, (uint32_t)SC_SHEAVY);
             CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s1[slot], ctx->side));
             if (heavy && !count) launch(heavy_trace_shadow, heavy_blocks, ctx->side, S, 0u);
@@ -1261,6 +1283,9 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         };
         // the deeper levels' shadow rays level by level on the side stream (plan kernels only), or all at once at the end
         const bool level_shadows = lean && A.plan_ok && !(quad & 4u) && ctx->side_blocks_per_cu && !deep && !packets && ctx->tuning.level_shadows;
+        // level_shadows >= 2: only the levels 1 .. level_shadows, on a THIRD stream (beside the bulk pass, not behind it); the rest at the end
+        const uint32_t early_levels = level_shadows && ctx->tuning.level_shadows >= 2u ? std::min(ctx->tuning.level_shadows, (uint32_t)MAX_GENERATIONS - 2u) : 0u;
+        bool side2_used = false, forked = false;
         const uint32_t level_shadow_blocks = (uint32_t)ctx->num_cus * 2u;
         KernelArgs SL = S;  // their argument block: the second pass's budget (few rays, all tail)
         {
@@ -1272,17 +1297,27 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
             SL.exec_counters = ctx->d_exec;
             SL.exec_plan = ctx->d_exec + 4;
         }
-        for (uint32_t g = 0; g <= (deep ? 0u : o->max_depth); g++) {
+        for (uint32_t g = 0; g <= (deep ? deep_first - 1u : o->max_depth); g++) {
             A.step_budget = heavy ? (g == 0 ? budget0 : ctx->step_budget) : 0u;
+            // The per-lane kernel of a deeper level fetches its rays through a cursor, so any grid does the whole level; beside
+            // the bulk shadow pass every workgroup of it waits for a free slot, and a level below heavy_level_threshold has
+            // nothing for it to do (measured: 0.15 ms for an empty full-size grid).  Sized by what the level held a frame ago.
+            uint32_t level_blocks = lane_blocks;
+            if (g >= 1 && lean && !count && ctx->tuning.level_grid && prev_items == n_items && ctx->h_counts) {
+                const uint32_t prev = ctx->h_counts[SC_COUNT + g];
+                const uint32_t want = prev < A.heavy_level_threshold ? 64u : std::max<uint32_t>((uint32_t)ctx->num_cus, (prev + prev / 2u + BLOCK - 1) / BLOCK);
+                level_blocks = std::min(lane_blocks, want);
+            }
             if (count) launch(stream_trace_shade<true>, lane_blocks, stream, A, g);
-            else if (lean && A.plan_ok && (quad & 1u)) launch_lds(stream_trace_shade_plan<true>, lane_blocks, qlds + plds, stream, A, g);
-            else if (lean && A.plan_ok) launch_lds(stream_trace_shade_plan<false>, lane_blocks, plds, stream, A, g);
-            else if (lean && (quad & 1u)) launch_lds(stream_trace_shade_lean<true>, lane_blocks, qlds, stream, A, g);
-            else if (lean) launch(stream_trace_shade_lean<false>, lane_blocks, stream, A, g);
+            else if (lean && A.plan_ok && (quad & 1u)) launch_lds(stream_trace_shade_plan<true>, level_blocks, qlds + plds, stream, A, g);
+            else if (lean && A.plan_ok) launch_lds(stream_trace_shade_plan<false>, level_blocks, plds, stream, A, g);
+            else if (lean && (quad & 1u)) launch_lds(stream_trace_shade_lean<true>, level_blocks, qlds, stream, A, g);
+            else if (lean) launch(stream_trace_shade_lean<false>, level_blocks, stream, A, g);
             else launch(stream_trace_shade<false>, lane_blocks, stream, A, g);
-            if (g == 0 && A.early_shadow) { rc = fork_shadow0(); if (rc) return rc; }
+            if (g == 0 && A.early_shadow) { rc = fork_shadow0(); if (rc) return rc; forked = true; }
             if (heavy) {
                 if (ctx->tuning.heavy_waves == 7u && g > 0) launch(heavy_trace_closest<7>, heavy_blocks, stream, A, g);
+                else if (ctx->tuning.heavy_waves == 4u) launch(heavy_trace_closest<4>, heavy_blocks, stream, A, g);
                 else launch(heavy_trace_closest<5>, heavy_blocks, stream, A, g);
                 if (g == 0 && A.early_shadow) {  // the fixed shadow slots are being read already: queue these pixels' shadow rays
                     KernelArgs AE = A;
@@ -1296,15 +1331,30 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
             if (level_shadows) {
                 // where level g's shadow rays end; from level 1 on they are walked on the side stream while the next level runs
                 hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, stream, A, (uint32_t)(SC_LSPLIT + g + 1), (uint32_t)SC_SHADOW);
-                if (g >= 1) {
+                if (g >= 1 && (!early_levels || g <= early_levels)) {
+                    hipStream_t where = ctx->side;
+                    if (early_levels) {
+                        if (!ctx->side2) CRT_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking));
+                        where = ctx->side2;
+                        side2_used = true;
+                    }
                     if (!ctx->ev_level[g]) CRT_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_level[g], hipEventDisableTiming));
                     CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_level[g], stream));
-                    CRT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_level[g], 0));
-                    if (ctx->tuning.pool & 2u) launch_lds(stream_trace_shadow_pool_level, level_shadow_blocks, POOL_LDS_BYTES, ctx->side, SL, g);
-                    else launch(stream_trace_shadow_level, level_shadow_blocks, ctx->side, SL, g);
+                    CRT_HIP_CHECK(ctx, hipStreamWaitEvent(where, ctx->ev_level[g], 0));
+                    if (ctx->tuning.pool & 2u) launch_lds(stream_trace_shadow_pool_level, level_shadow_blocks, POOL_LDS_BYTES, where, SL, g);
+                    else launch(stream_trace_shadow_level, level_shadow_blocks, where, SL, g);
                 }
             }
-            if (g == 0 && ctx->side_blocks_per_cu && !A.early_shadow) { rc = fork_shadow0(); if (rc) return rc; }
+            if (g == 0 && ctx->side_blocks_per_cu && !A.early_shadow) { rc = fork_shadow0(); if (rc) return rc; forked = true; }
+        }
+        if (forked) {
+            if (side2_used) {  // the third stream's passes append to the list of walks given up: complete before the mark
+                if (!ctx->ev_side2) CRT_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_side2, hipEventDisableTiming));
+                CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_side2, ctx->side2));
+                CRT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_side2, 0));
+            }
+            rc = finish_shadow0();
+            if (rc) return rc;
         }
         if (deep) {
             A.step_budget = ctx->step_budget;
@@ -1343,7 +1393,12 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
             const uint32_t env1 = ctx->pass1_budget ? ctx->pass1_budget : ctx->step_budget;
             S.step_budget = heavy ? (est1 >= env1 ? env1 : (est1 < 64u ? 64u : (uint32_t)est1)) : 0u;
         }
-        if (level_shadows) {
+        if (early_levels) {
+            // the levels up to `early_levels` are done or under way on the third stream (the side stream, and through ev_s1 this
+            // one, waits for them): what the later levels queued
+            launch(stream_trace_shadow_rest, lane_blocks, stream, S, early_levels + 1u);
+        }
+        else if (level_shadows) {
             // every level's shadow rays are on the side stream already: wait for the last of them
             CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s2[slot], ctx->side));
         }
@@ -1725,7 +1780,7 @@ extern "C" int crt_describe_kernels(const crt_ctx *ctx, char *out, size_t size) 
         d += !lean ? "stream_trace_shadow<false>" : ((quad & 2u) ? "stream_trace_shadow_lean<0u, true>" : (A.plan_ok ? "stream_trace_shadow_plan<0u>" : "stream_trace_shadow_lean<0u, false>"));
         d += ";levels=";
         d += !heavy ? "stream_trace_shade<false>" : (ctx->tuning.deep == 1u ? "deep_trace" : (ctx->tuning.deep == 2u && A.plan_ok ? "deep_lanes" :
-             (ctx->tuning.heavy_waves == 7u ? "heavy_trace_closest<7>" : "heavy_trace_closest<5>")));
+             (ctx->tuning.heavy_waves == 7u ? "heavy_trace_closest<7>" : (ctx->tuning.heavy_waves == 4u ? "heavy_trace_closest<4>" : "heavy_trace_closest<5>"))));
     }
     snprintf(out, size, "%s", d.c_str());
     return CRT_OK;

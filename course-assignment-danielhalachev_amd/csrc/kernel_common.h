@@ -138,6 +138,8 @@ struct KernelArgs {
     const float4 *pnodes;
     uint32_t plan_list_words;     // LDS words per lane of a closest-hit ray's mesh list: ceil(meshes / 4)
     // kernel_deep.h: the level-free queue of the recursion levels >= 1
+    uint32_t deep_first;          // kernel_deep.h: the first recursion level the persistent launch handles
+    uint32_t wave_prio;           // s_setprio of the recursion levels' waves (crt_tuning::wave_priority)
     uint32_t early_shadow;        // level 0: the bulk shadow pass starts before the evicted primary walks are finished (kernel_plan.h)
     uint32_t pool_refill, pool_switch;  // kernel_pool.h: lanes with a free place that make a refill round worth it; lanes below which the wave changes mode
     uint32_t node_repeat;         // kernel_plan.h shadow walk: node steps per loop trip (>= 1)

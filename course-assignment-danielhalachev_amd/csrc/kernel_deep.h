@@ -12,9 +12,11 @@
 // when the child is created and travels with the ray -- and stream_resolve evaluates it in the reference's post-order, so
 // the order in which the waves happen to produce the nodes cannot change a bit of the frame.
 //
-// Queue = s_rayq[1].  Slots [0, tail0) are the level-1 rays that level 0 left there (complete before this launch).
-//   tail   s_counts[SC_COUNT + 1]   slots reserved so far (producers add to it BEFORE they bump `done`)
-//   head   s_counts[SC_FETCH + 1]   slots claimed so far (a claim may run ahead of tail: that wave waits for its slot)
+// The launch takes over at level f = KernelArgs::deep_first (1: everything below the primary rays; 3: only the thin levels,
+// whose launches are all latency -- crt_tuning::deep_first).  Queue = s_rayq[f & 1].  Slots [0, tail0) are the level-f rays
+// that level f - 1 left there (complete before this launch).
+//   tail   s_counts[SC_COUNT + f]   slots reserved so far (producers add to it BEFORE they bump `done`)
+//   head   s_counts[SC_FETCH + f]   slots claimed so far (a claim may run ahead of tail: that wave waits for its slot)
 //   done   s_counts[SC_DEEP_DONE]   claimed slots whose whole chain has been finished
 // Publication of a slot (agent scope, MI355X_MICROARCH.md "Workgroup dispatch ... inter-workgroup visibility"): EVERY
 // dword of the record is written with a relaxed agent-scope atomic store (global_store sc1: written through, coherent
@@ -49,9 +51,9 @@ __device__ __forceinline__ void agent_storef(float *p, float v) {
 // one thread, between level 0 and the deep launch
 __global__ void deep_begin(const KernelArgs A) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const uint32_t level1 = A.s_counts[SC_COUNT + 1];
-    A.s_counts[SC_DEEP_TAIL0] = level1;
-    A.s_counts[SC_DEEP_NODES] = A.n_items * 64u + level1;   // level-1 ray k owns node n_items * 64 + k (shade_and_emit)
+    const uint32_t first = A.s_counts[SC_COUNT + A.deep_first];
+    A.s_counts[SC_DEEP_TAIL0] = first;
+    A.s_counts[SC_DEEP_NODES] = stream_level_base(A, A.deep_first) + first;   // ray k of level g owns node base(g) + k (shade_and_emit)
     A.s_counts[SC_DEEP_DONE] = 0;
     A.s_counts[SC_DEEP_CHAINED] = 0;
 }
@@ -71,7 +73,7 @@ __device__ __forceinline__ void deep_store_record(float4 *q, const size_t index,
 // transmission rays go into the queue.  Returns false when a queue ran full (the overflow word is up).
 __device__ __forceinline__ bool deep_wave_chain(const KernelArgs &A, const TopRegs &TR, Ray R, uint32_t gen, uint32_t node, bool prepared,
                                                 const uint32_t lane, uint32_t &node_next, uint32_t &node_left, uint32_t &chained) {
-    uint32_t *const tail = A.s_counts + SC_COUNT + 1;
+    uint32_t *const tail = A.s_counts + SC_COUNT + A.deep_first;
     for (uint32_t hops = 0; hops <= A.max_depth; hops++) {  // (a chain cannot be longer than the recursion is deep)
         if (!prepared) normalize3(R.dx, R.dy, R.dz);  // shootRay entry (RayTracer.cpp:420)
         prepared = false;
@@ -106,7 +108,7 @@ __device__ __forceinline__ bool deep_wave_chain(const KernelArgs &A, const TopRe
                     E.N.a = nb;
                     if (E.transmit) {
                         E.N.b = nb + 1u;
-                        deep_store_record(A.s_rayq[1], ts, E.tox, E.toy, E.toz, gen + 1u, E.tdx, E.tdy, E.tdz, nb + 1u);
+                        deep_store_record(A.s_rayq[A.deep_first & 1u], ts, E.tox, E.toy, E.toz, gen + 1u, E.tdx, E.tdy, E.tdz, nb + 1u);
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the record is in place before the flag goes up
                         __hip_atomic_store(A.s_ready + ts, A.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
@@ -141,7 +143,7 @@ __device__ __forceinline__ bool deep_load_record(const KernelArgs &A, const floa
 
 // "Everything that was ever reserved has been finished": tail, done, tail read in this order, equal and unchanged.
 __device__ __forceinline__ bool deep_all_done(const KernelArgs &A, uint32_t &tail_now) {
-    const uint32_t t1 = agent_load(A.s_counts + SC_COUNT + 1), d = agent_load(A.s_counts + SC_DEEP_DONE), t2 = agent_load(A.s_counts + SC_COUNT + 1);
+    const uint32_t t1 = agent_load(A.s_counts + SC_COUNT + A.deep_first), d = agent_load(A.s_counts + SC_DEEP_DONE), t2 = agent_load(A.s_counts + SC_COUNT + A.deep_first);
     tail_now = t1;
     return t1 == t2 && d == t1;
 }
@@ -150,7 +152,7 @@ template <int WAVES_PER_SIMD>  // register budget: 4 = what the compiler takes b
 __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void deep_trace(const KernelArgs A) {
     const uint32_t lane = threadIdx.x & 63u;
     if (A.s_counts[SC_OVERFLOW]) return;
-    uint32_t *const head = A.s_counts + SC_FETCH + 1;
+    uint32_t *const head = A.s_counts + SC_FETCH + A.deep_first;
     uint32_t *const done = A.s_counts + SC_DEEP_DONE;
     const uint32_t tail0 = A.s_counts[SC_DEEP_TAIL0];   // written by deep_begin, a launch ago
     const TopRegs TR = heavy_top_load(A, lane);
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void deep_trace(const Kernel
         // ---- the slot's ray; then, for as long as a hit is a mirror, its reflection ray without going through the queue
         Ray R;
         uint32_t gen = 0, node = 0;
-        if (!deep_load_record(A, A.s_rayq[1], slot, R, gen, node)) {  // not a record of this frame: never follow it
+        if (!deep_load_record(A, A.s_rayq[A.deep_first & 1u], slot, R, gen, node)) {  // not a record of this frame: never follow it
             if (lane == 0) { A.s_counts[SC_GUARD] = 3; atomicExch(A.s_counts + SC_OVERFLOW, 1u); }
             break;
         }
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void deep_trace(const Kernel
 //   lane waves   every lane claims a queue slot, waits (without blocking the other lanes) until its record is published,
 //                plans and walks the ray (binary nodes), shades it, publishes the transmission child, goes on with the
 //                reflection child itself; a walk that outlasts the step budget, or a ray with a direction component below
-//                FLT_EPSILON, is handed over through the heavy queue (s_rayq[0], flags s_ready2);
+//                FLT_EPSILON, is handed over through the heavy queue (the other s_rayq, flags s_ready2);
 //   heavy waves  (every A.deep_heavy_every-th wave) take those rays and finish their chains the way deep_trace does.
 // Every workgroup holds both roles, so whatever is resident can finish whatever exists: no wave ever waits for work that
 // only a non-resident wave could do.  Accounting as in deep_trace: a claimed slot is `done` when its chain has ended --
@@ -252,7 +254,7 @@ __device__ __forceinline__ void deep_heavy_role(const KernelArgs &A, const uint3
         if (!alive) break;
         Ray R;
         uint32_t gen = 0, node = 0;
-        if (!deep_load_record(A, A.s_rayq[0], h, R, gen, node)) {
+        if (!deep_load_record(A, A.s_rayq[(A.deep_first & 1u) ^ 1u], h, R, gen, node)) {
             if (lane == 0) { A.s_counts[SC_GUARD] = 5; atomicExch(A.s_counts + SC_OVERFLOW, 1u); }
             break;
         }
@@ -273,8 +275,8 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void deep_lanes(const Kernel
     const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (A.deep_heavy_every && (wave_in_block % A.deep_heavy_every) == A.deep_heavy_every - 1u) { deep_heavy_role(A, lane); return; }
 
-    uint32_t *const head = A.s_counts + SC_FETCH + 1;
-    uint32_t *const tail = A.s_counts + SC_COUNT + 1;
+    uint32_t *const head = A.s_counts + SC_FETCH + A.deep_first;
+    uint32_t *const tail = A.s_counts + SC_COUNT + A.deep_first;
     uint32_t *const done = A.s_counts + SC_DEEP_DONE;
     const uint32_t tail0 = A.s_counts[SC_DEEP_TAIL0];
     const char *nodes_b = reinterpret_cast<const char *>(A.pnodes);
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void deep_lanes(const Kernel
         if (state == ST_PENDING) {
             const bool ready = slot < tail0 || (slot < A.s_ray_cap && agent_load(A.s_ready + slot) == A.epoch);
             if (ready) {
-                if (deep_load_record(A, A.s_rayq[1], slot, R, gen, node)) {
+                if (deep_load_record(A, A.s_rayq[A.deep_first & 1u], slot, R, gen, node)) {
                     normalize3(R.dx, R.dy, R.dz);  // shootRay entry (RayTracer.cpp:420)
                     fresh = true;
                     state = ST_TRAVERSE;
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void deep_lanes(const Kernel
                         const uint32_t k = (uint32_t)__popcll(m2 & below);
                         E.N.b = nbase + n1 + k;
                         pub_slot = tbase + k;
-                        deep_store_record(A.s_rayq[1], pub_slot, E.tox, E.toy, E.toz, gen + 1u, E.tdx, E.tdy, E.tdz, nbase + n1 + k);
+                        deep_store_record(A.s_rayq[A.deep_first & 1u], pub_slot, E.tox, E.toy, E.toz, gen + 1u, E.tdx, E.tdy, E.tdz, nbase + n1 + k);
                         published = true;
                     }
                     go_on = true;
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void deep_lanes(const Kernel
             hbase = __shfl(hbase, __ffsll((long long)m) - 1);
             hq_slot = hbase + (uint32_t)__popcll(m & below);
             if (hq_slot >= A.s_ray_cap) { atomicExch(A.s_counts + SC_OVERFLOW, 1u); to_heavy = false; }
-            else deep_store_record(A.s_rayq[0], hq_slot, R.ox, R.oy, R.oz, gen | DEEP_PREPARED, R.dx, R.dy, R.dz, node);
+            else deep_store_record(A.s_rayq[(A.deep_first & 1u) ^ 1u], hq_slot, R.ox, R.oy, R.oz, gen | DEEP_PREPARED, R.dx, R.dy, R.dz, node);
             state = ST_FETCH;  // the slot's `done` is the heavy wave's to report
             chain_fresh = false;
         }

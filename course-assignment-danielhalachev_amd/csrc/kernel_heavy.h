@@ -386,6 +386,7 @@ __device__ __forceinline__ float uniform_f(float v) { return __uint_as_float(__b
 template <int WAVES_PER_SIMD>  // register budget: 5 = what the compiler takes by itself (91 VGPRs); 7 = 72 VGPRs with spills, which
                                // lets three of these waves per SIMD (not two) sit beside the bulk shadow pass's four
 __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void heavy_trace_closest(const KernelArgs A, const uint32_t gen) {
+    if (A.wave_prio) __builtin_amdgcn_s_setprio(3);  // crt_tuning::wave_priority: ahead of the bulk shadow pass's waves on this SIMD
     __shared__ TopLdsStorage top_storage;  // used when the top-level tree is too large for the registers and small enough for this
     TopLds TL;
     TL.fast = false;

@@ -203,6 +203,12 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shadow_level(const KernelA
     shadow_plan_walks(A, begin, end > begin ? end - begin : 0u, A.s_counts + SC_LFETCH + gen);
 }
 
+// ... and everything from recursion level `gen` on, at the end of the frame (crt_tuning::level_shadows >= 2)
+__global__ __launch_bounds__(BLOCK) void stream_trace_shadow_rest(const KernelArgs A, const uint32_t gen) {
+    const uint32_t begin = gen <= A.max_depth + 1u ? A.s_counts[SC_LSPLIT + gen] : A.s_counts[SC_SHADOW], end = A.s_counts[SC_SHADOW];
+    shadow_plan_walks(A, begin, end > begin ? end - begin : 0u, A.s_counts + SC_LFETCH + gen);
+}
+
 // ---------------------------------------------------------------------------------------------------------- closest hit
 // The meshes a closest-hit ray has to walk, in the reference's order, as a byte list per lane in LDS: word w of thread t at
 // list[w * BLOCK + t] holds entries 4w .. 4w+3 (conflict-free: consecutive lanes, consecutive words).
@@ -260,6 +266,7 @@ __device__ __forceinline__ void early_shadow_release(const KernelArgs &A, const 
 // step budget and (QUAD) walks that outgrow the LDS stack go to heavy_trace_closest.
 template <bool QUAD>
 __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArgs A, const uint32_t gen) {
+    if (A.wave_prio) __builtin_amdgcn_s_setprio(3);  // crt_tuning::wave_priority: ahead of the bulk shadow pass's waves on this SIMD
     extern __shared__ uint32_t plan_lds[];  // [quad stack: A.quad_stack_depth x BLOCK (QUAD only)] [mesh lists: A.plan_list_words x BLOCK]
     __shared__ TopLdsStorage top_storage;
     const TopLds TL = top_lds_load(A, top_storage);  // mesh records {flags, tree root, quad root} (a barrier inside)

@@ -366,6 +366,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade(const KernelArgs A, 
 // Rays with a parallel axis and walks longer than step_budget go to heavy_trace_closest.
 template <bool QUAD>
 __global__ __launch_bounds__(BLOCK) void stream_trace_shade_lean(const KernelArgs A, const uint32_t gen) {
+    if (A.wave_prio) __builtin_amdgcn_s_setprio(3);  // crt_tuning::wave_priority: ahead of the bulk shadow pass's waves on this SIMD
     extern __shared__ uint32_t qstack[];  // QUAD: A.quad_stack_depth x BLOCK words
     __shared__ TopLdsStorage top_storage;
     const TopLds TL = top_lds_load(A, top_storage);  // (a barrier inside: before any return)
@@ -568,6 +569,7 @@ __global__ __launch_bounds__(BLOCK) void stream_packets_gen0(const KernelArgs A)
 // Shading of the rays stream_trace_shade(gen) evicted, after heavy_trace_closest(gen) has found their hits.
 template <bool COUNT>
 __global__ __launch_bounds__(BLOCK) void stream_shade_evicted(const KernelArgs A, const uint32_t gen) {
+    if (A.wave_prio) __builtin_amdgcn_s_setprio(3);  // crt_tuning::wave_priority: ahead of the bulk shadow pass's waves on this SIMD
     // (early_shadow, kernel_plan.h: level 0's fixed shadow slots are being read already, so the host passes level 0's launch
     // a copy of the arguments with fixed0 = 0 and this pixel's shadow rays are queued)
     const uint32_t lane = threadIdx.x & 63u;

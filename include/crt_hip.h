@@ -200,14 +200,23 @@ typedef struct crt_tuning {
     uint32_t level0_budget;   /* 0 (= min(step_budget, what a lane gets through in the launch)): steps after which a PRIMARY ray's
                                * walk goes to the wave-per-ray kernel */
     uint32_t node_repeat;     /* 2: node steps per loop trip of the planned shadow walk (one triangle step per trip) */
-    uint32_t heavy_waves;     /* 5: register budget of the deeper levels' wave-per-ray launches in waves per SIMD (5 or 7) */
+    uint32_t heavy_waves;     /* 5: register budget of the deeper levels' wave-per-ray launches in waves per SIMD (4, 5 or 7) */
     uint32_t level_shadows;   /* 0: all the deeper levels' shadow rays in one pass at the end of the frame; 1: a deeper level's shadow
-                               * rays are queued on the side stream as soon as the level is done */
+                               * rays are queued on the side stream (behind the bulk pass) as soon as the level is done; n >= 2: the shadow
+                               * rays of the levels 1..n each on a THIRD stream as soon as the level is done, beside the bulk pass, and one
+                               * pass over the later levels' at the end */
     uint32_t pool;            /* shadow walks with three rays per lane (kernel_pool.h): bit 0 the bulk pass, bit 1 the deeper levels' */
     uint32_t pool_refill;     /* 48: lanes with a free place that make a refill round of that kernel worth it */
     uint32_t pool_switch;     /* 24: lanes below which its wave changes between node and triangle mode */
     uint32_t early_shadow;    /* 0; 1: the bulk shadow pass starts straight after level 0's per-lane kernel, and the primary walks handed to
                                * the wave-per-ray kernel queue their shadow rays for the later pass instead of using their fixed slots */
+    uint32_t deep_first;      /* 1: with `deep`, the first recursion level the persistent launch handles (the levels before it run level by
+                               * level) */
+    uint32_t level_grid;      /* 1: the per-lane launch of a deeper level is sized by the rays that level held in the previous frame (0: always
+                               * the full grid) */
+    uint32_t wave_priority;   /* 3 (0..3): s_setprio of the recursion levels' waves (the frame's critical path) over the bulk shadow pass's, which
+                               * shares the SIMDs with them */
+    uint32_t side_priority;   /* 1 (0 = default priority): the side stream (bulk shadow pass) is created with the lowest stream priority */
 } crt_tuning;
 void crt_tuning_defaults(crt_tuning *tuning);
 

@@ -72,7 +72,11 @@ KERNEL_PATHS = [
     dict(deep=0, heavy_level=0),                                 # ... with the per-lane kernels at every level
     dict(deep=1, deep_blocks=3),                                 # persistent deep kernel on a tiny grid
     dict(deep=1, deep_waves=4, deep_blocks=4096),                # ... with its natural register budget, on a grid larger than the chip
+    dict(deep=1, deep_first=3),                                  # ... only from recursion level 3 on (levels 0-2 level by level)
+    dict(deep=1, deep_first=2, wave_priority=0, side_priority=0),# ... from level 2 on; no wave / stream priorities
+    dict(deep=1, deep_first=20),                                 # ... beyond the recursion depth: never launched
     dict(deep=2),                                                # persistent deep kernel, one ray per lane + heavy waves
+    dict(deep=2, deep_first=2),                                  # ... from level 2 on (the queues swap roles)
     dict(deep=2, step_budget=8),                                 # ... nearly every walk handed to the heavy waves
     dict(deep=2, deep_blocks=2, deep_heavy_every=2, bundle=64),  # ... two workgroups, half the waves heavy, lanes refill one by one
     dict(deep=2, deep_waves=4, deep_blocks=4096, bundle=0),      # ... a grid larger than the chip; lanes refill only when the wave is empty
@@ -82,6 +86,8 @@ KERNEL_PATHS = [
     dict(pool=3), dict(pool=1, pool_refill=1, pool_switch=64),   # shadow walks with three rays per lane (kernel_pool.h)
     dict(pool=3, pool_refill=64, pool_switch=1, level_shadows=1),
     dict(early_shadow=1), dict(early_shadow=1, level0_budget=16, shadow_cap=1 << 20),  # bulk shadow pass after / before the evicted primary walks
+    dict(level_shadows=2),                                       # levels 1-2's shadow rays on a third stream beside the bulk pass, the rest at the end
+    dict(level_shadows=4, wave_priority=2, level_grid=0),        # ... levels 1-4's
     dict(level_shadows=1),                                       # the deeper levels' shadow rays in one pass at the end
     dict(heavy_waves=7),                                         # deeper levels' wave-per-ray launches on a 72-register budget
 ]
