@@ -76,7 +76,8 @@ class SceneDesc(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("max_depth", C.c_uint32), ("shadow_bias", C.c_float), ("reflection_bias", C.c_float),
-                ("refraction_bias", C.c_float), ("use_gi", C.c_uint32), ("collect_counters", C.c_uint32)]
+                ("refraction_bias", C.c_float), ("use_gi", C.c_uint32), ("collect_counters", C.c_uint32),
+                ("gi_sample_size", C.c_uint32), ("rays_per_pixel", C.c_uint32), ("monte_carlo_bias", C.c_float), ("gi_seed", C.c_uint32)]
 
 
 class Rect(C.Structure):
@@ -131,7 +132,7 @@ def tuning_from_string(text):
 # every symbol include/crt_hip.h and include/crt_host.h declare
 DEVICE_SYMBOLS = ["crt_tuning_defaults", "crt_create_tuned", "crt_create", "crt_set_camera", "crt_render", "crt_render_tiles_device", "crt_packed_tile_count",
                   "crt_unpack_tiles_device", "crt_quantize_device", "crt_read_quantized", "crt_kernel_elapsed_ms", "crt_kernel_times_ms",
-                  "crt_get_stats", "crt_get_kernel_counters", "crt_synchronize", "crt_destroy", "crt_last_error", "crt_device_count", "crt_test_pow5",
+                  "crt_get_stats", "crt_get_kernel_counters", "crt_synchronize", "crt_destroy", "crt_last_error", "crt_device_count", "crt_test_pow5", "crt_test_gi",
                   "crt_describe_kernels", "crt_debug_stream_counts", "crt_debug_packet_counters", "crt_get_executed_counters", "crt_get_executed_plan_tests",
                   "crt_render_async", "crt_wait", "crt_alloc_pinned", "crt_free_pinned",
                   "crt_build_tree_device", "crt_built_tree_node_count", "crt_built_tree_index_total", "crt_built_tree_boxes",
@@ -235,9 +236,12 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def make_options(max_depth=5, shadow_bias=1e-4, reflection_bias=1e-4, refraction_bias=1e-4, counters=False):
+def make_options(max_depth=5, shadow_bias=1e-4, reflection_bias=1e-4, refraction_bias=1e-4, counters=False, use_gi=False,
+                 gi_sample_size=2, rays_per_pixel=1, monte_carlo_bias=1e-4, gi_seed=0):
     # counters: False / True (the counting build, reference semantics) / 2 (production kernels tallying executed tests)
-    return Options(max_depth, shadow_bias, reflection_bias, refraction_bias, 0, int(counters))
+    # use_gi: the reference's GI / multi-sample mode (RayTracer.h:27-30) with the counter-based generator of csrc/gi_random.h
+    return Options(max_depth, shadow_bias, reflection_bias, refraction_bias, int(bool(use_gi)), int(counters), gi_sample_size,
+                   rays_per_pixel, monte_carlo_bias, gi_seed)
 
 
 def _host_check(rc):

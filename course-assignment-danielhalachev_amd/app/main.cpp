@@ -15,7 +15,8 @@
 int main(int argc, char **argv) {
   if (argc < 3) {
     std::fprintf(stderr,
-                 "usage: %s scene.crtscene out.ppm [--folder DIR] [--depth N] [--mode 0..9] [--device D | --devices 0-7 | --devices 0,2,5] [--repeat K]\n",
+                 "usage: %s scene.crtscene out.ppm [--folder DIR] [--depth N] [--mode 0..9] [--device D | --devices 0-7 | --devices 0,2,5] [--repeat K]\n"
+                 "       [--gi GI_SAMPLE_SIZE RAYS_PER_PIXEL [--seed S]]   (RenderOptions::USE_GI, RayTracer.h:27-30)\n",
                  argv[0]);
     return 2;
   }
@@ -23,6 +24,8 @@ int main(int argc, char **argv) {
   unsigned depth = 5;
   int mode = crt::BVHBucketsThreadPool, device = 0, repeat = 1;
   std::vector<int> devices;  // --devices: the frame's tiles over several GPUs (first one gathers)
+  bool useGI = false;
+  unsigned giSamples = 2, raysPerPixel = 1, seed = 0;
   for (int i = 3; i < argc; i++) {
     if (!strcmp(argv[i], "--folder") && i + 1 < argc) folder = argv[++i];
     else if (!strcmp(argv[i], "--depth") && i + 1 < argc) depth = (unsigned)atoi(argv[++i]);
@@ -41,6 +44,8 @@ int main(int argc, char **argv) {
       }
     }
     else if (!strcmp(argv[i], "--repeat") && i + 1 < argc) repeat = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--gi") && i + 2 < argc) { useGI = true; giSamples = (unsigned)atoi(argv[++i]); raysPerPixel = (unsigned)atoi(argv[++i]); }
+    else if (!strcmp(argv[i], "--seed") && i + 1 < argc) seed = (unsigned)strtoul(argv[++i], nullptr, 0);
   }
   try {
     crt::SceneParser parser;
@@ -49,7 +54,8 @@ int main(int argc, char **argv) {
     std::unique_ptr<crt::RayTracer> tracerPtr(devices.size() > 0 ? new crt::RayTracer(scene, devices) : new crt::RayTracer(scene, device));
     crt::RayTracer &tracer = *tracerPtr;
     auto t1 = std::chrono::high_resolution_clock::now();
-    crt::RenderOptions options((crt::RenderOptimization)mode, depth, false);
+    crt::RenderOptions options((crt::RenderOptimization)mode, depth, useGI, giSamples, raysPerPixel);
+    tracer.setGISeed(seed);  // frame r of this run uses seed + r (the reference's GI frames all differ: clock() ^ thread id)
     double best = 1e30;
     for (int r = 0; r < repeat; r++) {
       auto a = std::chrono::high_resolution_clock::now();

@@ -224,6 +224,51 @@ extern "C" int crt_test_pow5(int device, const float *x, float *out, uint64_t n)
     return rc;
 }
 
+__host__ __device__ static inline uint32_t gi_test_value(uint32_t what, uint32_t a, uint32_t b) {
+    float f;
+    memcpy(&f, &a, sizeof(f));
+    float r = 0;
+    switch (what) {
+        case 0: r = crt_sinf(f); break;
+        case 1: r = crt_cosf(f); break;
+        case 2: r = crt_gi_uniform(a, b); break;
+        default: return crt_gi_mix(a, b);
+    }
+    uint32_t u;
+    memcpy(&u, &r, sizeof(u));
+    return u;
+}
+__global__ void gi_test_kernel(uint32_t what, const uint32_t *a, const uint32_t *b, uint32_t *out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = gi_test_value(what, a[i], b ? b[i] : 0u);
+}
+// Unit-test hook: the GI mode's sinf / cosf / generator (csrc/glibc_sincosf.h, csrc/gi_random.h) on host arrays.
+extern "C" int crt_test_gi(int device, uint32_t what, const uint32_t *a, const uint32_t *b, uint32_t *out, uint64_t n) {
+    if (!a || !out || what > 3u || (what >= 2u && !b)) return CRT_ERR_INVALID;
+    if (device < 0) {
+        for (uint64_t i = 0; i < n; i++) out[i] = gi_test_value(what, a[i], b ? b[i] : 0u);
+        return CRT_OK;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) return CRT_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return CRT_ERR_HIP;
+    uint32_t *da = nullptr, *db = nullptr, *dout = nullptr;
+    int rc = CRT_OK;
+    if (hipMalloc((void **)&da, (n ? n : 1) * 4) != hipSuccess || hipMalloc((void **)&db, (n ? n : 1) * 4) != hipSuccess ||
+        hipMalloc((void **)&dout, (n ? n : 1) * 4) != hipSuccess) rc = CRT_ERR_NOMEM;
+    if (rc == CRT_OK && n) {
+        if (hipMemcpy(da, a, n * 4, hipMemcpyHostToDevice) != hipSuccess || (b && hipMemcpy(db, b, n * 4, hipMemcpyHostToDevice) != hipSuccess)) rc = CRT_ERR_HIP;
+        if (rc == CRT_OK) {
+            hipLaunchKernelGGL(gi_test_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, what, da, b ? db : nullptr, dout, n);
+            if (hipGetLastError() != hipSuccess || hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = CRT_ERR_HIP;
+        }
+    }
+    if (da) (void)hipFree(da);
+    if (db) (void)hipFree(db);
+    if (dout) (void)hipFree(dout);
+    return rc;
+}
+
 extern "C" int crt_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -983,7 +1028,8 @@ extern "C" int crt_set_camera(crt_ctx *ctx, const float position[3], const float
 
 static int check_options(crt_ctx *ctx, const crt_options *o) {
     if (!o) { ctx->error = "options is NULL"; return CRT_ERR_INVALID; }
-    if (o->use_gi) { ctx->error = "USE_GI is outside this path (non-deterministic in the reference)"; return CRT_ERR_INVALID; }
+    if (o->use_gi && o->collect_counters == 2) { ctx->error = "collect_counters == 2 belongs to the ray-stream kernels; the GI mode renders with render_lanes"; return CRT_ERR_INVALID; }
+    if (o->use_gi && (o->gi_sample_size > 64u || o->rays_per_pixel > 65536u)) { ctx->error = "gi_sample_size > 64 or rays_per_pixel > 65536"; return CRT_ERR_INVALID; }
     if (o->max_depth > 4096) { ctx->error = "max_depth too large"; return CRT_ERR_INVALID; }
     return CRT_OK;
 }
@@ -1003,9 +1049,9 @@ static int ensure_items(crt_ctx *ctx, size_t n) {
     return CRT_OK;
 }
 
-static int ensure_frames(crt_ctx *ctx, uint32_t max_depth) {
+static int ensure_frames(crt_ctx *ctx, uint32_t max_depth, bool gi) {
     const size_t waves = (size_t)ctx->grid_blocks * (BLOCK / 64);
-    const size_t per_wave = (size_t)(max_depth + 1) * FRAME_DWORDS * 64;
+    const size_t per_wave = (size_t)(max_depth + 1) * (gi ? FRAME_DWORDS_GI : FRAME_DWORDS) * 64;
     if (waves * per_wave > ctx->frames_floats) {
         if (ctx->d_frames) (void)hipFree(ctx->d_frames);
         ctx->d_frames = nullptr;
@@ -1141,10 +1187,16 @@ static void launch_lds(K kernel, uint32_t blocks, uint32_t lds_bytes, hipStream_
 
 static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, float *d_out, uint32_t packed,
                          hipStream_t stream, bool timed) {
-    int rc = ensure_frames(ctx, o->max_depth);
+    const bool gi = o->use_gi != 0;  // the GI / multi-sample mode: rendered pixel by pixel by render_lanes<.., true> (kernel_lane.h)
+    int rc = ensure_frames(ctx, o->max_depth, gi);
     if (rc) return rc;
     KernelArgs &A = ctx->args;
-    if (ctx->mode == crt_ctx::MODE_STREAM && o->max_depth + 1 > (uint32_t)MAX_GENERATIONS) {
+    A.use_gi = gi ? 1u : 0u;
+    A.gi_samples = o->gi_sample_size;
+    A.rays_per_pixel = o->rays_per_pixel;
+    A.monte_carlo_bias = o->monte_carlo_bias;
+    A.gi_seed = o->gi_seed;
+    if (!gi && ctx->mode == crt_ctx::MODE_STREAM && o->max_depth + 1 > (uint32_t)MAX_GENERATIONS) {
         ctx->error = "max_depth too large for the ray-stream pass";
         return CRT_ERR_INVALID;
     }
@@ -1176,7 +1228,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
     const uint32_t lane_need = (n_items * 64u + BLOCK - 1) / BLOCK;
     const uint32_t lane_blocks = lane_need < ctx->grid_blocks ? lane_need : ctx->grid_blocks;
     if (timed) CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0[slot], stream));
-    if (ctx->mode == crt_ctx::MODE_STREAM) {
+    if (ctx->mode == crt_ctx::MODE_STREAM && !gi) {
         const uint32_t prev_items = ctx->last_items;  // (the previous frame's counter block describes a frame of this many work items)
         rc = ensure_stream(ctx, n_items);
         if (rc) return rc;
@@ -1424,7 +1476,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         CRT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_scounts, SC_ALLOC_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         if (timed) CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev3[slot], stream));
     } else {
-        if (ctx->mode == crt_ctx::MODE_PACKETS) {
+        if (ctx->mode == crt_ctx::MODE_PACKETS && !gi) {
             // coherent work: one wave per 8x8 tile; what it defers goes to the lane kernel
             const uint32_t need = (n_items + BLOCK / 64 - 1) / (BLOCK / 64);
             const uint32_t blocks = need < ctx->grid_blocks ? need : ctx->grid_blocks;
@@ -1435,7 +1487,9 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         }
         if (timed) CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev1[slot], stream));
         A.counters = ctx->d_counters + C_N;
-        if (count) launch(render_lanes<true>, lane_blocks, stream, A);
+        if (gi && count) launch(render_lanes<true, true>, lane_blocks, stream, A);
+        else if (gi) launch(render_lanes<false, true>, lane_blocks, stream, A);
+        else if (count) launch(render_lanes<true>, lane_blocks, stream, A);
         else launch(render_lanes<false>, lane_blocks, stream, A);
         CRT_HIP_CHECK(ctx, hipGetLastError());
         if (timed) {

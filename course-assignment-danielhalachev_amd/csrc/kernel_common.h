@@ -8,6 +8,7 @@ constexpr uint32_t LAST = CRT_ENTRY_LAST;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr int TILE = 8;             // 8x8 pixel tiles: 64 pixels = one wavefront's worth
 constexpr int FRAME_DWORDS = 8;     // per recursion level and lane
+constexpr int FRAME_DWORDS_GI = 18; // ... in the GI mode (kernel_lane.h)
 constexpr int BLOCK = 256;
 constexpr float PI_F = 3.14159265358979323846f;  // M_PIf, RayTracer.cpp:27
 
@@ -138,6 +139,8 @@ struct KernelArgs {
     const float4 *pnodes;
     uint32_t plan_list_words;     // LDS words per lane of a closest-hit ray's mesh list: ceil(meshes / 4)
     // kernel_deep.h: the level-free queue of the recursion levels >= 1
+    uint32_t use_gi, gi_samples, rays_per_pixel, gi_seed;  // crt_options: the GI / multi-sample mode (kernel_lane.h, gi_random.h)
+    float monte_carlo_bias;
     uint32_t deep_first;          // kernel_deep.h: the first recursion level the persistent launch handles
     uint32_t wave_prio;           // s_setprio of the recursion levels' waves (crt_tuning::wave_priority)
     uint32_t early_shadow;        // level 0: the bulk shadow pass starts before the evicted primary walks are finished (kernel_plan.h)

@@ -8,6 +8,54 @@
 #pragma once
 
 #include "kernel_common.h"
+#include "gi_random.h"
+#include "glibc_sincosf.h"
+
+// GI frames (FR_DIFFUSE_GI and, in the GI mode, every other kind) are FRAME_DWORDS_GI wide:
+//   [0] kind   [1..3] the direct light sum (finalColor)   [4..6] the indirect sum   [7] samples done
+//   [8] the invocation's key (gi_random.h; every kind keeps it here)   [9..11] hit point   [12..14] hit normal   [15..17] incoming direction
+enum : int { FR_DIFFUSE_GI = 4 };
+
+// RayTracer::getRay with the pixel offsets given (RayTracer.cpp:61-80; 0.5, 0.5 = primary_ray), then shootRay's own normalisation
+__device__ __forceinline__ void primary_ray_offset(const KernelArgs &A, uint32_t px, uint32_t py, float offx, float offy, Ray &R) {
+    float x = (float)px + offx;
+    float y = (float)py + offy;
+    x = x / (float)A.width;
+    y = y / (float)A.height;
+    x = (2.0f * x) - 1.0f;
+    y = 1.0f - (2.0f * y);
+    x = x * ((float)A.width / (float)A.height);
+    const float z = -1.0f;
+    R.dx = x * A.cam[0] + y * A.cam[3] + z * A.cam[6];
+    R.dy = x * A.cam[1] + y * A.cam[4] + z * A.cam[7];
+    R.dz = x * A.cam[2] + y * A.cam[5] + z * A.cam[8];
+    normalize3(R.dx, R.dy, R.dz);
+    R.ox = A.cam_pos[0]; R.oy = A.cam_pos[1]; R.oz = A.cam_pos[2];
+    normalize3(R.dx, R.dy, R.dz);
+    ray_prepare(R);
+}
+
+// The direction of GI sample i at a diffuse hit (RayTracer.cpp:334-347): a vector in the XY half-plane turned around Y, taken
+// from the hit's local frame {right = normalize(d x n), up = n, forward = right x up} to world space.  (d: the incoming ray's
+// direction, n: the hit normal, u1 / u2: the sample's two uniform numbers.)
+__device__ __forceinline__ void gi_sample_direction(float dx, float dy, float dz, float nx, float ny, float nz, float u1, float u2,
+                                                    float &ox, float &oy, float &oz) {
+    float rx = dy * nz - dz * ny, ry = dz * nx - dx * nz, rz = dx * ny - dy * nx;  // Vector::operator*(Vector), Vector.cpp:61-65
+    normalize3(rx, ry, rz);
+    const float fx = ry * nz - rz * ny, fy = rz * nx - rx * nz, fz = rx * ny - ry * nx;
+    const float angle1 = PI_F * u1;
+    const float angle2 = 2 * PI_F * u2;
+    const float vx = crt_cosf(angle1), vy = crt_sinf(angle1), vz = 0.0f;
+    const float c2 = crt_cosf(angle2), s2 = crt_sinf(angle2);
+    // randomVectorInXY * rotateAroundY, rows {c2, 0, -s2} {0, 1, 0} {s2, 0, c2} (Matrix.h:137-142)
+    const float qx = vx * c2 + vy * 0.0f + vz * s2;
+    const float qy = vx * 0.0f + vy * 1.0f + vz * 0.0f;
+    const float qz = vx * -s2 + vy * 0.0f + vz * c2;
+    // ... * localHitMatrix, rows right / up / forward
+    ox = qx * rx + qy * nx + qz * fx;
+    oy = qx * ry + qy * ny + qz * fy;
+    oz = qx * rz + qy * nz + qz * fz;
+}
 
 struct LaneWalk {
     // traversal cursors: top-level node / position in a top-level leaf / mesh-tree node / position in a mesh leaf
@@ -91,7 +139,7 @@ __device__ __forceinline__ bool traversal_step(LaneWalk &L, const Ray &R, const 
         L.tleaf = (ent & LAST) ? NONE : L.tleaf + 1;
         if (COUNT) cnt[C_LEAFIDX]++;
         const crt_mesh m = A.meshes[mi];
-        if (L.rtype == RAY_SHADOW && (m.flags & 1u)) return true;
+        if (L.rtype == RAY_SHADOW && (m.flags & 1u) && !A.use_gi) return true;  // AccelerationStructure.cpp:67-71
         L.cur_mesh = mi;
         L.mnode = m.root;
         L.mhave = false;
@@ -115,13 +163,21 @@ __device__ __forceinline__ bool traversal_step(LaneWalk &L, const Ray &R, const 
     return false;
 }
 
-template <bool COUNT>
+// GI: the reference's GI / multi-sample mode (RayTracer.cpp:90-104, 331-354) with the counter-based generator of gi_random.h
+template <bool COUNT, bool GI = false>
 __global__ __launch_bounds__(BLOCK) void render_lanes(const KernelArgs A) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     float *frames = A.frames + (size_t)wave * A.frame_wave_stride + lane;
-    auto FR = [&](uint32_t level, int field) -> float & { return frames[((size_t)level * FRAME_DWORDS + field) * 64]; };
-    auto FRK = [&](uint32_t level) -> int & { return *reinterpret_cast<int *>(&frames[(size_t)level * FRAME_DWORDS * 64]); };
+    constexpr int FDW = GI ? FRAME_DWORDS_GI : FRAME_DWORDS;
+    auto FR = [&](uint32_t level, int field) -> float & { return frames[((size_t)level * FDW + field) * 64]; };
+    auto FRK = [&](uint32_t level) -> int & { return *reinterpret_cast<int *>(&frames[(size_t)level * FDW * 64]); };
+    auto FRU = [&](uint32_t level, int field) -> uint32_t & { return *reinterpret_cast<uint32_t *>(&frames[((size_t)level * FDW + field) * 64]); };
+    // GI state: the current invocation's key; the pixel being sampled
+    uint32_t key = 0, pixel_key = 0, sample = 0, cur_px = 0, cur_py = 0;
+    float sumx = 0, sumy = 0, sumz = 0;          // std::accumulate over the pixel's samples (RayTracer.cpp:102-104)
+    float inx = 0, iny = 0, inz = 0;             // the ray direction that reached the diffuse hit being lit
+    const uint32_t n_samples = A.rays_per_pixel ? A.rays_per_pixel : 1u;  // colorVector always holds the centre sample
 
     uint32_t cnt[C_N];
     if (COUNT) for (int k = 0; k < C_N; k++) cnt[k] = 0;
@@ -162,6 +218,13 @@ __global__ __launch_bounds__(BLOCK) void render_lanes(const KernelArgs A) {
                 if (!((wi.mask >> sub) & 1ull) || px >= A.width || py >= A.height) continue;  // not covered: take another
                 out_off = A.packed ? ((size_t)wi.out_tile * 64 + sub) * 3 : ((size_t)py * A.width + px) * 3;
                 primary_ray(A, px, py, R);  // depth 0 <= MAX_DEPTH always (RayTracer.cpp:427)
+                if (GI) {
+                    cur_px = px; cur_py = py;
+                    pixel_key = crt_gi_mix(A.gi_seed, py * A.width + px);
+                    sample = 0;
+                    key = crt_gi_mix(pixel_key, 0u);
+                    sumx = sumy = sumz = 0;
+                }
                 L.rtype = RAY_PRIMARY;
                 sp = 0;
                 if (COUNT) cnt[C_PRIMARY]++;
@@ -202,6 +265,7 @@ __global__ __launch_bounds__(BLOCK) void render_lanes(const KernelArgs A) {
                 if (COUNT) cnt[C_HIT]++;
                 if (S.M.type == CRT_MAT_DIFFUSE) {
                     hpx = S.px; hpy = S.py; hpz = S.pz; hnx = S.nx; hny = S.ny; hnz = S.nz;
+                    if (GI) { inx = R.dx; iny = R.dy; inz = R.dz; }
                     base_is_bitmap = false;
                     if (S.M.texture >= 0) {
                         texture_color<COUNT>(A, A.textures[S.M.texture], L.btri, S.u, S.v, 1.0f - S.u - S.v, basex, basey,
@@ -214,6 +278,7 @@ __global__ __launch_bounds__(BLOCK) void render_lanes(const KernelArgs A) {
                     // RayTracer::calculateReflection (RayTracer.cpp:358-374)
                     FRK(sp) = FR_REFLECT;
                     FR(sp, 1) = S.M.ax; FR(sp, 2) = S.M.ay; FR(sp, 3) = S.M.az;
+                    if (GI) { FRU(sp, 8) = key; key = crt_gi_child_key(key, 0u); }
                     const float k = 2 * dot3(R.dx, R.dy, R.dz, S.nx, S.ny, S.nz);  // Vector::reflect, Vector.cpp:119-122
                     const float rx = R.dx - k * S.nx, ry = R.dy - k * S.ny, rz = R.dz - k * S.nz;
                     R.ox = S.px + S.nx * A.reflection_bias; R.oy = S.py + S.ny * A.reflection_bias; R.oz = S.pz + S.nz * A.reflection_bias;
@@ -259,6 +324,7 @@ __global__ __launch_bounds__(BLOCK) void render_lanes(const KernelArgs A) {
                     R.dx = rx; R.dy = ry; R.dz = rz;
                     normalize3(R.dx, R.dy, R.dz);
                     L.rtype = RAY_REFLECTION;
+                    if (GI) { FRU(sp, 8) = key; key = crt_gi_child_key(key, 0u); }
                     sp++;
                     new_ray = true;
                 } else {
@@ -273,6 +339,28 @@ __global__ __launch_bounds__(BLOCK) void render_lanes(const KernelArgs A) {
                     light_setup(A, li, hpx, hpy, hpz, hnx, hny, hnz, R, L.light_dist, kfac);
                     L.rtype = RAY_SHADOW;
                     traversal_begin(L, A.top_root);
+                } else if (GI && A.use_gi) {
+                    // RayTracer.cpp:331-354: GI_SAMPLE_SIZE diffuse reflection rays, one after the other, each a shootRay(depth + 1)
+                    if (A.gi_samples == 0) {
+                        const float inv = 1.0f / (float)(A.gi_samples + 1u);
+                        cx = (accx + 0.0f) * inv; cy = (accy + 0.0f) * inv; cz = (accz + 0.0f) * inv;
+                        returning = true;
+                    } else {
+                        FRK(sp) = FR_DIFFUSE_GI;
+                        FR(sp, 1) = accx; FR(sp, 2) = accy; FR(sp, 3) = accz;
+                        FR(sp, 4) = 0.0f; FR(sp, 5) = 0.0f; FR(sp, 6) = 0.0f;
+                        FRU(sp, 7) = 0u;
+                        FRU(sp, 8) = key;
+                        FR(sp, 9) = hpx; FR(sp, 10) = hpy; FR(sp, 11) = hpz;
+                        FR(sp, 12) = hnx; FR(sp, 13) = hny; FR(sp, 14) = hnz;
+                        FR(sp, 15) = inx; FR(sp, 16) = iny; FR(sp, 17) = inz;
+                        gi_sample_direction(inx, iny, inz, hnx, hny, hnz, crt_gi_uniform(key, 2u), crt_gi_uniform(key, 3u), R.dx, R.dy, R.dz);
+                        R.ox = hpx + hnx * A.monte_carlo_bias; R.oy = hpy + hny * A.monte_carlo_bias; R.oz = hpz + hnz * A.monte_carlo_bias;
+                        L.rtype = RAY_REFLECTION;
+                        key = crt_gi_child_key(key, 2u);
+                        sp++;
+                        new_ray = true;
+                    }
                 } else {
                     cx = accx; cy = accy; cz = accz; returning = true;
                 }
@@ -291,13 +379,48 @@ __global__ __launch_bounds__(BLOCK) void render_lanes(const KernelArgs A) {
                     break;
                 }
                 if (sp == 0) {
+                    if (GI && A.use_gi) {  // RayTracer.cpp:90-104: the centre sample, then RAYS_PER_PIXEL - 1 jittered ones, then the mean
+                        sumx = sumx + cx; sumy = sumy + cy; sumz = sumz + cz;
+                        sample++;
+                        if (sample < n_samples) {
+                            key = crt_gi_mix(pixel_key, sample);
+                            primary_ray_offset(A, cur_px, cur_py, crt_gi_uniform(key, 0u), crt_gi_uniform(key, 1u), R);
+                            L.rtype = RAY_PRIMARY;
+                            if (COUNT) cnt[C_PRIMARY]++;
+                            traversal_begin(L, A.top_root);
+                            returning = false;
+                            break;
+                        }
+                        const float inv = 1.0f / (float)n_samples;
+                        cx = sumx * inv; cy = sumy * inv; cz = sumz * inv;
+                    }
                     A.out[out_off] = cx; A.out[out_off + 1] = cy; A.out[out_off + 2] = cz;  // RayTracer.cpp:106
                     state = ST_FETCH;
                     break;
                 }
                 const uint32_t f = sp - 1;
                 const int kind = FRK(f);
-                if (kind == FR_REFLECT) {
+                if (GI) key = FRU(f, 8);  // back in the caller's invocation
+                if (GI && kind == FR_DIFFUSE_GI) {
+                    const float ix = FR(f, 4) + cx, iy = FR(f, 5) + cy, iz = FR(f, 6) + cz;  // indirectLightContribution += shootRay(...)
+                    const uint32_t i = FRU(f, 7) + 1u;
+                    if (i < A.gi_samples) {
+                        FR(f, 4) = ix; FR(f, 5) = iy; FR(f, 6) = iz;
+                        FRU(f, 7) = i;
+                        const float px = FR(f, 9), py = FR(f, 10), pz = FR(f, 11), nx = FR(f, 12), ny = FR(f, 13), nz = FR(f, 14);
+                        gi_sample_direction(FR(f, 15), FR(f, 16), FR(f, 17), nx, ny, nz, crt_gi_uniform(key, 2u + 2u * i),
+                                            crt_gi_uniform(key, 3u + 2u * i), R.dx, R.dy, R.dz);
+                        R.ox = px + nx * A.monte_carlo_bias; R.oy = py + ny * A.monte_carlo_bias; R.oz = pz + nz * A.monte_carlo_bias;
+                        L.rtype = RAY_REFLECTION;
+                        key = crt_gi_child_key(key, 2u + i);
+                        returning = false;
+                        new_ray = true;   // enters shootRay at level sp (== f + 1)
+                    } else {
+                        const float inv = 1.0f / (float)(A.gi_samples + 1u);  // RayTracer.cpp:352-353
+                        cx = (FR(f, 1) + ix) * inv; cy = (FR(f, 2) + iy) * inv; cz = (FR(f, 3) + iz) * inv;
+                        sp = f;
+                    }
+                } else if (kind == FR_REFLECT) {
                     cx = 0.0f + FR(f, 1) * cx; cy = 0.0f + FR(f, 2) * cy; cz = 0.0f + FR(f, 3) * cz;  // RayTracer.cpp:368-372
                     sp = f;
                 } else if (kind == FR_REFRACT_NO_TRANSMISSION) {
@@ -306,6 +429,7 @@ __global__ __launch_bounds__(BLOCK) void render_lanes(const KernelArgs A) {
                     R.ox = FR(f, 1); R.oy = FR(f, 2); R.oz = FR(f, 3);
                     R.dx = FR(f, 4); R.dy = FR(f, 5); R.dz = FR(f, 6);
                     L.rtype = RAY_REFRACTION;
+                    if (GI) key = crt_gi_child_key(key, 1u);
                     FRK(f) = FR_REFRACT_WAIT_REFRACTION;
                     FR(f, 1) = cx; FR(f, 2) = cy; FR(f, 3) = cz;  // reflectionColor
                     returning = false;

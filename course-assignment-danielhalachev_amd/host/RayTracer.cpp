@@ -160,6 +160,10 @@ int RayTracer::renderAsync(const RenderOptions &ro) {
   o.reflection_bias = ro.REFLECTION_BIAS;
   o.refraction_bias = ro.REFRACTION_BIAS;
   o.use_gi = ro.USE_GI ? 1u : 0u;
+  o.gi_sample_size = ro.GI_SAMPLE_SIZE;
+  o.rays_per_pixel = ro.RAYS_PER_PIXEL;
+  o.monte_carlo_bias = ro.MONTE_CARLO_BIAS;
+  o.gi_seed = ro.USE_GI ? giSeed++ : 0u;  // every GI frame its own seed, as every GI render of the reference differs
   const Matrix3 &m = camera.getRotationMatrix();
   const float pos[3] = {camera.getPosition().x, camera.getPosition().y, camera.getPosition().z};
   int rc = crt_set_camera(f.ctx, pos, &m.m[0][0]);
@@ -196,6 +200,10 @@ int RayTracer::renderFlat(const std::string &pathToImage, const RenderOptions &r
   o.reflection_bias = ro.REFLECTION_BIAS;
   o.refraction_bias = ro.REFRACTION_BIAS;
   o.use_gi = ro.USE_GI ? 1u : 0u;
+  o.gi_sample_size = ro.GI_SAMPLE_SIZE;
+  o.rays_per_pixel = ro.RAYS_PER_PIXEL;
+  o.monte_carlo_bias = ro.MONTE_CARLO_BIAS;
+  o.gi_seed = ro.USE_GI ? giSeed++ : 0u;  // every GI frame its own seed, as every GI render of the reference differs
   o.collect_counters = counters;  // 0, 1 (counting build) or 2 (production kernels with tallies), see crt_hip.h
   const Matrix3 &m = camera.getRotationMatrix();
   const float pos[3] = {camera.getPosition().x, camera.getPosition().y, camera.getPosition().z};

@@ -85,6 +85,9 @@ class RayTracer {
   // the next one and returns its slot at once; finishFrame(slot) waits for that frame and returns its quantised pixels
   // (H*W*3 bytes, PPMColor rule, valid until the slot is used again).  The GPU then works on frame k+1's primary rays while
   // frame k's deepest recursion levels and its copy to the host drain.  render() is unaffected.
+  // USE_GI frames (RayTracer.cpp:90-104, 331-354): the reference seeds its generator from clock() ^ thread id, so no two of its
+  // renders agree; here frame k of a tracer uses seed k (csrc/gi_random.h) unless setGISeed() says otherwise
+  void setGISeed(unsigned int seed) { giSeed = seed; }
   void setFramesInFlight(unsigned int k);
   unsigned int framesInFlight() const { return (unsigned int)ring.size(); }
   int renderAsync(const RenderOptions &renderOptions);
@@ -108,6 +111,7 @@ class RayTracer {
   struct InFlight { crt_ctx *ctx = nullptr; uint8_t *rgb8 = nullptr; bool busy = false; };
   std::vector<InFlight> ring;  // ring[0].ctx == ctx
   unsigned int ringNext = 0;
+  unsigned int giSeed = 0;
   int deviceIndex = 0;
   crt_tuning tuningCopy{};
   bool haveTuning = false;

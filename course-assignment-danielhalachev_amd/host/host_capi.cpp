@@ -224,8 +224,9 @@ extern "C" int crt_host_tracer_render(crt_host_tracer *t, const char *ppm_path, 
                                       float *out_rgb) {
   if (!t || !o || optimization < 0 || optimization > CRT_OPT_BVH_BUCKETS_QUEUE) return CRT_ERR_INVALID;
   return guarded([&]() {
-    crt::RenderOptions ro((crt::RenderOptimization)optimization, o->max_depth, o->use_gi != 0, 2, 1, o->shadow_bias,
-                          o->reflection_bias, o->refraction_bias);
+    crt::RenderOptions ro((crt::RenderOptimization)optimization, o->max_depth, o->use_gi != 0, o->gi_sample_size, o->rays_per_pixel,
+                          o->shadow_bias, o->reflection_bias, o->refraction_bias, o->monte_carlo_bias);
+    if (o->use_gi) t->tracer->setGISeed(o->gi_seed);
     int rc = t->tracer->renderFlat(ppm_path ? ppm_path : "", ro, out_rgb, o->collect_counters);
     if (rc) g_error = t->tracer->multiContext() ? crt_multi_last_error(t->tracer->multiContext()) : crt_last_error(t->tracer->context());
     return rc;

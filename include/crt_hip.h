@@ -121,17 +121,25 @@ typedef struct crt_scene_desc {
     const crt_light *lights;        uint32_t n_lights;
 } crt_scene_desc;
 
-/* RenderOptions (RayTracer.h:25-50).  USE_GI / GI_SAMPLE_SIZE / RAYS_PER_PIXEL are not part of
- * this path (the reference seeds its GI RNG from clock() ^ thread id, RayTracer.cpp:28-30, so no
- * parity is definable); use_gi != 0 is rejected with CRT_ERR_INVALID. */
+/* RenderOptions (RayTracer.h:25-50).  use_gi selects the reference's GI / multi-sample mode (RayTracer.cpp:90-104, 331-354):
+ * RAYS_PER_PIXEL primary rays per pixel (the first through the pixel centre, the others jittered) averaged, GI_SAMPLE_SIZE
+ * diffuse reflection rays at every diffuse hit, and refractive meshes no longer skipped by shadow rays
+ * (AccelerationStructure.cpp:67-71).  The reference seeds that mode's generator from clock() ^ thread id (RayTracer.cpp:28-30):
+ * only the distribution of its images is defined.  Here the random numbers come from a counter-based generator keyed by
+ * (gi_seed, pixel, sample, position in the ray tree) -- csrc/gi_random.h -- so a frame is a function of its options, whatever
+ * the device count or tile order; the GI mode is rendered pixel by pixel (csrc/kernel_lane.h), not by the ray-stream kernels. */
 typedef struct crt_options {
     uint32_t max_depth;      /* MAX_DEPTH, default 5 */
     float shadow_bias;       /* SHADOW_BIAS, default 1e-4 */
     float reflection_bias;   /* REFLECTION_BIAS */
     float refraction_bias;   /* REFRACTION_BIAS */
-    uint32_t use_gi;         /* must be 0 */
+    uint32_t use_gi;         /* USE_GI, default 0 */
     uint32_t collect_counters; /* 1: run the counting build (every ray walked the reference's way; fills crt_stats);
                                 * 2: run the production kernels and tally the tests they execute (crt_get_executed_counters) */
+    uint32_t gi_sample_size; /* GI_SAMPLE_SIZE, default 2 (used when use_gi) */
+    uint32_t rays_per_pixel; /* RAYS_PER_PIXEL, default 1 (used when use_gi; 0 renders like 1, as in the reference) */
+    float monte_carlo_bias;  /* MONTE_CARLO_BIAS, default 1e-4 */
+    uint32_t gi_seed;        /* the frame's seed of the GI generator */
 } crt_options;
 
 /* A pixel rectangle = the reference's unit of work, RayTracer::renderRectangle(row, col, w, h)
@@ -336,6 +344,10 @@ int crt_get_executed_plan_tests(crt_ctx *ctx, uint64_t out[2]);
 
 /* Test hook: out[i] = the device build of the restated glibc powf(x[i], 5) (the Fresnel term, RayTracer.cpp:407). */
 int crt_test_pow5(int device, const float *x, float *out, uint64_t n);
+/* Test hook for the GI mode's arithmetic (csrc/glibc_sincosf.h, csrc/gi_random.h), evaluated on `device`, or by the host
+ * build of the same headers when device < 0.  what = 0: out[i] = bits of sinf(a[i] as float); 1: cosf; 2: bits of the
+ * uniform number u(key a[i], draw b[i]); 3: mix(a[i], b[i]).  b may be NULL for 0 and 1. */
+int crt_test_gi(int device, uint32_t what, const uint32_t *a, const uint32_t *b, uint32_t *out, uint64_t n);
 
 /* Diagnostics for the development tools under tools/ (no counterpart in the reference; not needed to render):
  * the ray-stream pass's queue counters of the last frame (rays per recursion level, walks handed to the

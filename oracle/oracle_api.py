@@ -23,11 +23,16 @@ COUNTER_NAMES = ["box_tests", "tri_tests", "leaf_index_reads", "shaded_hits", "l
 
 class Options(C.Structure):
     _fields_ = [("max_depth", C.c_uint32), ("shadow_bias", C.c_float), ("reflection_bias", C.c_float),
-                ("refraction_bias", C.c_float)]
+                ("refraction_bias", C.c_float), ("use_gi", C.c_uint32), ("gi_sample_size", C.c_uint32),
+                ("rays_per_pixel", C.c_uint32), ("monte_carlo_bias", C.c_float), ("gi_seed", C.c_uint32)]
 
 
-def make_options(max_depth=5, shadow_bias=1e-4, reflection_bias=1e-4, refraction_bias=1e-4):
-    return Options(max_depth, shadow_bias, reflection_bias, refraction_bias)
+def make_options(max_depth=5, shadow_bias=1e-4, reflection_bias=1e-4, refraction_bias=1e-4, use_gi=0, gi_sample_size=2,
+                 rays_per_pixel=1, monte_carlo_bias=1e-4, gi_seed=0):
+    """RenderOptions (RayTracer.h:25-50); use_gi=1 selects the GI / multi-sample mode with the counter-based generator
+    cpu_ref.c defines (gi_seed = the frame's seed)."""
+    return Options(max_depth, shadow_bias, reflection_bias, refraction_bias, use_gi, gi_sample_size, rays_per_pixel,
+                   monte_carlo_bias, gi_seed)
 
 
 def build(force=False):
@@ -74,6 +79,16 @@ def lib():
         L.oracle_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
         L.oracle_powf.restype = C.c_float
         L.oracle_powf.argtypes = [C.c_float, C.c_float]
+        for name in ("oracle_sinf", "oracle_cosf"):
+            getattr(L, name).restype = C.c_float
+            getattr(L, name).argtypes = [C.c_float]
+        L.oracle_gi_uniform.restype = C.c_float
+        L.oracle_gi_uniform.argtypes = [C.c_uint32, C.c_uint32]
+        L.oracle_gi_mix.restype = C.c_uint32
+        L.oracle_gi_mix.argtypes = [C.c_uint32, C.c_uint32]
+        L.oracle_sincos_array.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.oracle_gi_array.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.oracle_sincos_vs_libm.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         _lib = L
     return _lib
 
@@ -195,15 +210,59 @@ def powf(x, y):
     return float(lib().oracle_powf(x, y))
 
 
+def sinf(x):
+    return float(lib().oracle_sinf(x))
+
+
+def cosf(x):
+    return float(lib().oracle_cosf(x))
+
+
+def sincos_array(y):
+    """(sinf, cosf) of a float32 array by the oracle's restatement of glibc's routines."""
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    s, c = np.empty_like(y), np.empty_like(y)
+    lib().oracle_sincos_array(_p(y), y.size, _p(s), _p(c))
+    return s, c
+
+
+def gi_array(a, b):
+    """(mix(a, b), u(a, b)) elementwise for uint32 arrays: the GI generator of cpu_ref.c."""
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    b = np.ascontiguousarray(b, dtype=np.uint32)
+    m, u = np.empty_like(a), np.empty(a.shape, dtype=np.float32)
+    lib().oracle_gi_array(_p(a), _p(b), a.size, _p(m), _p(u))
+    return m, u
+
+
+def sincos_vs_libm(first=0.0, last=6.2831860, stride=1):
+    """Compares the restated sinf / cosf with this machine's libm over every stride-th float of [first, last] (both >= 0):
+    returns (values tested, sinf mismatches, cosf mismatches)."""
+    lo = int(np.float32(first).view(np.uint32))
+    hi = int(np.float32(last).view(np.uint32))
+    out = np.zeros(3, dtype=np.uint64)
+    lib().oracle_sincos_vs_libm(lo, hi, stride, _p(out))
+    return int(out[0]), int(out[1]), int(out[2])
+
+
+def gi_uniform(key, d):
+    return float(lib().oracle_gi_uniform(key, d))
+
+
+def gi_mix(a, b):
+    return int(lib().oracle_gi_mix(a, b))
+
+
 # ----------------------------------------------------------------------------- the REAL reference
 def reference_available(textured=False) -> bool:
     return os.path.exists(REF_TEX if textured else REF_PLAIN)
 
 
 def reference_render(blob: bytes, max_depth=5, mode="bvhpool", textured=None, ppm_path=None, repeat=1,
-                     cpus=None):
+                     cpus=None, gi=None, all_frames=False):
     """Run the real reference (oracle/_ref/ref_render[_tex]) on a CRTS blob.
-    Returns (rgb float32 [H,W,3], info dict with render_s/build_s/threads)."""
+    Returns (rgb float32 [H,W,3], info dict with render_s/build_s/threads).  gi=(GI_SAMPLE_SIZE, RAYS_PER_PIXEL) selects
+    the reference's GI mode (every render differs); all_frames=True returns all `repeat` frames as [repeat,H,W,3]."""
     if textured is None:
         textured = blob[80:84] != b"\x00\x00\x00\x00"  # n_textures field (after the 80-byte header)
     exe = REF_TEX if textured else REF_PLAIN
@@ -217,9 +276,14 @@ def reference_render(blob: bytes, max_depth=5, mode="bvhpool", textured=None, pp
         cmd = [exe, sp, op, "--depth", str(max_depth), "--mode", mode, "--repeat", str(repeat)]
         if ppm_path:
             cmd += ["--ppm", ppm_path]
+        if gi:
+            cmd += ["--gi", str(int(gi[0])), str(int(gi[1]))]
+        if all_frames:
+            cmd += ["--all-frames"]
         if cpus:
             cmd = ["taskset", "-c", cpus] + cmd
         r = subprocess.run(cmd, capture_output=True, text=True, check=True)
         info = json.loads(r.stdout.strip().splitlines()[-1])
-        rgb = np.fromfile(op, dtype=np.float32).reshape(info["height"], info["width"], 3)
+        rgb = np.fromfile(op, dtype=np.float32)
+        rgb = rgb.reshape(-1, info["height"], info["width"], 3) if all_frames else rgb.reshape(info["height"], info["width"], 3)
     return rgb, info

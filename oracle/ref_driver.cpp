@@ -9,7 +9,7 @@
 // `Scene` from a CRTS blob (oracle/scene_blob.h) and calls the reference's own
 // `RayTracer::render` (RayTracer.cpp:204-298).  Nothing of the hot path is restated here.
 //
-// usage: ref_render <scene.crts> <out.f32> [--depth N] [--mode NAME] [--ppm out.ppm] [--repeat K]
+// usage: ref_render <scene.crts> <out.f32> [--depth N] [--mode NAME] [--ppm out.ppm] [--repeat K] [--gi SAMPLES RAYS_PER_PIXEL] [--all-frames]
 //   out.f32 = H*W*3 little-endian float32, row 0 = top  (the reference's colorBuffer)
 //   prints one JSON line: {"render_s": ..., "build_s": ..., "width": W, "height": H, ...}
 // usage: ref_render --camera-ops <ops.txt> <out.txt>
@@ -93,18 +93,22 @@ static int cameraOps(const char *opsPath, const char *outPath) {
 int main(int argc, char **argv) {
   if (argc == 4 && std::string(argv[1]) == "--camera-ops") return cameraOps(argv[2], argv[3]);
   if (argc < 3) {
-    std::fprintf(stderr, "usage: %s scene.crts out.f32 [--depth N] [--mode NAME] [--ppm P] [--repeat K]\n", argv[0]);
+    std::fprintf(stderr, "usage: %s scene.crts out.f32 [--depth N] [--mode NAME] [--ppm P] [--repeat K] [--gi SAMPLES RAYS_PER_PIXEL] [--all-frames]\n", argv[0]);
     return 2;
   }
   std::string blobPath = argv[1], outPath = argv[2], ppmPath, mode = "bvhpool";
   unsigned depth = 5;
   int repeat = 1;
+  bool useGI = false, allFrames = false;
+  unsigned giSamples = 2, raysPerPixel = 1;
   for (int i = 3; i < argc; i++) {
     std::string a = argv[i];
     if (a == "--depth" && i + 1 < argc) depth = std::atoi(argv[++i]);
     else if (a == "--mode" && i + 1 < argc) mode = argv[++i];
     else if (a == "--ppm" && i + 1 < argc) ppmPath = argv[++i];
     else if (a == "--repeat" && i + 1 < argc) repeat = std::atoi(argv[++i]);
+    else if (a == "--gi" && i + 2 < argc) { useGI = true; giSamples = (unsigned)std::atoi(argv[++i]); raysPerPixel = (unsigned)std::atoi(argv[++i]); }
+    else if (a == "--all-frames") allFrames = true;
   }
 
   std::ifstream in(blobPath, std::ios::binary);
@@ -229,9 +233,13 @@ int main(int argc, char **argv) {
   auto t0 = std::chrono::high_resolution_clock::now();
   RayTracer tracer(scene);
   auto t1 = std::chrono::high_resolution_clock::now();
-  RenderOptions options(parseMode(mode), depth, false);
+  // --gi N R: the GI / multi-sample mode (RayTracer.h:27-30) -- every render then differs (the reference seeds its generator
+  // from clock() ^ thread id), so --all-frames writes each of the --repeat frames, for statistics over them
+  RenderOptions options(parseMode(mode), depth, useGI, giSamples, raysPerPixel);
   std::vector<std::vector<Color>> buffer;
   double best = 1e30, total = 0;
+  std::ofstream out(outPath, std::ios::binary);
+  std::vector<float> flat((size_t)W * H * 3);
   for (int r = 0; r < repeat; r++) {
     auto a = std::chrono::high_resolution_clock::now();
     buffer = tracer.render(r == repeat - 1 ? ppmPath : std::string(), options);
@@ -239,14 +247,13 @@ int main(int argc, char **argv) {
     double s = std::chrono::duration<double>(b - a).count();
     total += s;
     if (s < best) best = s;
+    if (allFrames || r == repeat - 1) {
+      for (unsigned y = 0; y < H; y++)
+        for (unsigned x = 0; x < W; x++)
+          for (unsigned k = 0; k < 3; k++) flat[((size_t)y * W + x) * 3 + k] = buffer[y][x][k];
+      out.write((const char *)flat.data(), (std::streamsize)flat.size() * 4);
+    }
   }
-
-  std::vector<float> flat((size_t)W * H * 3);
-  for (unsigned y = 0; y < H; y++)
-    for (unsigned x = 0; x < W; x++)
-      for (unsigned k = 0; k < 3; k++) flat[((size_t)y * W + x) * 3 + k] = buffer[y][x][k];
-  std::ofstream out(outPath, std::ios::binary);
-  out.write((const char *)flat.data(), (std::streamsize)flat.size() * 4);
   for (auto &r : texRecs)
     if (!r.file.empty()) std::remove(r.file.c_str());
 

@@ -103,5 +103,31 @@ def camera_ops():
     print("camera_ops", after.shape)
 
 
+# The GI / multi-sample mode (RayTracer.cpp:90-104, 331-354).  The reference seeds its generator from clock() ^ thread id,
+# so no frame of it can be pinned -- its DISTRIBUTION can: per case the mean and the variance of every pixel over `frames`
+# renders of the real reference.  tests/test_gi.py holds the oracle's counter-based generator to these moments.
+GI_CASES = [("hw11", 48, 32, 0.15, 2, 2, 2, 400), ("hw08", 40, 30, 0.3, 3, 1, 3, 300)]  # scene, W, H, detail, depth, GI_SAMPLE_SIZE, RAYS_PER_PIXEL, frames
+
+
+def gi_stats():
+    oa.build()
+    out = {}
+    for name, w, h, detail, depth, n, r, frames in GI_CASES:
+        scene = sc.make(name, width=w, height=h, detail=detail)
+        blob = sc.to_blob(scene)
+        rgb, _ = oa.reference_render(blob, max_depth=depth, gi=(n, r), repeat=frames, all_frames=True)
+        rgb = rgb.astype(np.float64)
+        out[name + "_blob"] = np.frombuffer(blob, dtype=np.uint8)
+        out[name + "_params"] = np.array([depth, n, r, frames], dtype=np.int32)
+        out[name + "_mean"] = rgb.mean(axis=0).astype(np.float32)
+        out[name + "_var"] = rgb.var(axis=0, ddof=1).astype(np.float32)
+        print("gi", name, rgb.shape, "mean", float(rgb.mean()))
+    np.savez_compressed(os.path.join(HERE, "gi_stats.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "gi":
+        gi_stats()
+    else:
+        main()
+        gi_stats()

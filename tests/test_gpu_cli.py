@@ -97,3 +97,20 @@ def test_crt_main_on_several_devices(scenes, oracle, tmp_path):
     ref = str(tmp_path / "ref.ppm")
     oracle.write_ppm(ref, want)
     assert open(out, "rb").read() == open(ref, "rb").read()
+
+
+def test_crt_main_gi_mode(scenes, oracle, tmp_path):
+    # --gi N R --seed S: RenderOptions::USE_GI through the host mirror; the PPM of the oracle's frame for the same seed
+    if not os.path.exists(EXE):
+        pytest.skip("crt_main not built")
+    scene = scenes.make("hw11", width=64, height=40, detail=0.2)
+    (tmp_path / "scene.crtscene").write_text(scenes.to_json(scene))
+    out = str(tmp_path / "out.ppm")
+    r = subprocess.run([EXE, "scene.crtscene", out, "--depth", "2", "--gi", "2", "3", "--seed", "41"], capture_output=True, text=True,
+                       timeout=120, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    want, _ = oracle.OracleScene(scenes.to_blob(scene)).render(
+        options=oracle.make_options(2, use_gi=1, gi_sample_size=2, rays_per_pixel=3, gi_seed=41))
+    ref = str(tmp_path / "ref.ppm")
+    oracle.write_ppm(ref, want)
+    assert open(out, "rb").read() == open(ref, "rb").read()

@@ -1,0 +1,23 @@
+"""Dev helper (GPU box): one GI frame (crt_options::use_gi) of a BASELINE scene, timed, with the counting build's ray counts.
+usage: python tools/gi_time.py hw14 960 540 3 2 2   (scene width height depth GI_SAMPLE_SIZE RAYS_PER_PIXEL)"""
+import importlib, sys, time
+sys.path.insert(0, '.')
+import numpy as np
+pkg = importlib.import_module('course-assignment-danielhalachev_amd'); sc = pkg.scenes
+name = sys.argv[1] if len(sys.argv) > 1 else 'hw14'
+w, h, depth, n, r = (int(v) for v in (sys.argv[2:7] + ['960', '540', '3', '2', '2'][len(sys.argv) - 2:]))
+scene = sc.make(name, width=w, height=h)
+import tempfile
+folder = tempfile.mkdtemp() + '/'
+if scene.get('textures'): sc.write_bitmaps(scene, folder)
+tr = pkg.Tracer(pkg.Scene(json_text=sc.to_json(scene), folder=folder))
+opts = dict(use_gi=True, gi_sample_size=n, rays_per_pixel=r)
+tr.render(options=pkg.make_options(depth, gi_seed=0, **opts))
+t0 = time.perf_counter(); k = 3
+for i in range(k): got = tr.render(options=pkg.make_options(depth, gi_seed=1 + i, **opts))
+ms = (time.perf_counter() - t0) / k * 1e3
+tr.render(options=pkg.make_options(depth, counters=True, gi_seed=1, **opts))
+c = tr.stats().counters()
+rays = c['primary_rays'] + c['secondary_rays'] + c['shadow_rays']
+print('%s %dx%d depth %d GI_SAMPLE_SIZE %d RAYS_PER_PIXEL %d: %.1f ms per frame, %.1f M rays per frame (%.0f M rays/s), mean colour %.4f'
+      % (name, w, h, depth, n, r, ms, rays / 1e6, rays / ms / 1e3, float(got.mean())), flush=True)
