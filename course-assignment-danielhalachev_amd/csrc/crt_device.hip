@@ -445,6 +445,7 @@ extern "C" void crt_tuning_defaults(crt_tuning *t) {
     t->early_shadow = 0;
     t->deep_first = 1;
     t->level_grid = 1;
+    t->skip_unlit = 1;
     t->wave_priority = 3;
     t->side_priority = 1;
 }
@@ -1251,6 +1252,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         A.bundle = (A.plan_ok && ctx->bundle < 64u) ? ctx->bundle : 64u;
         A.fixed0 = 0;
         A.early_shadow = 0;
+        A.skip_unlit = ctx->tuning.skip_unlit ? 1u : 0u;
         A.wave_prio = ctx->tuning.wave_priority > 3u ? 3u : ctx->tuning.wave_priority;
         if (ctx->fixed0) {  // level 0 owns the first n_items * 64 * n_lights slots of the shadow queue; the deeper levels append
             const uint64_t n0 = (uint64_t)n_items * 64u * ctx->n_lights;

@@ -71,6 +71,11 @@ __device__ __forceinline__ void shadow_plan_walks(const KernelArgs &A, const uin
                 r += first;
                 const float4 q0 = A.s_shadowq[2 * (size_t)r], q1 = A.s_shadowq[2 * (size_t)r + 1];
                 if (__float_as_uint(q0.w) == SHADOW_SLOT_UNUSED) continue;  // a level-0 pixel without a diffuse hit
+                // The light is behind the surface (angle = max(0, l . n) = 0, RayTracer.cpp:312): its contribution is
+                // intensity / area * 0 = +-0 times the albedo, and adding +-0 to the light sum -- which starts at +0 and can
+                // therefore never be -0 -- changes no bit of it (RayTracer.cpp:319-328).  Occluded or not, the pixel is the same:
+                // no walk.  (A NaN factor -- the light AT the surface -- is not zero and is walked.)
+                if (A.skip_unlit && q1.w == 0.0f) { A.s_occluded[r] = 0; continue; }
                 R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
                 R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;  // already normalised once; shadow rays skip shootRay (RayTracer.cpp:313-317)
                 ray_prepare(R);

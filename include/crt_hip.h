@@ -222,6 +222,8 @@ typedef struct crt_tuning {
                                * level) */
     uint32_t level_grid;      /* 1: the per-lane launch of a deeper level is sized by the rays that level held in the previous frame (0: always
                                * the full grid) */
+    uint32_t skip_unlit;      /* 1: a shadow ray towards a light behind its surface (light factor exactly 0: the pixel is the same occluded or
+                               * not) is not walked by the planned shadow kernels */
     uint32_t wave_priority;   /* 3 (0..3): s_setprio of the recursion levels' waves (the frame's critical path) over the bulk shadow pass's, which
                                * shares the SIMDs with them */
     uint32_t side_priority;   /* 1 (0 = default priority): the side stream (bulk shadow pass) is created with the lowest stream priority */

@@ -86,6 +86,7 @@ KERNEL_PATHS = [
     dict(pool=3), dict(pool=1, pool_refill=1, pool_switch=64),   # shadow walks with three rays per lane (kernel_pool.h)
     dict(pool=3, pool_refill=64, pool_switch=1, level_shadows=1),
     dict(early_shadow=1), dict(early_shadow=1, level0_budget=16, shadow_cap=1 << 20),  # bulk shadow pass after / before the evicted primary walks
+    dict(skip_unlit=0),                                          # shadow rays towards lights behind their surface walked like the others
     dict(level_shadows=2),                                       # levels 1-2's shadow rays on a third stream beside the bulk pass, the rest at the end
     dict(level_shadows=4, wave_priority=2, level_grid=0),        # ... levels 1-4's
     dict(level_shadows=1),                                       # the deeper levels' shadow rays in one pass at the end

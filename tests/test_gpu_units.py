@@ -45,6 +45,8 @@ def test_abi_rejects_inconsistent_arguments(pkg, scenes):
     with pytest.raises(pkg.CrtError):
         tracer.unpack_tiles_device(packed.data_ptr(), 0, 48 * 192, frame.data_ptr())
     with pytest.raises(pkg.CrtError):
-        tracer.render(options=pkg.Options(3, 1e-4, 1e-4, 1e-4, 1, 0))      # use_gi = 1: GI is outside this path
+        tracer.render(options=pkg.make_options(3, use_gi=True, gi_sample_size=65))   # more GI samples per hit than the ABI takes
+    with pytest.raises(pkg.CrtError):
+        tracer.render(options=pkg.make_options(3, use_gi=True, counters=2))          # the executed-test tallies belong to the ray-stream kernels
     tracer.unpack_tiles_device(packed.data_ptr(), 1, 48 * 192, frame.data_ptr())   # the consistent call goes through
     torch.cuda.synchronize()
