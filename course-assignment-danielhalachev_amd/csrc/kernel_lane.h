@@ -8,6 +8,7 @@
 #pragma once
 
 #include "kernel_common.h"
+#include "kernel_walk.h"
 #include "gi_random.h"
 #include "glibc_sincosf.h"
 
@@ -65,6 +66,7 @@ struct LaneWalk {
     float mmin, mt, tmin, bt, light_dist;
     uint32_t mtri, btri, bmesh;
     int rtype;
+    SeenMeshes seen;   // meshes already walked for this ray (kernel_common.h: mesh_walk_is_repeat; production build only)
 };
 
 __device__ __forceinline__ void traversal_begin(LaneWalk &L, uint32_t top_root) {
@@ -78,6 +80,7 @@ __device__ __forceinline__ void traversal_begin(LaneWalk &L, uint32_t top_root) 
     L.occluded = false;
     L.tmin = INFINITY;
     L.mmin = INFINITY;
+    seen_clear(L.seen);
 }
 
 // One unit of traversal work for this lane: either one triangle test (when inside a leaf) or one
@@ -100,6 +103,13 @@ __device__ __forceinline__ bool traversal_step(LaneWalk &L, const Ray &R, const 
             // `closest = hits[0]; min = inf; for h: if (h.d < min) {min = h.d; closest = h}` fused into the walk
             if (!L.mhave) { L.mhave = true; L.mt = t; L.mtri = tri; }
             if (t < L.mmin) { L.mmin = t; L.mt = t; L.mtri = tri; }
+            // production build: a shadow walk ends at the first accepted hit within the light's distance -- exact, by the
+            // monotonicity argument at kernel_walk.h: shadow_hit_occludes (the counting build walks on, as the reference does)
+            if (!COUNT && L.rtype == RAY_SHADOW && t < INFINITY &&
+                shadow_hit_occludes(R, R.ox + R.dx * t, R.oy + R.dy * t, R.oz + R.dz * t, L.light_dist)) {
+                L.occluded = true;
+                L.mleaf = NONE; L.cur_mesh = NONE; L.mnode = END; L.tleaf = NONE; L.tnode = END;  // the next step reports the end
+            }
         }
         return true;
     }
@@ -140,6 +150,7 @@ __device__ __forceinline__ bool traversal_step(LaneWalk &L, const Ray &R, const 
         if (COUNT) cnt[C_LEAFIDX]++;
         const crt_mesh m = A.meshes[mi];
         if (L.rtype == RAY_SHADOW && (m.flags & 1u) && !A.use_gi) return true;  // AccelerationStructure.cpp:67-71
+        if (!COUNT && mesh_walk_is_repeat(L.seen, mi)) return true;  // production build: every mesh once per ray (kernel_common.h, exact)
         L.cur_mesh = mi;
         L.mnode = m.root;
         L.mhave = false;
