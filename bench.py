@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alone", action="store_true", help="skip roofline.alone (keeps a rocprofv3 --stats run of this command to the in-frame launches)")
     ap.add_argument("--tuning", default="", help="development: crt_tuning fields as 'name=value ...' (default: the library's defaults)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="development only: N processes share GPU 0 and gather through gloo on host buffers "
@@ -275,6 +276,8 @@ def main():
         # (crt_tuning::side_blocks = 0).  `frac` stays the in-frame figure; `alone` is reported beside it.
         alone = None
         try:
+            if args.no_alone:
+                raise RuntimeError("--no-alone")
             base = dict(kv.split("=") for kv in args.tuning.split()) if args.tuning else {}
             solo = pkg.Tracer(hs, device=local_rank, tuning=pkg.make_tuning(**dict({k: int(v, 0) for k, v in base.items()}, side_blocks=0)))
             for _ in range(8):
@@ -342,7 +345,7 @@ def main():
                                        "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
         if not frame_ok or gathered_ok is False or fallback:
-            # a line whose frame is wrong (or that silently took the 20x slower fallback) is not a measurement
+            # a line whose frame is wrong (or that silently took the 4x slower fallback) is not a measurement
             print("bench.py: FAILED self-check: frame_matches_counting_build=%r gathered_frame_matches_single_rank=%r "
                   "fallback_frames=%d" % (frame_ok, gathered_ok, fallback), file=sys.stderr, flush=True)
             failed = True

@@ -14,7 +14,7 @@ DOM = "stream_trace_shadow_plan<0"
 def run(args, name):
     d = os.path.join(out, name)
     cmd = ["rocprofv3"] + args + ["-d", d, "--output-format", "csv", "--", "python3", os.path.join(root, "bench.py"),
-                                  "--steps", "10", "--warmup", "2", "--no-cpu-baseline"]
+                                  "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-alone"]
     with open(os.path.join(out, name + ".log"), "w") as log:
         rc = subprocess.run(cmd, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT, timeout=400).returncode
     print(name, "rc", rc, flush=True)
@@ -26,6 +26,7 @@ def find(d, suffix):
     return hits[0] if hits else None
 
 
+stats_only = "--stats-only" in sys.argv
 d = run(["--kernel-trace", "--stats"], "stats")
 stats = find(d, "kernel_stats.csv")
 if stats:
@@ -36,7 +37,7 @@ for line in open(os.path.join(out, "stats.log")):
         bench_line = json.loads(line)
 
 pmc = {}
-for counters in (["FETCH_SIZE"], ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"], ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum"],
+for counters in () if stats_only else (["FETCH_SIZE"], ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"], ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum"],
                  ["SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD", "SQ_WAVES", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU"],
                  ["SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES"]):
     name = "pmc_" + "_".join(c.replace("_sum", "") for c in counters)
@@ -57,7 +58,10 @@ for counters in (["FETCH_SIZE"], ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"]
         pmc.setdefault(k, {})[c] = {"per_launch": v / max(len(ids), 1), "launches": len(ids)}
 
 summary = {"bench": bench_line, "pmc_per_launch": pmc}
-json.dump(summary, open(os.path.join(out, tag + "_summary.json"), "w"), indent=1)
+if stats_only:
+    json.dump(bench_line, open(os.path.join(out, tag + "_stats_bench_line.json"), "w"), indent=1)
+else:
+    json.dump(summary, open(os.path.join(out, tag + "_summary.json"), "w"), indent=1)
 dom = [k for k in pmc if k.startswith(DOM)]
 if dom and "FETCH_SIZE" in pmc[dom[0]] and "WRITE_SIZE" in pmc[dom[0]]:
     f_kb, w_kb = pmc[dom[0]]["FETCH_SIZE"]["per_launch"], pmc[dom[0]]["WRITE_SIZE"]["per_launch"]
