@@ -392,6 +392,11 @@ class Tracer:
                                                  C.byref(o), _p(rgb)))
         return rgb
 
+    def synchronize(self):
+        """crt_synchronize on the first context: waits for everything enqueued on its device; afterwards stats() reflects the
+        last frame (fallback_frames included)."""
+        self._check(lib().crt_synchronize(self.ctx))
+
     def stats(self) -> Stats:
         s = Stats()
         lib().crt_host_tracer_stats(self._h, C.byref(s))
