@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=None,
+                    help="frames in flight of the extra `pipelined` measurement (default: 3 on one GPU, 0 = skipped on several, where only "
+                         "the gloo rehearsal of the gather has run so far); `value` is always one frame at a time")
     ap.add_argument("--no-alone", action="store_true", help="skip roofline.alone (keeps a rocprofv3 --stats run of this command to the in-frame launches)")
     ap.add_argument("--tuning", default="", help="development: crt_tuning fields as 'name=value ...' (default: the library's defaults)")
     ap.add_argument("--rehearse-gloo", action="store_true",
@@ -222,6 +225,57 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         d2h_elapsed = float(t.item())
 
+    # The same K steps once more with several frames in flight (reported beside `value`, never as it): frame k on context k % F
+    # and stream k % F, each context with the scene resident and queues of its own, so that one frame's latency-bound head and
+    # tail (level 0's longest walks; the deeper levels' shadow rays, resolve) overlap its neighbours' busy middle -- what the
+    # animation driver does (crt_animation --in-flight).  Every frame is complete inside the timed region and is compared with
+    # the one-at-a-time frame afterwards.
+    pipelined = None
+    F = 0 if args.rehearse_gloo else max(0, args.in_flight if args.in_flight is not None else (3 if world == 1 else 0))
+    if F >= 2:
+        trs = [tracer] + [pkg.Tracer(hs, device=local_rank, tuning=pkg.tuning_from_string(args.tuning)) for _ in range(F - 1)]
+        strs = [torch.cuda.Stream(dev) for _ in range(F)]
+        packs = [packed] + [torch.zeros_like(packed) for _ in range(F - 1)]
+        gaths = [gathered] + [(torch.zeros_like(gathered) if world > 1 else packs[i + 1]) for i in range(F - 1)]
+        frames_f = [frame] + [torch.zeros_like(frame) for _ in range(F - 1)] if rank == 0 else [frame] * F
+        reference_frame = frame.clone() if rank == 0 else None
+
+        def pstep(k):
+            i = k % F
+            with torch.cuda.stream(strs[i]):
+                trs[i].render_tiles_device(opts, rank, world, packs[i].data_ptr(), strs[i].cuda_stream)
+                if world > 1:
+                    dist.all_gather_into_tensor(gaths[i], packs[i])
+                if rank == 0:
+                    trs[i].unpack_tiles_device(gaths[i].data_ptr(), world, part_floats, frames_f[i].data_ptr(), strs[i].cuda_stream)
+
+        for k in range(max(args.warmup, 2 * F)):
+            pstep(k)
+        fence()
+        for t_ in trs:
+            t_.synchronize()
+        fb0 = sum(int(t_.stats().fallback_frames) for t_ in trs)
+        tp = time.perf_counter()
+        for k in range(args.steps):
+            pstep(k)
+        fence()
+        p_elapsed = time.perf_counter() - tp
+        if world > 1:
+            t = torch.tensor([p_elapsed], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            p_elapsed = float(t.item())
+        for t_ in trs:
+            t_.synchronize()
+        p_fallback = sum(int(t_.stats().fallback_frames) for t_ in trs) - fb0
+        p_ok = None
+        if rank == 0:
+            p_ok = all(bool(torch.equal(f.view(torch.int32), reference_frame.view(torch.int32))) for f in frames_f)
+        pipelined = {"frames_in_flight": F, "value": round(W * H * args.steps / p_elapsed / 1e6, 3), "unit": "Mpixels/s",
+                     "ms_per_step": round(p_elapsed / args.steps * 1e3, 4), "frames_match_one_at_a_time": p_ok,
+                     "fallback_frames": p_fallback,
+                     "note": "the same K steps with frame k on context / stream k % F; every frame complete inside the timed region"}
+        del trs[1:], packs[1:], gaths[1:]
+
     # every rank's production tiles matched its counting build's?  (and, for N > 1, does the gathered frame equal
     # a single-rank render of the whole frame on rank 0?)
     if world > 1:
@@ -310,6 +364,7 @@ def main():
                        "scene": args.scene, "width": W, "height": H, "max_depth": depth,
                        "parallelism": "tiles8x8-roundrobin-%d" % world, "tuning": args.tuning or "defaults"},
             "frame_matches_counting_build": frame_ok,
+            "pipelined": pipelined,
             "value_incl_d2h": round(W * H / d2h_elapsed / 1e6, 3),
             "kernel_ms": {"first_to_last": round(avg_kernel_ms, 4), "recursion_levels": round(pk_ms, 4),
                           "shadow_pass0_overlapped": round(ln_ms, 4), "shadow_pass1_heavy_resolve": round(rs_ms, 4)},
@@ -354,6 +409,9 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
+        if pipelined and pipelined["frames_match_one_at_a_time"] is False:
+            print("bench.py: FAILED self-check: a frame of the pipelined run differs from the one-at-a-time frame", file=sys.stderr, flush=True)
+            failed = True
         if not frame_ok or gathered_ok is False or fallback:
             # a line whose frame is wrong (or that silently took the 4x slower fallback) is not a measurement
             print("bench.py: FAILED self-check: frame_matches_counting_build=%r gathered_frame_matches_single_rank=%r "
