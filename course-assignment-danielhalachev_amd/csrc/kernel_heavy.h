@@ -31,6 +31,7 @@ struct HeavyState {   // all wave-uniform
     bool stop;        // shadow walks: an accepted hit within the light's distance ends the walk (kernel_walk.h: shadow_hit_occludes)
     float light_dist;
     uint32_t nbox, ntri;  // tests executed for this ray (KernelArgs::exec_count)
+    uint32_t n_chunks, n_batches, n_meshes;  // diagnostics (exec_count): 64-box chunk tests, 64-triangle batches, mesh trees entered
     __device__ __forceinline__ bool go() const { return guard != 0 && !stop; }
 };
 
@@ -67,7 +68,7 @@ __device__ __forceinline__ void heavy_batch(const KernelArgs &A, const Ray &R, c
                                             const size_t e, HeavyState &H) {
     const float4 a = A.ltris[4 * e + 0], b = A.ltris[4 * e + 1], c = A.ltris[4 * e + 2], d = A.ltris[4 * e + 3];
     float t = 0;
-    if (A.exec_count) H.ntri += (uint32_t)__popcll(__ballot(valid));
+    if (A.exec_count) { H.ntri += (uint32_t)__popcll(__ballot(valid)); H.n_batches++; }
     const bool acc = valid && triangle_test(R, primary, a, b, c, d.x, t);
     const unsigned long long am = __ballot(acc);
     if (!am) return;
@@ -138,7 +139,7 @@ __device__ __forceinline__ ChunkBoxes heavy_chunk_load(const KernelArgs &A, cons
 template <int LEVEL, bool SHADOW>
 __device__ __forceinline__ void heavy_chunk(const KernelArgs &A, const Ray &R, const bool primary, const HeavyMesh &M,
                                             const uint32_t chunk, const ChunkBoxes &C, HeavyState &H, const uint32_t lane) {
-    if (A.exec_count) H.nbox += (uint32_t)__popcll(__ballot(C.valid));
+    if (A.exec_count) { H.nbox += (uint32_t)__popcll(__ballot(C.valid)); H.n_chunks++; }
     bool hit = C.valid && slab_test(R, C.b0.x, C.b0.y, C.b0.z, C.b1.x, C.b1.y, C.b1.z);
     if (!SHADOW && (A.prune & 2u)) {
         const float bound = fminf(H.tmin_scene, H.mmin);  // wave-uniform
@@ -182,7 +183,7 @@ __device__ __forceinline__ void heavy_tiny_batch(const KernelArgs &A, const Ray 
                                                  const uint32_t tag, unsigned long long tags, TinyResults &T, HeavyState &H, const uint32_t lane) {
     const float4 a = A.ltris[4 * e + 0], b = A.ltris[4 * e + 1], c = A.ltris[4 * e + 2], d = A.ltris[4 * e + 3];
     float t = 0;
-    if (A.exec_count) H.ntri += (uint32_t)__popcll(__ballot(valid));
+    if (A.exec_count) { H.ntri += (uint32_t)__popcll(__ballot(valid)); H.n_batches++; }
     const bool acc = valid && triangle_test(R, primary, a, b, c, d.x, t);
     if (!__ballot(acc)) return;
     while (tags) {  // the meshes that have triangles in this batch, one masked reduction each (registers only)
@@ -307,7 +308,7 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const TopRegs &T
     H.guard = 1u << 18;
     H.stop = false;
     H.light_dist = light_dist;
-    H.nbox = 0; H.ntri = 0;
+    H.nbox = 0; H.ntri = 0; H.n_chunks = 0; H.n_batches = 0; H.n_meshes = 0;
     H.tmin_scene = INFINITY;
     if (!SHADOW) prune_prepare(H.prune, R, A.scene_scale);
     TinyResults T;
@@ -358,6 +359,7 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const TopRegs &T
                     H.mtri = lane_value(T.mtri, k);
                     H.mmin = lane_value(T.mmin, k);
                 } else {
+                    if (A.exec_count) H.n_meshes++;
                     heavy_mesh<SHADOW>(A, R, primary, mi, H, lane);
                 }
                 if (SHADOW && H.stop) { occluded = true; break; }
@@ -377,7 +379,12 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const TopRegs &T
         ti = miss;
     }
     if (!H.guard && lane == 0) { A.s_counts[SC_GUARD] = 1; A.s_counts[SC_OVERFLOW] = 1; }  // bound hit: let the fallback redo the frame
-    if (A.exec_count && lane == 0) { atomicAdd(&A.exec_counters[0], (unsigned long long)H.nbox); atomicAdd(&A.exec_counters[1], (unsigned long long)H.ntri); }
+    if (A.exec_count && lane == 0) {
+        atomicAdd(&A.exec_counters[0], (unsigned long long)H.nbox); atomicAdd(&A.exec_counters[1], (unsigned long long)H.ntri);
+        uint32_t *diag = A.s_counts + SC_HEAVY_DIAG + (SHADOW ? 8 : 0);  // tools/stream_stats.py: what a wave-per-ray walk consists of
+        atomicAdd(diag + 0, 1u); atomicAdd(diag + 1, H.n_chunks); atomicAdd(diag + 2, H.n_batches); atomicAdd(diag + 3, H.n_meshes);
+        atomicAdd(diag + 4, (1u << 18) - H.guard);
+    }
 }
 
 __device__ __forceinline__ float uniform_f(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }

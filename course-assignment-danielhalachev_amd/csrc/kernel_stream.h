@@ -47,6 +47,7 @@ enum : int { SC_COUNT = 0, SC_FETCH = MAX_GENERATIONS, SC_HEAVY = 2 * MAX_GENERA
              SC_DEEP_HQ_HEAD = 352, SC_DEEP_DONE = 384, SC_DEEP_NODES = 416, SC_DEEP_WAITS = 448, SC_DEEP_HQ_TAIL = 480,
              // per recursion level: where its shadow rays begin in the shadow queue ([g + 1] = where they end), fetch cursors
              SC_LSPLIT = 512, SC_LFETCH = SC_LSPLIT + MAX_GENERATIONS + 1 + 31,
+             SC_HEAVY_DIAG = 704,  // diagnostics of a collect_counters == 2 render (kernel_heavy.h): 8 words closest-hit walks, 8 words shadow walks
              SC_ALLOC_WORDS = 1024 };
 static_assert(SC_LFETCH + MAX_GENERATIONS <= SC_ALLOC_WORDS, "counter block too small");
 static_assert(SC_WORDS <= 352, "the deep kernel's counters start at word 384");
