@@ -1357,12 +1357,17 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
             // the bulk shadow pass every workgroup of it waits for a free slot, and a level below heavy_level_threshold has
             // nothing for it to do (measured: 0.15 ms for an empty full-size grid).  Sized by what the level held a frame ago.
             uint32_t level_blocks = lane_blocks;
+            A.force_whole = 0u;
             if (g >= 1 && lean && !count && ctx->tuning.level_grid && prev_items == n_items && ctx->h_counts) {
                 const uint32_t prev = ctx->h_counts[SC_COUNT + g];
                 const uint32_t want = prev < A.heavy_level_threshold ? 64u : std::max<uint32_t>((uint32_t)ctx->num_cus, (prev + prev / 2u + BLOCK - 1) / BLOCK);
                 level_blocks = std::min(lane_blocks, want);
+                // far below the threshold a frame ago (level_grid = 2): no per-lane launch at all; the wave-per-ray kernel and the
+                // shading of its hits are told to take the whole level whatever it holds now
+                if (ctx->tuning.level_grid >= 2u && heavy && (uint64_t)prev * 2u < A.heavy_level_threshold) A.force_whole = 1u;
             }
-            if (count) launch(stream_trace_shade<true>, lane_blocks, stream, A, g);
+            if (A.force_whole) {}
+            else if (count) launch(stream_trace_shade<true>, lane_blocks, stream, A, g);
             else if (lean && A.plan_ok && (quad & 1u)) launch_lds(stream_trace_shade_plan<true>, level_blocks, qlds + plds, stream, A, g);
             else if (lean && A.plan_ok) launch_lds(stream_trace_shade_plan<false>, level_blocks, plds, stream, A, g);
             else if (lean && (quad & 1u)) launch_lds(stream_trace_shade_lean<true>, level_blocks, qlds, stream, A, g);

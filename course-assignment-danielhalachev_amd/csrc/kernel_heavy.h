@@ -402,6 +402,10 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void heavy_trace_closest(con
     if (A.s_counts[SC_OVERFLOW]) return;
     const uint32_t count = stream_level_count(A, gen);
     const bool whole = stream_level_is_whole_heavy(A, gen, count);  // every ray of the level: entry k is ray k
+    if (A.force_whole && !whole && gen > 0) {  // no per-lane launch and more rays than s_hits holds: the fallback redoes the frame
+        if (threadIdx.x == 0 && blockIdx.x == 0) A.s_counts[SC_OVERFLOW] = 1;
+        return;
+    }
     uint32_t total = whole ? count : A.s_counts[SC_HEAVY + gen];
     if (total > A.s_heavy_cap) total = A.s_heavy_cap;
     const float4 *in_q = A.s_rayq[gen & 1u];

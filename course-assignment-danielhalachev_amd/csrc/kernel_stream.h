@@ -58,8 +58,10 @@ __device__ __forceinline__ uint32_t stream_level_count(const KernelArgs &A, uint
     return g == 0 ? A.n_items * 64u : A.s_counts[SC_COUNT + g];
 }
 // Levels below the threshold skip the per-lane kernel: list entry k of the wave-per-ray kernel is ray k itself.
+// (force_whole: the host did not launch the per-lane kernel for this level at all -- a frame ago the level was far below the
+// threshold, crt_tuning::level_grid -- so the wave-per-ray kernel takes every ray whatever the count turns out to be.)
 __device__ __forceinline__ bool stream_level_is_whole_heavy(const KernelArgs &A, uint32_t g, uint32_t count) {
-    return g > 0 && count < A.heavy_level_threshold && count <= A.s_heavy_cap;  // s_hits holds s_heavy_cap records
+    return g > 0 && (A.force_whole || count < A.heavy_level_threshold) && count <= A.s_heavy_cap;  // s_hits holds s_heavy_cap records
 }
 __device__ __forceinline__ uint32_t stream_level_base(const KernelArgs &A, uint32_t g) {
     uint32_t base = 0;

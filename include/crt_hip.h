@@ -220,8 +220,9 @@ typedef struct crt_tuning {
                                * the wave-per-ray kernel queue their shadow rays for the later pass instead of using their fixed slots */
     uint32_t deep_first;      /* 1: with `deep`, the first recursion level the persistent launch handles (the levels before it run level by
                                * level) */
-    uint32_t level_grid;      /* 1: the per-lane launch of a deeper level is sized by the rays that level held in the previous frame (0: always
-                               * the full grid) */
+    uint32_t level_grid;      /* 1: the per-lane launch of a deeper level is sized by the rays that level held in the previous frame; 2: and
+                               * left out altogether when that was less than half of heavy_level (the wave-per-ray kernel then takes the
+                               * whole level whatever it holds; measured: no gain over 1); 0: always the full grid */
     uint32_t skip_unlit;      /* 1: a shadow ray towards a light behind its surface (light factor exactly 0: the pixel is the same occluded or
                                * not) is not walked by the planned shadow kernels */
     uint32_t wave_priority;   /* 3 (0..3): s_setprio of the recursion levels' waves (the frame's critical path) over the bulk shadow pass's, which

@@ -86,6 +86,8 @@ KERNEL_PATHS = [
     dict(pool=3), dict(pool=1, pool_refill=1, pool_switch=64),   # shadow walks with three rays per lane (kernel_pool.h)
     dict(pool=3, pool_refill=64, pool_switch=1, level_shadows=1),
     dict(early_shadow=1), dict(early_shadow=1, level0_budget=16, shadow_cap=1 << 20),  # bulk shadow pass after / before the evicted primary walks
+    dict(level_grid=2),                                          # the deeper levels' per-lane launches left out where the level was small a frame ago
+    dict(level_grid=2, heavy_level=3000),                        # ... here some levels straddle the threshold
     dict(skip_unlit=0),                                          # shadow rays towards lights behind their surface walked like the others
     dict(level_shadows=2),                                       # levels 1-2's shadow rays on a third stream beside the bulk pass, the rest at the end
     dict(level_shadows=4, wave_priority=2, level_grid=0),        # ... levels 1-4's
@@ -102,6 +104,9 @@ def test_every_kernel_path_gives_the_same_frame(pkg, scenes, oracle, name, tunin
     got = tracer.render(max_depth=depth)
     want, _ = oracle.OracleScene(scenes.to_blob(scene)).render(depth)
     assert_same_floats(got, want, "%s %r" % (name, tuning))
+    assert tracer.stats().fallback_frames == 0
+    # the second frame of a context sizes (or leaves out) launches by the first frame's counters: the same pixels again
+    assert_same_floats(tracer.render(max_depth=depth), want, "%s %r, second frame" % (name, tuning))
     assert tracer.stats().fallback_frames == 0
 
 
