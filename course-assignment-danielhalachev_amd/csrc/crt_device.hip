@@ -127,6 +127,7 @@ struct crt_ctx {
     enum Mode { MODE_STREAM, MODE_PACKETS, MODE_LANES } mode = MODE_STREAM;
     float4 *d_rayq[2] = {nullptr, nullptr};
     float4 *d_shadowq = nullptr;
+    uint2 *d_shadow_plan = nullptr;   // crt_tuning::preplan: the bulk shadow pass's plans, one per shadow slot
     uint8_t *d_occluded = nullptr;
     float4 *d_nodes = nullptr;
     uint32_t *d_scounts = nullptr;
@@ -446,6 +447,9 @@ extern "C" void crt_tuning_defaults(crt_tuning *t) {
     t->deep_first = 1;
     t->level_grid = 1;
     t->skip_unlit = 1;
+    t->preplan = 0;
+    t->pre_bundle = 48;
+    t->pre_trips = 16;
     t->wave_priority = 3;
     t->side_priority = 1;
 }
@@ -980,6 +984,7 @@ extern "C" void crt_destroy(crt_ctx *ctx) {
     for (int i = 0; i < 2; i++) if (ctx->d_rayq[i]) (void)hipFree(ctx->d_rayq[i]);
     if (ctx->d_shadowq) (void)hipFree(ctx->d_shadowq);
     if (ctx->d_occluded) (void)hipFree(ctx->d_occluded);
+    if (ctx->d_shadow_plan) (void)hipFree(ctx->d_shadow_plan);
     if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
     if (ctx->d_scounts) (void)hipFree(ctx->d_scounts);
     if (ctx->d_exec) (void)hipFree(ctx->d_exec);
@@ -1141,6 +1146,9 @@ static int ensure_stream(crt_ctx *ctx, uint32_t n_items) {
         for (int i = 0; i < 2; i++) CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_rayq[i], ray_cap * 2 * sizeof(float4)));
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_shadowq, shadow_cap * 2 * sizeof(float4)));
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_occluded, shadow_cap));
+        if (ctx->d_shadow_plan) (void)hipFree(ctx->d_shadow_plan);
+        ctx->d_shadow_plan = nullptr;
+        if (ctx->tuning.preplan) CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_shadow_plan, shadow_cap * sizeof(uint2)));
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_nodes, node_cap * 2 * sizeof(float4)));
         if (ctx->d_ready) (void)hipFree(ctx->d_ready);
         ctx->d_ready = nullptr;
@@ -1166,7 +1174,7 @@ static int ensure_stream(crt_ctx *ctx, uint32_t n_items) {
         A.s_ray_cap = (uint32_t)ray_cap; A.s_shadow_cap = (uint32_t)shadow_cap; A.s_node_cap = (uint32_t)node_cap;
         ctx->stream_items = n_items;
         ctx->queue_bytes = ray_cap * 64 + shadow_cap * 33 + node_cap * 32 + ray_cap * 8 + (size_t)ctx->heavy_cap * 24 +
-                           (ctx->packet_budget ? shadow_cap * 4 : 4) + ((size_t)n_items + 1) * 4;
+                           (ctx->packet_budget ? shadow_cap * 4 : 4) + ((size_t)n_items + 1) * 4 + (ctx->d_shadow_plan ? shadow_cap * 8 : 0);
     }
     A.s_rayq[0] = ctx->d_rayq[0]; A.s_rayq[1] = ctx->d_rayq[1];
     A.s_shadowq = ctx->d_shadowq; A.s_occluded = ctx->d_occluded; A.s_nodes = ctx->d_nodes;
@@ -1321,6 +1329,14 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
             if (count) launch(stream_trace_shadow<true>, side_blocks, ctx->side, S, 0u);
             else if (lean && (quad & 2u)) launch_lds(stream_trace_shadow_lean<0, true>, side_blocks, qlds, ctx->side, S);
             else if (lean && A.plan_ok && ctx->tuning.pool) launch_lds(stream_trace_shadow_pool<0>, side_blocks, POOL_LDS_BYTES, ctx->side, S);
+            else if (lean && A.plan_ok && ctx->d_shadow_plan) {
+                // the plans first, one ray per thread (kernel_plan.h: stream_plan_shadow), then the walks with cheap refills
+                S.s_shadow_plan = ctx->d_shadow_plan;
+                S.pre_bundle = ctx->tuning.pre_bundle > 64u ? 64u : ctx->tuning.pre_bundle;
+                S.pre_trips = ctx->tuning.pre_trips < 1u ? 1u : (ctx->tuning.pre_trips > 64u ? 64u : ctx->tuning.pre_trips);
+                launch(stream_plan_shadow, lane_blocks, ctx->side, S);
+                launch(stream_trace_shadow_preplanned, side_blocks, ctx->side, S);
+            }
             else if (lean && A.plan_ok) launch(stream_trace_shadow_plan<0>, side_blocks, ctx->side, S);
             else if (lean) launch(stream_trace_shadow_lean<0, false>, side_blocks, ctx->side, S);
             else launch(stream_trace_shadow<false>, side_blocks, ctx->side, S, 0u);

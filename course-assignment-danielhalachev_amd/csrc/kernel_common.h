@@ -141,6 +141,9 @@ struct KernelArgs {
     // kernel_deep.h: the level-free queue of the recursion levels >= 1
     uint32_t use_gi, gi_samples, rays_per_pixel, gi_seed;  // crt_options: the GI / multi-sample mode (kernel_lane.h, gi_random.h)
     float monte_carlo_bias;
+    uint2 *s_shadow_plan;         // kernel_plan.h: stream_plan_shadow's result per level-0 shadow slot (crt_tuning::preplan)
+    uint32_t pre_bundle;          // ... and the refill threshold of the walk kernel that reads it
+    uint32_t pre_trips;           // ... and its loop trips between two looks at the refill condition
     uint32_t force_whole;         // this level's per-lane kernel was not launched: the wave-per-ray kernel takes all its rays (kernel_stream.h)
     uint32_t skip_unlit;          // kernel_plan.h: shadow rays whose light factor is exactly zero are not walked (crt_tuning::skip_unlit)
     uint32_t deep_first;          // kernel_deep.h: the first recursion level the persistent launch handles

@@ -44,6 +44,9 @@ __device__ __forceinline__ uint32_t leaf_cursor_next(uint32_t c) { return (c >> 
 
 // ---------------------------------------------------------------------------------------------------------------- shadow
 // the shadow rays [first, first + total) of the queue; `cursor` hands them out
+// PRE: the plans were computed by stream_plan_shadow (below) and are read back per ray; a refill then costs the wave a few loads
+// instead of the loop over the top-level leaves, and free lanes are refilled as soon as `pre_bundle` of them wait.
+template <bool PRE = false>
 __device__ __forceinline__ void shadow_plan_walks(const KernelArgs &A, const uint32_t first, const uint32_t total, uint32_t *cursor) {
     __shared__ uint32_t root_of_bit[64];  // shadow order -> root node of the mesh's tree
     if (threadIdx.x < 64u) root_of_bit[threadIdx.x] = threadIdx.x < A.plan_shadow_bits ? A.meshes[A.plan_shadow_mesh[threadIdx.x]].root : END;
@@ -63,7 +66,8 @@ __device__ __forceinline__ void shadow_plan_walks(const KernelArgs &A, const uin
     for (;;) {
         // ---- refill: free lanes wait until no more than `bundle` lanes still walk, then fetch together (the plan below
         //      costs the wave the same for one new ray as for 64)
-        if (__ballot(state == ST_FETCH) && (A.bundle >= 64u || (uint32_t)__popcll(__ballot(state == ST_TRAVERSE)) <= A.bundle)) {
+        const uint32_t bundle = PRE ? A.pre_bundle : A.bundle;
+        if (__ballot(state == ST_FETCH) && (bundle >= 64u || (uint32_t)__popcll(__ballot(state == ST_TRAVERSE)) <= bundle)) {
             bool fresh = false;
             while (state == ST_FETCH) {
                 r = wave_fetch(cursor, lane);
@@ -88,8 +92,9 @@ __device__ __forceinline__ void shadow_plan_walks(const KernelArgs &A, const uin
                 fresh = true;
                 steps = 0;
                 state = ST_TRAVERSE;
+                if (PRE) { const uint2 m = A.s_shadow_plan[r]; mlo = m.x; mhi = m.y; wn = END; we = NONE; }
             }
-            if (fresh) {
+            if (!PRE && fresh) {
                 // the plan: which meshes does this ray have to walk?  (k is wave-uniform: scalar loads, no gathers)
                 uint32_t lo = 0, hi = 0;
                 for (uint32_t k = 0; k < A.plan_leaves; k++) {
@@ -124,7 +129,8 @@ __device__ __forceinline__ void shadow_plan_walks(const KernelArgs &A, const uin
                 wn = (hit && !leaf) ? link : miss;
                 return true;
             };
-            for (int it = 0; it < 64; ++it) {
+            const int trips = PRE ? (int)A.pre_trips : 64;  // (a lane whose walk ends waits for the end of this block of trips)
+            for (int it = 0; it < trips; ++it) {
                 // What a trip costs the wave is its vector-memory instructions (a divergent gather occupies the vector L1 for
                 // ~64 cycles however few lanes take part): 4 for the triangle block, 2 for the node block.  With tri_gather
                 // set, a trip runs ONE of the blocks: lanes that have reached a leaf wait there until tri_gather of them
@@ -198,6 +204,41 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shadow_plan(const KernelAr
     const uint32_t split = A.s_counts[SC_SHADOW_SPLIT];
     shadow_plan_walks(A, pass == 0 ? 0u : split, pass == 0 ? split : A.s_counts[SC_SHADOW] - split,
                       A.s_counts + (pass == 0 ? SC_SHADOW_FETCH : SC_SHADOW_FETCH2));
+}
+
+// The plans of pass 0's rays, one ray per thread with every lane busy: which meshes (bits of the shadow order) does the ray have
+// to walk?  Inside the walk kernel the same loop runs once per REFILL of a wave, whatever the number of lanes refilled, which is
+// why that kernel waits for many free lanes before it refills (KernelArgs::bundle) -- and why its lanes idle.  (crt_tuning::preplan)
+__global__ __launch_bounds__(BLOCK) void stream_plan_shadow(const KernelArgs A) {
+    if (A.s_counts[SC_OVERFLOW]) return;
+    const uint32_t split = A.s_counts[SC_SHADOW_SPLIT];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t nplan = 0;
+    for (uint32_t base = (blockIdx.x * BLOCK + (threadIdx.x & ~63u)); base < split; base += gridDim.x * BLOCK) {  // wave-uniform trip count
+        const uint32_t r = base + lane;
+        const bool in = r < split;
+        const float4 q0 = A.s_shadowq[2 * (size_t)(in ? r : 0u)], q1 = A.s_shadowq[2 * (size_t)(in ? r : 0u) + 1];
+        Ray R;
+        R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
+        R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;
+        ray_prepare(R);
+        // (slots the walk kernel skips or hands to the wave-per-ray kernel get a plan nobody reads)
+        const bool used = in && __float_as_uint(q0.w) != SHADOW_SLOT_UNUSED && R.parmask == 0 && !(A.skip_unlit && q1.w == 0.0f);
+        if (__ballot(used)) {
+            uint32_t lo = 0, hi = 0;
+            for (uint32_t k = 0; k < A.plan_leaves; k++) {
+                const v16f L = plan_leaf(A, k);
+                const bool hit = slab_test_no_parallel(R, L[0], L[1], L[2], L[4], L[5], L[6]);
+                lo |= hit ? __float_as_uint(L[8]) : 0u;
+                hi |= hit ? __float_as_uint(L[9]) : 0u;
+            }
+            if (used) { A.s_shadow_plan[r] = make_uint2(lo, hi); if (A.exec_count) nplan += A.plan_leaves; }
+        }
+    }
+    exec_counters_flush(A, 0u, 0u, lane, nplan);
+}
+__global__ __launch_bounds__(BLOCK) void stream_trace_shadow_preplanned(const KernelArgs A) {
+    shadow_plan_walks<true>(A, 0u, A.s_counts[SC_SHADOW_SPLIT], A.s_counts + SC_SHADOW_FETCH);
 }
 
 // the shadow rays recursion level `gen` queued, alone: slots [SC_LSPLIT + gen, SC_LSPLIT + gen + 1).  Launched on the side

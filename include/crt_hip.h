@@ -225,6 +225,10 @@ typedef struct crt_tuning {
                                * whole level whatever it holds; measured: no gain over 1); 0: always the full grid */
     uint32_t skip_unlit;      /* 1: a shadow ray towards a light behind its surface (light factor exactly 0: the pixel is the same occluded or
                                * not) is not walked by the planned shadow kernels */
+    uint32_t preplan;         /* 1: the bulk shadow pass's plans (which meshes a ray must walk) are computed by a launch of their own, one ray
+                               * per thread, and read back by the walk kernel, whose refills then cost a few loads (8 B per shadow slot) */
+    uint32_t pre_bundle;      /* 48: that walk kernel refills a wave when at most this many lanes still walk */
+    uint32_t pre_trips;       /* 16: ... and looks at that condition every so many loop trips (the kernel that plans inside the walk: 64) */
     uint32_t wave_priority;   /* 3 (0..3): s_setprio of the recursion levels' waves (the frame's critical path) over the bulk shadow pass's, which
                                * shares the SIMDs with them */
     uint32_t side_priority;   /* 1 (0 = default priority): the side stream (bulk shadow pass) is created with the lowest stream priority */

@@ -88,6 +88,8 @@ KERNEL_PATHS = [
     dict(early_shadow=1), dict(early_shadow=1, level0_budget=16, shadow_cap=1 << 20),  # bulk shadow pass after / before the evicted primary walks
     dict(level_grid=2),                                          # the deeper levels' per-lane launches left out where the level was small a frame ago
     dict(level_grid=2, heavy_level=3000),                        # ... here some levels straddle the threshold
+    dict(preplan=1),                                             # the bulk shadow pass's plans by a launch of their own
+    dict(preplan=1, pre_bundle=63, shadow_budget=8),             # ... lanes refilled one by one; nearly every walk handed to the wave-per-ray kernel
     dict(skip_unlit=0),                                          # shadow rays towards lights behind their surface walked like the others
     dict(level_shadows=2),                                       # levels 1-2's shadow rays on a third stream beside the bulk pass, the rest at the end
     dict(level_shadows=4, wave_priority=2, level_grid=0),        # ... levels 1-4's
