@@ -1,6 +1,8 @@
-"""Dev helper: time one rank's share of the frame (tiles rank, rank+N, ...) for several world sizes on one GPU."""
+"""Dev helper: time one rank's share of the frame (tiles rank, rank+N, ...) for several world sizes on one GPU.
+usage: python tools/rank_time.py hw14 [1,2,4,8]"""
 import importlib, sys, time
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 pkg = importlib.import_module('course-assignment-danielhalachev_amd'); sc = pkg.scenes
 tiles = importlib.import_module('course-assignment-danielhalachev_amd.tiles')
@@ -9,7 +11,8 @@ s = sc.make(name); tr = pkg.Tracer(pkg.Scene(json_text=sc.to_json(s)), tuning=pk
 depth = sc.CONFIGS[name][3]
 opts = pkg.make_options(depth)
 dev = torch.device('cuda', 0)
-for world in (1, 2, 4, 8):
+worlds = [int(w) for w in sys.argv[2].split(',')] if len(sys.argv) > 2 else [1, 2, 4, 8]
+for world in worlds:
     per = tiles.tiles_per_rank(tr.width, tr.height, world)
     buf = torch.zeros(per * 192, dtype=torch.float32, device=dev)
     for _ in range(3):
