@@ -364,6 +364,7 @@ def main():
                        "scene": args.scene, "width": W, "height": H, "max_depth": depth,
                        "parallelism": "tiles8x8-roundrobin-%d" % world, "tuning": args.tuning or "defaults"},
             "frame_matches_counting_build": frame_ok,
+            "autotune": tracer.kernels().get("autotune"),   # crt_tuning::autotune: what the context settled on while it rendered
             "pipelined": pipelined,
             "value_incl_d2h": round(W * H / d2h_elapsed / 1e6, 3),
             "kernel_ms": {"first_to_last": round(avg_kernel_ms, 4), "recursion_levels": round(pk_ms, 4),

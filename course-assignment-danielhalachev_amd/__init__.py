@@ -105,7 +105,7 @@ class Tuning(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "size", "mode", "step_budget", "shadow_budget", "pass1_budget", "heavy_level", "heavy_blocks", "side_blocks",
         "quad", "quad_stack", "prune", "bundle", "fixed0", "packet_budget", "path_mask", "top_in_registers",
-        "tiny_meshes", "node_cap", "ray_cap", "shadow_cap", "deep", "deep_blocks", "plan", "deep_waves", "tri_gather", "deep_heavy_every", "level0_budget", "node_repeat", "heavy_waves", "level_shadows", "pool", "pool_refill", "pool_switch", "early_shadow", "deep_first", "level_grid", "skip_unlit", "preplan", "pre_bundle", "pre_trips", "wave_priority", "side_priority")]
+        "tiny_meshes", "node_cap", "ray_cap", "shadow_cap", "deep", "deep_blocks", "plan", "deep_waves", "tri_gather", "deep_heavy_every", "level0_budget", "node_repeat", "heavy_waves", "level_shadows", "pool", "pool_refill", "pool_switch", "early_shadow", "deep_first", "level_grid", "skip_unlit", "autotune", "preplan", "pre_bundle", "pre_trips", "wave_priority", "side_priority")]
 
 
 def make_tuning(**fields):

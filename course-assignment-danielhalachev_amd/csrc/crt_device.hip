@@ -150,6 +150,19 @@ struct crt_ctx {
     uint32_t sizing_seen_fallbacks = 0, last_items = 0;
     uint64_t queue_bytes = 0;         // bytes of the per-frame buffers as allocated now
     hipEvent_t ev_level[MAX_GENERATIONS] = {};  // level g is done (its shadow rays may start on the side stream)
+    // crt_tuning::autotune (see autotune_step): two budgets whose best value depends on the scene are tried on the frames
+    // themselves and the faster setting kept.  No setting changes a pixel.
+    struct AutoTune {
+        uint32_t b0 = 0, hl = 0;            // the settings in force: level-0 step budget, heavy_level threshold (0 = the defaults)
+        int stage = 0;                      // 0: measuring the defaults; 1..N_CAND: trying candidate stage - 1; -1: settled
+        double best_ms = 0;
+        float samples[16] = {};
+        uint32_t best_b0 = 0, best_hl = 0;
+        int n = 0, seen = 0;
+        uint64_t next_harvest = 0;          // the next launch whose events have not been read yet
+        int tag[EV_RING] = {};              // the stage each slot's frame was launched in (-2: not a frame of this workload)
+        uint32_t items = 0, depth = 0;      // the workload being tuned (a change starts over)
+    } at;
     hipStream_t side2 = nullptr;      // crt_tuning::level_shadows >= 2: the first deeper levels' shadow rays, beside the bulk pass
     hipEvent_t ev_side2 = nullptr;
     hipEvent_t ev_call0 = nullptr, ev_call1 = nullptr;  // around the last crt_render / crt_render_async call's device work
@@ -447,6 +460,7 @@ extern "C" void crt_tuning_defaults(crt_tuning *t) {
     t->deep_first = 1;
     t->level_grid = 1;
     t->skip_unlit = 1;
+    t->autotune = 1;
     t->preplan = 0;
     t->pre_bundle = 48;
     t->pre_trips = 16;
@@ -1194,6 +1208,62 @@ static void launch_lds(K kernel, uint32_t blocks, uint32_t lds_bytes, hipStream_
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK), lds_bytes, stream, args...);
 }
 
+// crt_tuning::autotune.  Two constants of the ray-stream pass have no best value across scenes -- measured on the five
+// BASELINE scenes: the step budget of level 0's per-lane kernel (256 / 192 / 128: HW14 5.87 / 5.76 / 5.85 ms, HW11 6.27 / 6.07 /
+// 6.04, HW12 20.6 / 20.7 / 21.4) and the ray count below which a deeper level goes to the wave-per-ray kernel whole (100 k / 40 k:
+// HW14 5.74 / 5.61 with the 192 budget, HW11 6.3 / 7.6) -- and no counter of the previous frame predicts it.  So the frames
+// themselves are the measurement: every frame is timed by events anyway (ev0 .. ev4); a context renders a dozen frames with the
+// defaults, a dozen with each candidate, and keeps what was faster by more than the noise.  Frames of another size or depth start
+// it over; explicit budgets in crt_tuning switch it off.  Events are only read once they have completed (hipEventQuery): no wait.
+static const uint32_t AT_CAND[][2] = {{192u, 0u}, {128u, 0u}, {0xFFFFFFFFu, 40000u}};  // {level-0 budget, heavy_level}; ~0: keep the best so far
+static constexpr int AT_N_CAND = 3, AT_SKIP = 3, AT_SAMPLES = 12;
+static void autotune_step(crt_ctx *ctx, uint32_t n_items, uint32_t depth, bool eligible) {
+    crt_ctx::AutoTune &T = ctx->at;
+    const int slot_now = (int)(ctx->launches % crt_ctx::EV_RING);
+    if (!eligible) { T.tag[slot_now] = -2; return; }
+    if (T.items != n_items || T.depth != depth) {  // another workload: start over with the defaults
+        T = crt_ctx::AutoTune();
+        T.items = n_items; T.depth = depth;
+        T.next_harvest = ctx->launches;
+        for (int i = 0; i < crt_ctx::EV_RING; i++) T.tag[i] = -2;
+    }
+    // read the frames that have completed since the last look
+    while (T.next_harvest < ctx->launches) {
+        const uint64_t j = T.next_harvest;
+        if (j + crt_ctx::EV_RING <= ctx->launches) { T.next_harvest++; continue; }  // its slot has been reused
+        const int slot = (int)(j % crt_ctx::EV_RING);
+        if (hipEventQuery(ctx->ev4[slot]) != hipSuccess) { (void)hipGetLastError(); break; }
+        T.next_harvest++;
+        float ms = 0;
+        if (T.stage < 0 || T.tag[slot] != T.stage || hipEventElapsedTime(&ms, ctx->ev0[slot], ctx->ev4[slot]) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (++T.seen <= AT_SKIP) continue;  // the first frames after a change still carry the previous setting's queues and counters
+        if (T.n < AT_SAMPLES) T.samples[T.n++] = ms;
+    }
+    // a candidate whose first frames are all clearly slower than the best so far is dropped at once (its fastest frame 4 % behind)
+    if (T.stage > 0 && T.n >= 4 && T.n < AT_SAMPLES && *std::min_element(T.samples, T.samples + T.n) > T.best_ms * 1.04) {
+        for (int i = T.n; i < AT_SAMPLES; i++) T.samples[i] = T.samples[0];
+        T.n = AT_SAMPLES;
+    }
+    if (T.stage >= 0 && T.n >= AT_SAMPLES) {
+        // the mean of the faster two thirds: a frame that was redone by the fallback, or met another process, does not count
+        std::sort(T.samples, T.samples + AT_SAMPLES);
+        double mean = 0;
+        for (int i = 0; i < AT_SAMPLES * 2 / 3; i++) mean += T.samples[i];
+        mean /= AT_SAMPLES * 2 / 3;
+        if (T.stage == 0 || mean < T.best_ms * 0.993) { T.best_ms = mean; T.best_b0 = T.b0; T.best_hl = T.hl; }
+        T.stage = T.stage + 1 <= AT_N_CAND ? T.stage + 1 : -1;
+        T.n = 0; T.seen = 0;
+        if (T.stage > 0) {
+            const uint32_t *c = AT_CAND[T.stage - 1];
+            T.b0 = c[0] == 0xFFFFFFFFu ? T.best_b0 : c[0];
+            T.hl = c[0] == 0xFFFFFFFFu ? c[1] : T.best_hl;
+        } else {
+            T.b0 = T.best_b0; T.hl = T.best_hl;  // settled
+        }
+    }
+    T.tag[slot_now] = T.stage;
+}
+
 static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, float *d_out, uint32_t packed,
                          hipStream_t stream, bool timed) {
     const bool gi = o->use_gi != 0;  // the GI / multi-sample mode: rendered pixel by pixel by render_lanes<.., true> (kernel_lane.h)
@@ -1249,6 +1319,12 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         A.debug = ctx->debug_skip;
         const bool lean = heavy && ctx->lean_ok && !(ctx->debug_skip & 256u);
         A.heavy_level_threshold = lean ? ctx->heavy_level_threshold : 0u;
+        {
+            const bool eligible = ctx->tuning.autotune && timed && lean && !count && !exec_count && ctx->tuning.level0_budget == 0u &&
+                                  ctx->tuning.heavy_level == 100000u && ctx->tuning.step_budget == 256u && !ctx->tuning.deep;
+            autotune_step(ctx, n_items, o->max_depth, eligible);
+            if (eligible && ctx->at.hl) A.heavy_level_threshold = ctx->at.hl;
+        }
         const uint32_t quad = lean ? ctx->use_quads : 0u;  // bit 0: the levels, bit 1: shadow pass 0, bit 2: shadow pass 1
         A.quad_stack_depth = ctx->quad_stack_depth;
         A.prune = ctx->prune;
@@ -1311,6 +1387,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         const uint64_t est0 = (uint64_t)n_items * 64u * 70u / ((uint64_t)lane_blocks * BLOCK);
         uint32_t budget0 = est0 >= ctx->step_budget ? ctx->step_budget : (est0 < 64u ? 64u : (uint32_t)est0);
         if (ctx->tuning.level0_budget) budget0 = ctx->tuning.level0_budget;
+        else if (ctx->at.b0 && ctx->at.tag[slot] >= -1 && ctx->at.b0 < budget0) budget0 = ctx->at.b0;  // crt_tuning::autotune
         // the recursion levels >= 1: one persistent queue-driven launch (kernel_deep.h), or a launch triple per level
         const uint32_t deep_first = ctx->tuning.deep_first < 1u ? 1u : ctx->tuning.deep_first;
         const bool deep = heavy && ctx->tuning.deep && o->max_depth >= deep_first;
@@ -1858,6 +1935,12 @@ extern "C" int crt_describe_kernels(const crt_ctx *ctx, char *out, size_t size) 
         d += ";levels=";
         d += !heavy ? "stream_trace_shade<false>" : (ctx->tuning.deep == 1u ? "deep_trace" : (ctx->tuning.deep == 2u && A.plan_ok ? "deep_lanes" :
              (ctx->tuning.heavy_waves == 7u ? "heavy_trace_closest<7>" : (ctx->tuning.heavy_waves == 4u ? "heavy_trace_closest<4>" : "heavy_trace_closest<5>"))));
+    }
+    if (ctx->mode == crt_ctx::MODE_STREAM) {
+        char buf[160];
+        snprintf(buf, sizeof(buf), ";autotune=%s level0_budget=%u heavy_level=%u", !ctx->tuning.autotune ? "off" : (ctx->at.stage < 0 ? "settled" : "measuring"),
+                 ctx->at.b0, ctx->at.hl ? ctx->at.hl : ctx->heavy_level_threshold);
+        d += buf;
     }
     snprintf(out, size, "%s", d.c_str());
     return CRT_OK;

@@ -225,6 +225,9 @@ typedef struct crt_tuning {
                                * whole level whatever it holds; measured: no gain over 1); 0: always the full grid */
     uint32_t skip_unlit;      /* 1: a shadow ray towards a light behind its surface (light factor exactly 0: the pixel is the same occluded or
                                * not) is not walked by the planned shadow kernels */
+    uint32_t autotune;        /* 1: two budgets whose best value depends on the scene (level 0's step budget, heavy_level) are tried on the frames
+                               * themselves -- a dozen frames each, timed by the events every frame records -- and the faster setting is kept
+                               * (crt_device.hip: autotune_step); off when level0_budget, heavy_level or step_budget are given explicitly */
     uint32_t preplan;         /* 1: the bulk shadow pass's plans (which meshes a ray must walk) are computed by a launch of their own, one ray
                                * per thread, and read back by the walk kernel, whose refills then cost a few loads (8 B per shadow slot) */
     uint32_t pre_bundle;      /* 48: that walk kernel refills a wave when at most this many lanes still walk */

@@ -480,3 +480,28 @@ def test_async_frames_equal_synchronous_ones(pkg, scenes, oracle):
         want, _ = o.render(depth)
         assert_same_floats(bufs[j % 2][0], want, "async frame %d" % j)
     assert ring[0].stats().pixels == H * W and ring[0].stats().kernel_ms > 0
+
+
+def test_autotune_tries_settings_on_the_frames_and_never_changes_one(pkg, scenes, oracle):
+    """crt_tuning::autotune (default on): a context times its own frames and tries two budgets on them.  Every frame on the way is
+    the oracle's, and after enough frames the context has settled; explicit budgets switch the tuner off."""
+    scene, depth, _ = small_case(scenes, "hw14")
+    want, _ = oracle.OracleScene(scenes.to_blob(scene)).render(depth)
+    tracer = make_tracer(pkg, scenes, scene)
+    assert tracer.kernels()["autotune"].startswith("measuring")
+    for k in range(80):
+        got = tracer.render(max_depth=depth)
+        if k % 7 == 0 or k > 70:
+            assert_same_floats(got, want, "autotune frame %d (%s)" % (k, tracer.kernels()["autotune"]))
+    assert tracer.kernels()["autotune"].startswith("settled"), tracer.kernels()["autotune"]
+    assert tracer.stats().fallback_frames == 0
+    # another depth is another workload: the tuner starts over
+    tracer.render(max_depth=depth - 1)
+    assert tracer.kernels()["autotune"].startswith("measuring")
+    fixed = make_tracer(pkg, scenes, scene, tuning=dict(level0_budget=192))
+    for _ in range(3):
+        fixed.render(max_depth=depth)
+    assert fixed.kernels()["autotune"].startswith("measuring level0_budget=0")   # never leaves its start: not eligible
+    off = make_tracer(pkg, scenes, scene, tuning=dict(autotune=0))
+    off.render(max_depth=depth)
+    assert off.kernels()["autotune"].startswith("off")
