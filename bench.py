@@ -88,7 +88,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=100)   # enough frames for crt_tuning::autotune to try its candidates and settle
     ap.add_argument("--scene", default=WORKLOAD)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
@@ -191,6 +191,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+        tracer.synchronize()   # (untimed: one frame at a time, so that the context sees each frame's duration before it launches the next)
     fence()
     # queue capacities follow the frames: a context's FIRST frames may outgrow them and be redone by the
     # queue-less kernel.  Such a frame inside the timed region would not be a measurement of the path; before it, it is start-up.

@@ -153,11 +153,11 @@ struct crt_ctx {
     // crt_tuning::autotune (see autotune_step): two budgets whose best value depends on the scene are tried on the frames
     // themselves and the faster setting kept.  No setting changes a pixel.
     struct AutoTune {
-        uint32_t b0 = 0, hl = 0;            // the settings in force: level-0 step budget, heavy_level threshold (0 = the defaults)
+        uint32_t b0 = 0, hl = 0, sb = 0;    // the settings in force: level-0 step budget, heavy_level threshold, workgroups of the bulk shadow pass per CU (0 = the defaults)
         int stage = 0;                      // 0: measuring the defaults; 1..N_CAND: trying candidate stage - 1; -1: settled
         double best_ms = 0;
         float samples[16] = {};
-        uint32_t best_b0 = 0, best_hl = 0;
+        uint32_t best_b0 = 0, best_hl = 0, best_sb = 0;
         int n = 0, seen = 0;
         uint64_t next_harvest = 0;          // the next launch whose events have not been read yet
         int tag[EV_RING] = {};              // the stage each slot's frame was launched in (-2: not a frame of this workload)
@@ -182,7 +182,7 @@ struct crt_ctx {
     uint32_t heavy_blocks = 4096;     // CRT_HEAVY_BLOCKS: grid of the wave-per-ray kernels (more blocks than fit: late ones balance the load)
     uint32_t prune = 0;               // CRT_PRUNE: distance pruning of closest-hit walks (kernel_common.h); bit 0 quad walk, bit 1 heavy_trace
     uint32_t n_quads = 0;
-    uint32_t side_blocks_per_cu = 4;  // CRT_SIDE_BLOCKS: blocks per CU of the overlapped shadow pass
+    uint32_t side_blocks_per_cu = 3;  // crt_tuning::side_blocks: blocks per CU of the overlapped shadow pass
     uint32_t debug_skip = 0;          // CRT_DEBUG_SKIP: path selection for tests (256: no lean kernels, 512: no packets)
     uint64_t stream_items = 0;        // work items the stream buffers are sized for
     uint64_t overflows = 0;           // frames redone by the fallback (diagnostic)
@@ -442,7 +442,7 @@ extern "C" void crt_tuning_defaults(crt_tuning *t) {
     t->size = (uint32_t)sizeof(*t);
     t->mode = CRT_MODE_STREAM;
     t->step_budget = 256; t->shadow_budget = 4096; t->pass1_budget = 0;
-    t->heavy_level = 100000; t->heavy_blocks = 4096; t->side_blocks = 4;
+    t->heavy_level = 100000; t->heavy_blocks = 4096; t->side_blocks = 3;
     t->quad = 1; t->quad_stack = 16; t->prune = 0; t->bundle = 16; t->fixed0 = 1;
     t->packet_budget = 0; t->path_mask = 0; t->top_in_registers = 1; t->tiny_meshes = 1;
     t->node_cap = t->ray_cap = t->shadow_cap = 0;
@@ -1215,8 +1215,11 @@ static void launch_lds(K kernel, uint32_t blocks, uint32_t lds_bytes, hipStream_
 // themselves are the measurement: every frame is timed by events anyway (ev0 .. ev4); a context renders a dozen frames with the
 // defaults, a dozen with each candidate, and keeps what was faster by more than the noise.  Frames of another size or depth start
 // it over; explicit budgets in crt_tuning switch it off.  Events are only read once they have completed (hipEventQuery): no wait.
-static const uint32_t AT_CAND[][2] = {{192u, 0u}, {128u, 0u}, {0xFFFFFFFFu, 40000u}};  // {level-0 budget, heavy_level}; ~0: keep the best so far
-static constexpr int AT_N_CAND = 3, AT_SKIP = 3, AT_SAMPLES = 12;
+// A third one: the workgroups per CU of the bulk shadow pass beside the levels (4 / 3: HW12 20.6 / 19.6 ms, HW11 6.06 / 6.0, HW14 and HW08 level;
+// 3 is the default, 4 the candidate).
+static constexpr uint32_t AT_KEEP = 0xFFFFFFFFu;  // "the best value so far"
+static const uint32_t AT_CAND[][3] = {{192u, 0u, 0u}, {128u, 0u, 0u}, {AT_KEEP, 40000u, 0u}, {AT_KEEP, AT_KEEP, 4u}};  // {level-0 budget, heavy_level, side workgroups}
+static constexpr int AT_N_CAND = 4, AT_SKIP = 3, AT_SAMPLES = 12;
 static void autotune_step(crt_ctx *ctx, uint32_t n_items, uint32_t depth, bool eligible) {
     crt_ctx::AutoTune &T = ctx->at;
     const int slot_now = (int)(ctx->launches % crt_ctx::EV_RING);
@@ -1250,15 +1253,16 @@ static void autotune_step(crt_ctx *ctx, uint32_t n_items, uint32_t depth, bool e
         double mean = 0;
         for (int i = 0; i < AT_SAMPLES * 2 / 3; i++) mean += T.samples[i];
         mean /= AT_SAMPLES * 2 / 3;
-        if (T.stage == 0 || mean < T.best_ms * 0.993) { T.best_ms = mean; T.best_b0 = T.b0; T.best_hl = T.hl; }
+        if (T.stage == 0 || mean < T.best_ms * 0.993) { T.best_ms = mean; T.best_b0 = T.b0; T.best_hl = T.hl; T.best_sb = T.sb; }
         T.stage = T.stage + 1 <= AT_N_CAND ? T.stage + 1 : -1;
         T.n = 0; T.seen = 0;
         if (T.stage > 0) {
             const uint32_t *c = AT_CAND[T.stage - 1];
-            T.b0 = c[0] == 0xFFFFFFFFu ? T.best_b0 : c[0];
-            T.hl = c[0] == 0xFFFFFFFFu ? c[1] : T.best_hl;
+            T.b0 = c[0] == AT_KEEP ? T.best_b0 : c[0];
+            T.hl = c[1] == AT_KEEP ? T.best_hl : (c[1] ? c[1] : T.best_hl);
+            T.sb = c[2] == AT_KEEP ? T.best_sb : (c[2] ? c[2] : T.best_sb);
         } else {
-            T.b0 = T.best_b0; T.hl = T.best_hl;  // settled
+            T.b0 = T.best_b0; T.hl = T.best_hl; T.sb = T.best_sb;  // settled
         }
     }
     T.tag[slot_now] = T.stage;
@@ -1319,11 +1323,13 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         A.debug = ctx->debug_skip;
         const bool lean = heavy && ctx->lean_ok && !(ctx->debug_skip & 256u);
         A.heavy_level_threshold = lean ? ctx->heavy_level_threshold : 0u;
+        uint32_t at_side_blocks = 0;  // crt_tuning::autotune's choice of the bulk shadow pass's workgroups per CU (0: the tuning's)
         {
             const bool eligible = ctx->tuning.autotune && timed && lean && !count && !exec_count && ctx->tuning.level0_budget == 0u &&
                                   ctx->tuning.heavy_level == 100000u && ctx->tuning.step_budget == 256u && !ctx->tuning.deep;
             autotune_step(ctx, n_items, o->max_depth, eligible);
             if (eligible && ctx->at.hl) A.heavy_level_threshold = ctx->at.hl;
+            at_side_blocks = eligible && ctx->at.sb && ctx->tuning.side_blocks == 3u ? ctx->at.sb : 0u;
         }
         const uint32_t quad = lean ? ctx->use_quads : 0u;  // bit 0: the levels, bit 1: shadow pass 0, bit 2: shadow pass 1
         A.quad_stack_depth = ctx->quad_stack_depth;
@@ -1402,7 +1408,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
             CRT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork[slot], 0));
             CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s0[slot], ctx->side));
             // its persistent waves must leave wave slots on every CU for the level kernels running beside it
-            const uint32_t side_blocks = (uint32_t)ctx->num_cus * ctx->side_blocks_per_cu;
+            const uint32_t side_blocks = (uint32_t)ctx->num_cus * (at_side_blocks ? at_side_blocks : ctx->side_blocks_per_cu);
             if (count) launch(stream_trace_shadow<true>, side_blocks, ctx->side, S, 0u);
             else if (lean && (quad & 2u)) launch_lds(stream_trace_shadow_lean<0, true>, side_blocks, qlds, ctx->side, S);
             else if (lean && A.plan_ok && ctx->tuning.pool) launch_lds(stream_trace_shadow_pool<0>, side_blocks, POOL_LDS_BYTES, ctx->side, S);
@@ -1938,8 +1944,8 @@ extern "C" int crt_describe_kernels(const crt_ctx *ctx, char *out, size_t size) 
     }
     if (ctx->mode == crt_ctx::MODE_STREAM) {
         char buf[160];
-        snprintf(buf, sizeof(buf), ";autotune=%s level0_budget=%u heavy_level=%u", !ctx->tuning.autotune ? "off" : (ctx->at.stage < 0 ? "settled" : "measuring"),
-                 ctx->at.b0, ctx->at.hl ? ctx->at.hl : ctx->heavy_level_threshold);
+        snprintf(buf, sizeof(buf), ";autotune=%s level0_budget=%u heavy_level=%u side_blocks=%u", !ctx->tuning.autotune ? "off" : (ctx->at.stage < 0 ? "settled" : "measuring"),
+                 ctx->at.b0, ctx->at.hl ? ctx->at.hl : ctx->heavy_level_threshold, ctx->at.sb ? ctx->at.sb : ctx->side_blocks_per_cu);
         d += buf;
     }
     snprintf(out, size, "%s", d.c_str());

@@ -183,7 +183,7 @@ typedef struct crt_tuning {
     uint32_t pass1_budget;    /* 0 (= step_budget): cap for the second shadow pass */
     uint32_t heavy_level;     /* 100000: recursion levels with fewer rays skip the per-lane kernel */
     uint32_t heavy_blocks;    /* 4096: grid of the wave-per-ray kernels */
-    uint32_t side_blocks;     /* 4: workgroups per CU of the bulk shadow pass on the side stream; 0 = no side stream */
+    uint32_t side_blocks;     /* 3: workgroups per CU of the bulk shadow pass on the side stream; 0 = no side stream */
     uint32_t quad;            /* 1: which lean kernels walk quad nodes (bit 0 levels, 1 bulk shadow pass, 2 second shadow pass) */
     uint32_t quad_stack;      /* 16: LDS words per lane of the quad walk's stack (4..60) */
     uint32_t prune;           /* 0: exact distance pruning of closest-hit walks (bit 0 quad walk, bit 1 wave-per-ray) */
@@ -225,9 +225,10 @@ typedef struct crt_tuning {
                                * whole level whatever it holds; measured: no gain over 1); 0: always the full grid */
     uint32_t skip_unlit;      /* 1: a shadow ray towards a light behind its surface (light factor exactly 0: the pixel is the same occluded or
                                * not) is not walked by the planned shadow kernels */
-    uint32_t autotune;        /* 1: two budgets whose best value depends on the scene (level 0's step budget, heavy_level) are tried on the frames
+    uint32_t autotune;        /* 1: three settings whose best value depends on the scene (level 0's step budget, heavy_level, side_blocks 3 / 4) are tried on the frames
                                * themselves -- a dozen frames each, timed by the events every frame records -- and the faster setting is kept
-                               * (crt_device.hip: autotune_step); off when level0_budget, heavy_level or step_budget are given explicitly */
+                               * (crt_device.hip: autotune_step); off when level0_budget, heavy_level or step_budget are given explicitly; side_blocks is only
+                               * tried from its default of 3 */
     uint32_t preplan;         /* 1: the bulk shadow pass's plans (which meshes a ray must walk) are computed by a launch of their own, one ray
                                * per thread, and read back by the walk kernel, whose refills then cost a few loads (8 B per shadow slot) */
     uint32_t pre_bundle;      /* 48: that walk kernel refills a wave when at most this many lanes still walk */

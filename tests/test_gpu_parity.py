@@ -489,9 +489,9 @@ def test_autotune_tries_settings_on_the_frames_and_never_changes_one(pkg, scenes
     want, _ = oracle.OracleScene(scenes.to_blob(scene)).render(depth)
     tracer = make_tracer(pkg, scenes, scene)
     assert tracer.kernels()["autotune"].startswith("measuring")
-    for k in range(80):
+    for k in range(100):
         got = tracer.render(max_depth=depth)
-        if k % 7 == 0 or k > 70:
+        if k % 7 == 0 or k > 90:
             assert_same_floats(got, want, "autotune frame %d (%s)" % (k, tracer.kernels()["autotune"]))
     assert tracer.kernels()["autotune"].startswith("settled"), tracer.kernels()["autotune"]
     assert tracer.stats().fallback_frames == 0
