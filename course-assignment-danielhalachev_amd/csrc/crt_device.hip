@@ -145,7 +145,7 @@ struct crt_ctx {
     uint32_t *d_ready = nullptr;      // kernel_deep.h: publication flags of the deep queue's slots
     uint32_t *d_ready2 = nullptr;     // ... and of the heavy queue's
     // queue sizing (ensure_stream): capacities as multiples of the frame's pixels, adapted from frame to frame
-    double node_mult = 1.25, ray_mult = 0.5, shadow_extra = 0.125;
+    double node_mult = 1.3, ray_mult = 0.5, shadow_extra = 0.125;
     uint32_t *h_counts = nullptr;     // pinned copy of the last frame's counter block (d_scounts)
     uint32_t sizing_seen_fallbacks = 0, last_items = 0;
     uint64_t queue_bytes = 0;         // bytes of the per-frame buffers as allocated now
@@ -1090,7 +1090,7 @@ static int ensure_frames(crt_ctx *ctx, uint32_t max_depth, bool gi) {
 // render_lanes, which needs no queues.
 // Queues of the ray-stream pass.  What a frame needs depends on the scene and the camera -- a frame of diffuse surfaces
 // has no child rays at all, nested glass can reach 2^(MAX_DEPTH+1)-1 rays per pixel -- so the capacities FOLLOW the frames:
-// they start at px * {1.25 ray-tree nodes, 0.5 rays per level, n_lights * 1.125 shadow rays} (px = 64 pixels per work item),
+// they start at px * {1.3 ray-tree nodes, 0.5 rays per level, n_lights * 1.125 shadow rays} (px = 64 pixels per work item),
 // grow by half when the previous frame used more than 70 % of one of them, and double (up to px * {4, 3, n_lights * 4})
 // after a frame that overflowed.  Such a frame is not lost: its queues raise the overflow word and render_lanes, which
 // needs no queues, redoes it in the same call (crt_stats::fallback_frames counts them).
