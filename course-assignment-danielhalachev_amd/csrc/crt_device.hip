@@ -1308,6 +1308,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
     if (count) CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_counters, 0, 3 * C_N * sizeof(unsigned long long), stream));
     if (n_items == 0) return CRT_OK;
     const int slot = (int)(ctx->launches % crt_ctx::EV_RING);
+    ctx->at.tag[slot] = -2;  // (crt_tuning::autotune: not a frame it may learn from, unless autotune_step below says otherwise)
     const uint32_t lane_need = (n_items * 64u + BLOCK - 1) / BLOCK;
     const uint32_t lane_blocks = lane_need < ctx->grid_blocks ? lane_need : ctx->grid_blocks;
     if (timed) CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0[slot], stream));

@@ -495,6 +495,12 @@ def test_autotune_tries_settings_on_the_frames_and_never_changes_one(pkg, scenes
             assert_same_floats(got, want, "autotune frame %d (%s)" % (k, tracer.kernels()["autotune"]))
     assert tracer.kernels()["autotune"].startswith("settled"), tracer.kernels()["autotune"]
     assert tracer.stats().fallback_frames == 0
+    settled = tracer.kernels()["autotune"]
+    # frames the tuner must not learn from (the counting build, a GI frame) leave it where it is
+    tracer.render(max_depth=depth, counters=True)
+    tracer.render(options=pkg.make_options(depth, use_gi=True, gi_sample_size=1, rays_per_pixel=1, gi_seed=1))
+    assert_same_floats(tracer.render(max_depth=depth), want, "after a counting and a GI frame")
+    assert tracer.kernels()["autotune"] == settled
     # another depth is another workload: the tuner starts over
     tracer.render(max_depth=depth - 1)
     assert tracer.kernels()["autotune"].startswith("measuring")
