@@ -88,7 +88,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=100)   # enough frames for crt_tuning::autotune to try its candidates and settle
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--settle", type=int, default=100,
+                    help="untimed frames rendered one at a time BEFORE the warm-up steps, on which the context's crt_tuning::autotune tries "
+                         "its candidate settings and settles (part of preparing the context, like building the tree; 0: none)")
     ap.add_argument("--scene", default=WORKLOAD)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
@@ -189,9 +192,15 @@ def main():
     frame_ok = bool(torch.equal(packed.view(torch.int32), counted_pixels.view(torch.int32)))
     del counted_pixels
 
+    # Preparing the context: crt_tuning::autotune times the context's own frames and tries three settings on
+    # them; like the tree build and the queue sizing this happens once per workload, before the steady state the bench measures.
+    # One frame at a time, so that the context sees each frame's duration before it launches the next.  (The same number of
+    # frames on every rank: the gather inside step() is a collective.)
+    for _ in range(max(0, args.settle)):
+        step()
+        tracer.synchronize()
     for _ in range(args.warmup):
         step()
-        tracer.synchronize()   # (untimed: one frame at a time, so that the context sees each frame's duration before it launches the next)
     fence()
     # queue capacities follow the frames: a context's FIRST frames may outgrow them and be redone by the
     # queue-less kernel.  Such a frame inside the timed region would not be a measurement of the path; before it, it is start-up.
@@ -366,6 +375,7 @@ def main():
                        "parallelism": "tiles8x8-roundrobin-%d" % world, "tuning": args.tuning or "defaults"},
             "frame_matches_counting_build": frame_ok,
             "autotune": tracer.kernels().get("autotune"),   # crt_tuning::autotune: what the context settled on while it rendered
+            "settle_frames": max(0, args.settle),           # untimed frames before the warm-up on which it did so
             "pipelined": pipelined,
             "value_incl_d2h": round(W * H / d2h_elapsed / 1e6, 3),
             "kernel_ms": {"first_to_last": round(avg_kernel_ms, 4), "recursion_levels": round(pk_ms, 4),

@@ -14,7 +14,7 @@ DOM = "stream_trace_shadow_plan<0"
 def run(args, name):
     d = os.path.join(out, name)
     cmd = ["rocprofv3"] + args + ["-d", d, "--output-format", "csv", "--", "python3", os.path.join(root, "bench.py"),
-                                  "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-alone", "--in-flight", "0"]
+                                  "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-alone", "--in-flight", "0", "--settle", "0"]
     with open(os.path.join(out, name + ".log"), "w") as log:
         rc = subprocess.run(cmd, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT, timeout=400).returncode
     print(name, "rc", rc, flush=True)
