@@ -25,6 +25,6 @@ for label, tuning in (('autotune', None), ('off', pkg.make_tuning(autotune=0))):
     buf = torch.zeros(tiles.tiles_per_rank(tr.width, tr.height, 1) * 192, dtype=torch.float32, device=dev)
     for _ in range(3): tr.render_tiles_device(opts, 0, 1, buf.data_ptr())
     out = []
-    for block in range(6):
+    for block in range(10):
         out.append('%.2f' % timed(tr, buf, 25))
     print(name, label, 'ms per frame in blocks of 25 frames:', ' '.join(out), '|', tr.kernels()['autotune'], flush=True)
