@@ -97,15 +97,14 @@ class Stats(C.Structure):
                                                    "shadow_rays")}
 
 
-MODE_STREAM, MODE_PACKETS, MODE_LANES = range(3)
+MODE_STREAM, MODE_LANES = range(2)
 
 
 class Tuning(C.Structure):
     """crt_tuning (include/crt_hip.h): kernel selection and sizing; no setting changes a pixel."""
     _fields_ = [(n, C.c_uint32) for n in (
-        "size", "mode", "step_budget", "shadow_budget", "pass1_budget", "heavy_level", "heavy_blocks", "side_blocks",
-        "quad", "quad_stack", "prune", "bundle", "fixed0", "packet_budget", "path_mask", "top_in_registers",
-        "tiny_meshes", "node_cap", "ray_cap", "shadow_cap", "deep", "deep_blocks", "plan", "deep_waves", "tri_gather", "deep_heavy_every", "level0_budget", "node_repeat", "heavy_waves", "level_shadows", "pool", "pool_refill", "pool_switch", "early_shadow", "deep_first", "level_grid", "skip_unlit", "autotune", "preplan", "pre_bundle", "pre_trips", "wave_priority", "side_priority")]
+        "size", "mode", "step_budget", "shadow_budget", "level0_budget", "heavy_level", "side_blocks", "quad",
+        "node_cap", "ray_cap", "shadow_cap", "autotune")]
 
 
 def make_tuning(**fields):
@@ -133,7 +132,7 @@ def tuning_from_string(text):
 DEVICE_SYMBOLS = ["crt_tuning_defaults", "crt_create_tuned", "crt_create", "crt_set_camera", "crt_render", "crt_render_tiles_device", "crt_packed_tile_count",
                   "crt_unpack_tiles_device", "crt_quantize_device", "crt_read_quantized", "crt_kernel_elapsed_ms", "crt_kernel_times_ms",
                   "crt_get_stats", "crt_get_kernel_counters", "crt_synchronize", "crt_destroy", "crt_last_error", "crt_device_count", "crt_test_pow5", "crt_test_gi",
-                  "crt_describe_kernels", "crt_debug_stream_counts", "crt_debug_packet_counters", "crt_get_executed_counters", "crt_get_executed_plan_tests",
+                  "crt_describe_kernels", "crt_debug_stream_counts", "crt_get_executed_counters", "crt_get_executed_plan_tests",
                   "crt_render_async", "crt_wait", "crt_alloc_pinned", "crt_free_pinned",
                   "crt_build_tree_device", "crt_built_tree_node_count", "crt_built_tree_index_total", "crt_built_tree_boxes",
                   "crt_built_tree_links", "crt_built_tree_indexes", "crt_built_tree_free", "crt_build_last_error",
@@ -414,7 +413,7 @@ class Tracer:
                 "plan_tests": int(b[0]), "shadow_pass0_plan_tests": int(b[1])}
 
     def kernel_counters(self):
-        """(packet-kernel counters, lane-kernel counters) of the last counted render, as dicts."""
+        """(recursion levels' counters, bulk shadow pass's counters) of the last counted render, as dicts."""
         names = ("box_tests", "tri_tests", "leaf_index_reads", "shaded_hits", "light_evals", "texel_fetches",
                  "primary_rays", "secondary_rays", "shadow_rays")
         a = (C.c_uint64 * 9)()
@@ -477,10 +476,10 @@ class Tracer:
 
     def stream_counts(self):
         """Diagnostics: the ray-stream pass's counter block of the last frame (SC_* layout of csrc/kernel_stream.h)."""
-        out = (C.c_uint32 * 1024)()
+        out = (C.c_uint32 * 512)()
         L = lib()
         L.crt_debug_stream_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]
-        self._check(L.crt_debug_stream_counts(self.ctx, out, 1024))
+        self._check(L.crt_debug_stream_counts(self.ctx, out, 512))
         return np.array(out[:], dtype=np.uint32)
 
     def read_quantized(self):

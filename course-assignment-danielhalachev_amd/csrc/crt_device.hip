@@ -16,9 +16,8 @@
 //  * the reference's stack DFS has a FIXED visit order and no distance pruning, so the trees are flattened into
 //    hit/miss links (crt_node) and walked without a stack; the quad and leaf-sequence forms rest on the boxes
 //    being nested, which crt_create verifies;
-//  * fallbacks, all bit-exact and all tested: render_lanes (kernel_lane.h: the full recursion per lane on an
-//    explicit frame stack; also redoes a frame whose queues overflowed) and render_packets (kernel_packet.h:
-//    one wave per 8x8 tile, scalar loads);
+//  * fallback, bit-exact and tested: render_lanes (kernel_lane.h: the full recursion per lane on an
+//    explicit frame stack; redoes a frame whose queues overflowed, and renders the GI mode);
 //  * arithmetic is IEEE binary32 with no contraction (-ffp-contract=off), correctly rounded divide and sqrt,
 //    std::min/std::max semantics written out, so results are bit-identical to the x86-64 reference build.
 //
@@ -46,13 +45,10 @@
 namespace {
 
 #include "kernel_common.h"
-#include "kernel_packet.h"
 #include "kernel_lane.h"
 #include "kernel_stream.h"
 #include "kernel_heavy.h"
 #include "kernel_plan.h"
-#include "kernel_deep.h"
-#include "kernel_pool.h"
 
 // scatter gathered packed tiles into the row-major frame
 __global__ void unpack_kernel(const float *packed, uint32_t n_parts, uint64_t part_stride, float *frame, uint32_t width,
@@ -105,8 +101,9 @@ struct crt_ctx {
     int device = 0;
     std::string error;
     hipStream_t stream = nullptr;
-    static constexpr int EV_RING = 64;       // event pairs of the most recent render launches
-    hipEvent_t ev0[EV_RING] = {}, ev1[EV_RING] = {}, ev2[EV_RING] = {}, ev3[EV_RING] = {};  // phase boundaries of a render
+    static constexpr int EV_RING = 64;       // event sets of the most recent render launches
+    hipEvent_t ev0[EV_RING] = {}, ev1[EV_RING] = {}, ev2[EV_RING] = {}, ev3[EV_RING] = {}, ev4[EV_RING] = {};  // phase boundaries of a render
+    hipEvent_t ev_fork[EV_RING] = {}, ev_s0[EV_RING] = {}, ev_s1[EV_RING] = {}, ev_s2[EV_RING] = {};        // ... of its side stream
     uint64_t launches = 0;
     uint32_t width = 0, height = 0, tiles_x = 0, tiles_y = 0;
     KernelArgs args{};
@@ -119,38 +116,36 @@ struct crt_ctx {
     bool cached_is_partition = false;     // ... or crt_render_tiles_device's {first, stride} (held in cached_rects[0].row / .col)
     uint32_t cached_n_items = 0;
     uint64_t cached_pixels = 0;
-    uint32_t *d_sync = nullptr;      // [0] lane-kernel pixel counter, [1] packet-kernel tile counter, [2] deferred count
-    uint32_t *d_deferred = nullptr;  // items_cap * 64 entries
-    uint64_t packet_counters[C_N] = {}, lane_counters[C_N] = {};  // of the last counted render, per kernel
-    // CRT_MODE selects the kernels (all three produce identical pixels): "stream" (default) = kernel_stream.h,
-    // "packets" = render_packets + render_lanes for the deferred pixels, "lanes" = render_lanes for everything.
-    enum Mode { MODE_STREAM, MODE_PACKETS, MODE_LANES } mode = MODE_STREAM;
+    uint32_t *d_sync = nullptr;      // [0] render_lanes' pixel counter
+    uint64_t level_counters[C_N] = {}, shadow0_counters[C_N] = {};  // of the last counted render: recursion levels, bulk shadow pass
+    enum Mode { MODE_STREAM, MODE_LANES } mode = MODE_STREAM;  // crt_tuning::mode (both produce identical pixels)
     float4 *d_rayq[2] = {nullptr, nullptr};
     float4 *d_shadowq = nullptr;
-    uint2 *d_shadow_plan = nullptr;   // crt_tuning::preplan: the bulk shadow pass's plans, one per shadow slot
     uint8_t *d_occluded = nullptr;
     float4 *d_nodes = nullptr;
     uint32_t *d_scounts = nullptr;
     unsigned long long *d_exec = nullptr;           // executed-test tallies of a collect_counters == 2 render
     unsigned long long exec_counters[6] = {0, 0, 0, 0, 0, 0};  // {box, tri} x {all but shadow pass 0, shadow pass 0}, plan tests x the same
-    uint32_t *h_overflow = nullptr;   // pinned copy of d_fallback_total, refreshed after every frame
     uint32_t *d_fallback_total = nullptr;  // frames redone by the queue-less kernel since crt_create
     uint32_t *d_heavy = nullptr;      // evicted ray ids
     uint32_t *d_sheavy = nullptr;     // evicted shadow ray ids
-    uint32_t *d_todo_tiles = nullptr, *d_todo_shadow = nullptr;  // what stream_packets_gen0 gave up on
-    uint32_t packet_budget = 0;       // CRT_PACKET_BUDGET: level 0 by packets, a walk abandoned after this many wave-level visits (0 = off, default: measured slower overall)
-    hipStream_t side = nullptr;       // shadow pass 0 overlaps the deeper recursion levels on this stream
-    hipEvent_t ev_fork[EV_RING] = {}, ev_s0[EV_RING] = {}, ev_s1[EV_RING] = {}, ev_s2[EV_RING] = {}, ev4[EV_RING] = {};
     float4 *d_hits = nullptr;         // their closest hits
-    uint32_t *d_ready = nullptr;      // kernel_deep.h: publication flags of the deep queue's slots
-    uint32_t *d_ready2 = nullptr;     // ... and of the heavy queue's
+    hipStream_t side = nullptr;       // shadow pass 0 overlaps the deeper recursion levels on this stream
+    // What a finished frame tells the next ones (queue sizing, launch sizes, fallback count): every frame copies its counter
+    // block and the fallback total to ITS slot of this pinned ring, and the host reads a slot only once that frame's last
+    // event has completed (harvest_counts), so launch decisions are a function of a completed frame, never of a copy in flight.
+    static constexpr uint32_t H_SLOT_WORDS = 512 + 1;   // SC_ALLOC_WORDS + the fallback total
+    uint32_t *h_ring = nullptr;       // EV_RING x H_SLOT_WORDS, pinned
+    uint64_t next_count_harvest = 0;  // the oldest launch whose slot has not been read
+    uint32_t slot_items[EV_RING] = {};               // work items of the frame in each slot
+    std::vector<uint32_t> last_counts;               // the most recent COMPLETED frame's counter block (SC_* layout) ...
+    uint32_t last_counts_items = 0;                  // ... and the work items it rendered (0: none yet)
+    uint32_t fallbacks_seen = 0;                     // fallback total of that frame
     // queue sizing (ensure_stream): capacities as multiples of the frame's pixels, adapted from frame to frame
     double node_mult = 1.3, ray_mult = 0.5, shadow_extra = 0.125;
-    uint32_t *h_counts = nullptr;     // pinned copy of the last frame's counter block (d_scounts)
-    uint32_t sizing_seen_fallbacks = 0, last_items = 0;
+    uint32_t sizing_seen_fallbacks = 0;
     uint64_t queue_bytes = 0;         // bytes of the per-frame buffers as allocated now
-    hipEvent_t ev_level[MAX_GENERATIONS] = {};  // level g is done (its shadow rays may start on the side stream)
-    // crt_tuning::autotune (see autotune_step): two budgets whose best value depends on the scene are tried on the frames
+    // crt_tuning::autotune (see autotune_step): settings whose best value depends on the scene are tried on the frames
     // themselves and the faster setting kept.  No setting changes a pixel.
     struct AutoTune {
         uint32_t b0 = 0, hl = 0, sb = 0;    // the settings in force: level-0 step budget, heavy_level threshold, workgroups of the bulk shadow pass per CU (0 = the defaults)
@@ -163,27 +158,13 @@ struct crt_ctx {
         int tag[EV_RING] = {};              // the stage each slot's frame was launched in (-2: not a frame of this workload)
         uint32_t items = 0, depth = 0;      // the workload being tuned (a change starts over)
     } at;
-    hipStream_t side2 = nullptr;      // crt_tuning::level_shadows >= 2: the first deeper levels' shadow rays, beside the bulk pass
-    hipEvent_t ev_side2 = nullptr;
     hipEvent_t ev_call0 = nullptr, ev_call1 = nullptr;  // around the last crt_render / crt_render_async call's device work
     bool pending = false;             // a frame enqueued by crt_render_async has not been waited for
     crt_options pending_options{};
-    uint32_t epoch = 0;               // frames launched (the deep queue's tag)
     uint32_t heavy_cap = 0;
-    uint32_t step_budget = 256;       // CRT_STEP_BUDGET: closest-hit walks are evicted to heavy_trace after this many steps (0 = never)
-    uint32_t shadow_budget = 4096;    // CRT_SHADOW_BUDGET: same for shadow walks (one big launch: only its tail matters)
-    uint32_t heavy_level_threshold = 100000;  // CRT_HEAVY_LEVEL: levels with fewer rays go to heavy_trace whole
+    uint32_t step_budget = 256;       // crt_tuning::step_budget (0 = never evict: also set when a mesh has too many leaves for the wave-per-ray walk)
     bool lean_ok = true;              // 32-bit byte offsets reach every node and leaf entry
-    uint32_t use_quads = 1;           // CRT_QUAD: which lean kernels walk quad nodes (bit 0 levels, 1 shadow pass 0, 2 shadow pass 1)
-    uint32_t quad_stack_depth = 16;   // CRT_QUAD_STACK
-    uint32_t fixed0 = 1;              // CRT_FIXED0
-    uint32_t bundle = 16;             // CRT_BUNDLE (shadow pass 0)
-    uint32_t pass1_budget = 0;        // CRT_PASS1_BUDGET: cap of the budget of the second shadow pass (0: the step budget)
-    uint32_t heavy_blocks = 4096;     // CRT_HEAVY_BLOCKS: grid of the wave-per-ray kernels (more blocks than fit: late ones balance the load)
-    uint32_t prune = 0;               // CRT_PRUNE: distance pruning of closest-hit walks (kernel_common.h); bit 0 quad walk, bit 1 heavy_trace
-    uint32_t n_quads = 0;
-    uint32_t side_blocks_per_cu = 3;  // crt_tuning::side_blocks: blocks per CU of the overlapped shadow pass
-    uint32_t debug_skip = 0;          // CRT_DEBUG_SKIP: path selection for tests (256: no lean kernels, 512: no packets)
+    bool quads_ok = true;             // the quad collapse succeeded
     uint64_t stream_items = 0;        // work items the stream buffers are sized for
     uint64_t overflows = 0;           // frames redone by the fallback (diagnostic)
     uint32_t n_lights = 0;
@@ -195,6 +176,11 @@ struct crt_ctx {
     crt_stats stats{};
     int num_cus = 0;
 };
+
+// constants that round 2 carried as crt_tuning fields (DESIGN.md section 7 has the measurements)
+static constexpr uint32_t HEAVY_BLOCKS = 4096;   // grid of the wave-per-ray kernels (more blocks than fit: late ones balance the load)
+static constexpr uint32_t QUAD_STACK_DEPTH = 16; // LDS words per lane of the quad walk's stack
+static constexpr uint32_t REFILL_BUNDLE = 16;    // the plan kernels refill a wave when at most this many lanes still walk
 
 static std::string g_create_error;
 
@@ -377,95 +363,16 @@ static int validate_scene(const crt_scene_desc *s, std::string &err) {
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// Loose boxes for distance pruning of closest-hit walks (kernel_walk.h: "pruning").
-// box(T) encloses every point p = o + d*t that Ray::intersectWithTriangle can ACCEPT for triangle T:
-// the inside test (Triangle.cpp:37-57) accepts p when, for each edge k, n . (e_k x (p - v_k)) >= -FLT_EPSILON,
-// i.e. when p's projection on the plane is at most FLT_EPSILON/|e_k| outside edge k; and p itself is within
-// rounding of the plane.  So box(T) = bounding box of the triangle whose edges are moved outwards by
-// d_k = 2*FLT_EPSILON/|e_k| + 1e-5*S (S = largest coordinate magnitude of the scene: the rounding of the test
-// itself is ~1e-6*S), grown by another 1e-5*S for the distance to the plane.  A triangle for which that
-// construction is ill-conditioned (zero edge, non-finite normal, edges almost parallel) gets the infinite box:
-// it is never pruned.
-static void triangle_loose_box(const crt_triangle &T, double S, float lo[3], float hi[3]) {
-    const double v[3][3] = {{T.v0[0], T.v0[1], T.v0[2]}, {T.v1[0], T.v1[1], T.v1[2]}, {T.v2[0], T.v2[1], T.v2[2]}};
-    const double n[3] = {T.nx, T.ny, T.nz};
-    auto infinite = [&]() { for (int a = 0; a < 3; a++) { lo[a] = -INFINITY; hi[a] = INFINITY; } };
-    const double nl = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-    if (!(nl > 0.99 && nl < 1.01)) return infinite();
-    // the stored plane offset must be the triangle's own (Ray.cpp:17: D = -(v0 . n)), or p is not near the triangle
-    if (!(std::fabs((double)T.plane + (v[0][0] * n[0] + v[0][1] * n[1] + v[0][2] * n[2])) <= 1e-5 * (1.0 + S))) return infinite();
-    double e[3][3], el[3], m[3][3], c[3];  // edges, their lengths, inward in-plane normals, offsets: m_k . x >= c_k
-    for (int k = 0; k < 3; k++) {
-        const double *a = v[k], *b = v[(k + 1) % 3];
-        for (int i = 0; i < 3; i++) e[k][i] = b[i] - a[i];
-        el[k] = std::sqrt(e[k][0] * e[k][0] + e[k][1] * e[k][1] + e[k][2] * e[k][2]);
-        if (!(el[k] > 0.0) || !std::isfinite(el[k])) return infinite();
-        if (!(std::fabs(n[0] * e[k][0] + n[1] * e[k][1] + n[2] * e[k][2]) <= 1e-4 * el[k])) return infinite();  // n must be the edges' normal
-        // n x e_k, normalised
-        m[k][0] = (n[1] * e[k][2] - n[2] * e[k][1]) / (nl * el[k]);
-        m[k][1] = (n[2] * e[k][0] - n[0] * e[k][2]) / (nl * el[k]);
-        m[k][2] = (n[0] * e[k][1] - n[1] * e[k][0]) / (nl * el[k]);
-        const double d = 2.0 * (double)FLT_EPSILON / el[k] + 1e-5 * S;
-        c[k] = m[k][0] * a[0] + m[k][1] * a[1] + m[k][2] * a[2] - d;
-    }
-    double blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int k = 0; k < 3; k++) {
-        // corner k: where the moved edges k-1 and k meet.  x = v_k + s*e_{k-1}^ + u*e_k^ in the plane; solve the two
-        // line equations m_j . x = c_j (j = k-1, k) for (s, u).
-        const int j = (k + 2) % 3;
-        double ej[3], ek[3];
-        for (int i = 0; i < 3; i++) { ej[i] = e[j][i] / el[j]; ek[i] = e[k][i] / el[k]; }
-        auto dot = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
-        // m_j . ej = 0 and m_k . ek = 0 (in-plane normals of their own edges):
-        //   m_j . x = m_j . v_k + u * (m_j . ek) = c_j      m_k . x = m_k . v_k + s * (m_k . ej) = c_k
-        const double ajk = dot(m[j], ek), akj = dot(m[k], ej);
-        if (!(std::fabs(ajk) > 1e-6) || !(std::fabs(akj) > 1e-6)) return infinite();  // a sliver: corners run away
-        const double u = (c[j] - dot(m[j], v[k])) / ajk, sdist = (c[k] - dot(m[k], v[k])) / akj;
-        for (int i = 0; i < 3; i++) {
-            const double x = v[k][i] + sdist * ej[i] + u * ek[i];
-            if (!std::isfinite(x)) return infinite();
-            blo[i] = std::min(blo[i], std::min(x, v[k][i]));
-            bhi[i] = std::max(bhi[i], std::max(x, v[k][i]));
-        }
-    }
-    const double grow = 2e-5 * S + 1e-30;
-    for (int i = 0; i < 3; i++) {
-        lo[i] = std::nextafterf((float)(blo[i] - grow), -INFINITY);
-        hi[i] = std::nextafterf((float)(bhi[i] + grow), INFINITY);
-    }
-}
-
 extern "C" void crt_tuning_defaults(crt_tuning *t) {
     if (!t) return;
     memset(t, 0, sizeof(*t));
     t->size = (uint32_t)sizeof(*t);
     t->mode = CRT_MODE_STREAM;
-    t->step_budget = 256; t->shadow_budget = 4096; t->pass1_budget = 0;
-    t->heavy_level = 100000; t->heavy_blocks = 4096; t->side_blocks = 3;
-    t->quad = 1; t->quad_stack = 16; t->prune = 0; t->bundle = 16; t->fixed0 = 1;
-    t->packet_budget = 0; t->path_mask = 0; t->top_in_registers = 1; t->tiny_meshes = 1;
+    t->step_budget = 256; t->shadow_budget = 4096; t->level0_budget = 0;
+    t->heavy_level = 100000; t->side_blocks = 3;
+    t->quad = 1;
     t->node_cap = t->ray_cap = t->shadow_cap = 0;
-    t->deep = 0; t->deep_blocks = 0;
-    t->plan = 1;
-    t->deep_waves = 5;
-    t->tri_gather = 0;
-    t->deep_heavy_every = 4;
-    t->level0_budget = 0;
-    t->node_repeat = 2;
-    t->heavy_waves = 5;
-    t->level_shadows = 0;
-    t->pool = 0; t->pool_refill = 48; t->pool_switch = 24;
-    t->early_shadow = 0;
-    t->deep_first = 1;
-    t->level_grid = 1;
-    t->skip_unlit = 1;
     t->autotune = 1;
-    t->preplan = 0;
-    t->pre_bundle = 48;
-    t->pre_trips = 16;
-    t->wave_priority = 3;
-    t->side_priority = 1;
 }
 
 extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) { return crt_create_tuned(s, device, nullptr, out); }
@@ -516,12 +423,10 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
     CK(hipGetDeviceProperties(&prop, device));
     ctx->num_cus = prop.multiProcessorCount;
     CK(hipStreamCreate(&ctx->stream));
-    if (tune.side_priority) {
+    {   // the side stream (bulk shadow pass) at the lowest stream priority: nothing waits for it until the levels are done
         int least = 0, greatest = 0;
         CK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         CK(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, least));
-    } else {
-        CK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
     }
     for (int i = 0; i < crt_ctx::EV_RING; i++) {
         CK(hipEventCreate(&ctx->ev0[i]));
@@ -606,67 +511,30 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
         if (upload(ctx, pn.data(), pn.size(), &A.pnodes)) return fail(CRT_ERR_HIP);
     }
     std::vector<HeavyMesh> hmesh_host;  // filled with the leaf sequences below, read again for the single-leaf mesh table
-    // loose boxes (see triangle_loose_box) of every mesh-tree node: a leaf's = union over its triangles, an inner
-    // node's = union over its children; nodes of one tree are in visit order, children after their parent
-    std::vector<float> nloose_lo((size_t)s->n_nodes * 3, INFINITY), nloose_hi((size_t)s->n_nodes * 3, -INFINITY);
     {
-        double S = 0.0;
-        for (uint64_t t = 0; t < s->n_triangles; t++) {
-            const crt_triangle &T = s->triangles[t];
-            for (int a = 0; a < 3; a++) {
-                const double m = std::max(std::fabs((double)T.v0[a]), std::max(std::fabs((double)T.v1[a]), std::fabs((double)T.v2[a])));
-                if (std::isfinite(m)) S = std::max(S, m);
-            }
-        }
-        A.scene_scale = (float)S;
-        std::vector<float> tlo((size_t)s->n_triangles * 3), thi((size_t)s->n_triangles * 3);
-        for (uint64_t t = 0; t < s->n_triangles; t++) triangle_loose_box(s->triangles[t], S, &tlo[3 * t], &thi[3 * t]);
-        std::vector<bool> is_top(s->n_nodes, false);  // top-level nodes hold meshes, not triangles: left empty
-        {
-            std::vector<uint32_t> stack{s->top_root};
-            while (!stack.empty()) {
-                const uint32_t i = stack.back();
-                stack.pop_back();
-                if (i >= s->n_nodes || is_top[i]) continue;
-                is_top[i] = true;
-                const crt_node &n = s->nodes[i];
-                if (is_leaf_link(n.link) || n.link == CRT_LINK_END) continue;
-                stack.push_back(n.link);
-                const uint32_t c2 = s->nodes[n.link].miss;
-                if (c2 != n.miss && c2 != CRT_LINK_END) stack.push_back(c2);
-            }
-        }
-        {
-            uint32_t lo = UINT32_MAX, hi = 0, cnt = 0;
-            for (uint32_t i = 0; i < s->n_nodes; i++)
-                if (is_top[i]) { lo = i < lo ? i : lo; hi = i > hi ? i : hi; cnt++; }
-            A.top_fast = (tune.top_in_registers && cnt > 0 && hi - lo + 1 == cnt && cnt <= 64u && s->n_leaf_meshes <= 128u && s->n_meshes <= 64u) ? 1u : 0u;
-            A.top_lds = (tune.top_in_registers && cnt > 0 && hi - lo + 1 == cnt && cnt <= 256u && s->n_leaf_meshes <= 1024u && s->n_meshes <= 256u) ? 1u : 0u;
-            A.top_first = cnt ? lo : 0u;
-            A.top_count = cnt;
-            A.top_leaf_entries = s->n_leaf_meshes;
-            A.top_meshes = s->n_meshes;
-        }
-        for (uint32_t i = s->n_nodes; i-- > 0;) {
-            if (is_top[i]) continue;
+        // the top-level tree's nodes: reachable from top_root (links point forward, so the walk is finite)
+        std::vector<bool> is_top(s->n_nodes, false);
+        std::vector<uint32_t> stack{s->top_root};
+        while (!stack.empty()) {
+            const uint32_t i = stack.back();
+            stack.pop_back();
+            if (i >= s->n_nodes || is_top[i]) continue;
+            is_top[i] = true;
             const crt_node &n = s->nodes[i];
-            float *lo = &nloose_lo[(size_t)i * 3], *hi = &nloose_hi[(size_t)i * 3];
-            auto join = [&](const float *l, const float *h) {
-                for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], l[a]); hi[a] = std::max(hi[a], h[a]); }
-            };
-            if (is_leaf_link(n.link)) {
-                uint64_t e = n.link & ~CRT_LINK_LEAF;
-                while (e < s->n_leaf_triangles) {
-                    const uint32_t ent = s->leaf_triangles[e++], tri = ent & ~CRT_ENTRY_LAST;
-                    join(&tlo[(size_t)tri * 3], &thi[(size_t)tri * 3]);
-                    if (ent & CRT_ENTRY_LAST) break;
-                }
-            } else if (n.link != CRT_LINK_END) {
-                const uint32_t c1 = n.link, c2 = s->nodes[c1].miss;
-                join(&nloose_lo[(size_t)c1 * 3], &nloose_hi[(size_t)c1 * 3]);
-                if (c2 != n.miss && c2 != CRT_LINK_END) join(&nloose_lo[(size_t)c2 * 3], &nloose_hi[(size_t)c2 * 3]);
-            }
+            if (is_leaf_link(n.link) || n.link == CRT_LINK_END) continue;
+            stack.push_back(n.link);
+            const uint32_t c2 = s->nodes[n.link].miss;
+            if (c2 != n.miss && c2 != CRT_LINK_END) stack.push_back(c2);
         }
+        uint32_t lo = UINT32_MAX, hi = 0, cnt = 0;
+        for (uint32_t i = 0; i < s->n_nodes; i++)
+            if (is_top[i]) { lo = i < lo ? i : lo; hi = i > hi ? i : hi; cnt++; }
+        A.top_fast = (cnt > 0 && hi - lo + 1 == cnt && cnt <= 64u && s->n_leaf_meshes <= 128u && s->n_meshes <= 64u) ? 1u : 0u;
+        A.top_lds = (cnt > 0 && hi - lo + 1 == cnt && cnt <= 256u && s->n_leaf_meshes <= 1024u && s->n_meshes <= 256u) ? 1u : 0u;
+        A.top_first = cnt ? lo : 0u;
+        A.top_count = cnt;
+        A.top_leaf_entries = s->n_leaf_meshes;
+        A.top_meshes = s->n_meshes;
     }
     {
         // Leaf sequence of every mesh tree (kernel_heavy.h): the leaves' own boxes in visit order, then union
@@ -676,7 +544,7 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
         roots.push_back(s->top_root);
         for (uint32_t m = 0; m < s->n_meshes; m++) roots.push_back(s->meshes[m].root);
         std::sort(roots.begin(), roots.end());
-        std::vector<float4> hbox, hloose;  // hloose: the entries' loose boxes, same indexing
+        std::vector<float4> hbox;
         std::vector<HeavyMesh> &hm = hmesh_host;
         hm.assign(s->n_meshes, HeavyMesh{});
         for (uint32_t m = 0; m < s->n_meshes; m++) {
@@ -685,7 +553,7 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
             const uint32_t root = s->meshes[m].root;
             auto it = std::upper_bound(roots.begin(), roots.end(), root);
             const uint32_t end = it == roots.end() ? s->n_nodes : *it;
-            std::vector<float4> level, loose;  // 2 x float4 per entry
+            std::vector<float4> level;  // 2 x float4 per entry
             for (uint32_t i = root; i < end; i++) {
                 const crt_node &n = s->nodes[i];
                 if (!is_leaf_link(n.link)) continue;
@@ -700,8 +568,6 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
                 memcpy(&cb, &count, 4);
                 level.push_back(make_float4(n.lo[0], n.lo[1], n.lo[2], bb));
                 level.push_back(make_float4(n.hi[0], n.hi[1], n.hi[2], cb));
-                loose.push_back(make_float4(nloose_lo[(size_t)i * 3], nloose_lo[(size_t)i * 3 + 1], nloose_lo[(size_t)i * 3 + 2], 0.0f));
-                loose.push_back(make_float4(nloose_hi[(size_t)i * 3], nloose_hi[(size_t)i * 3 + 1], nloose_hi[(size_t)i * 3 + 2], 0.0f));
             }
             uint32_t nl = 0;
             while (!level.empty() && nl < 4) {
@@ -709,35 +575,26 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
                 H.first[nl] = (uint32_t)(hbox.size() / 2);
                 H.count[nl] = cnt;
                 hbox.insert(hbox.end(), level.begin(), level.end());
-                hloose.insert(hloose.end(), loose.begin(), loose.end());
                 nl++;
                 if (cnt <= 64) break;
-                std::vector<float4> up, up_loose;
+                std::vector<float4> up;
                 for (uint32_t g = 0; g < cnt; g += 64) {
                     float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-                    float llo[3] = {INFINITY, INFINITY, INFINITY}, lhi[3] = {-INFINITY, -INFINITY, -INFINITY};
                     for (uint32_t k = g; k < cnt && k < g + 64; k++) {
                         const float4 &a = level[2 * k], &b = level[2 * k + 1];
                         lo[0] = a.x < lo[0] ? a.x : lo[0]; lo[1] = a.y < lo[1] ? a.y : lo[1]; lo[2] = a.z < lo[2] ? a.z : lo[2];
                         hi[0] = b.x > hi[0] ? b.x : hi[0]; hi[1] = b.y > hi[1] ? b.y : hi[1]; hi[2] = b.z > hi[2] ? b.z : hi[2];
-                        const float4 &la = loose[2 * k], &lb = loose[2 * k + 1];
-                        llo[0] = std::min(llo[0], la.x); llo[1] = std::min(llo[1], la.y); llo[2] = std::min(llo[2], la.z);
-                        lhi[0] = std::max(lhi[0], lb.x); lhi[1] = std::max(lhi[1], lb.y); lhi[2] = std::max(lhi[2], lb.z);
                     }
                     up.push_back(make_float4(lo[0], lo[1], lo[2], 0.0f));
                     up.push_back(make_float4(hi[0], hi[1], hi[2], 0.0f));
-                    up_loose.push_back(make_float4(llo[0], llo[1], llo[2], 0.0f));
-                    up_loose.push_back(make_float4(lhi[0], lhi[1], lhi[2], 0.0f));
                 }
                 level.swap(up);
-                loose.swap(up_loose);
             }
             // more than 64^4 leaves: leave n_levels = 0 for this mesh -> the heavy path is switched off below
             H.n_levels = (!level.empty() && H.count[nl ? nl - 1 : 0] <= 64) ? nl : 0;
             if (H.n_levels == 0 && !level.empty()) ctx->step_budget = 0;
         }
         if (upload(ctx, hbox.data(), hbox.size(), &A.hbox)) return fail(CRT_ERR_HIP);
-        if (upload(ctx, hloose.data(), hloose.size(), &A.hloose)) return fail(CRT_ERR_HIP);
         if (upload(ctx, hm.data(), hm.size(), &A.hmesh)) return fail(CRT_ERR_HIP);
     }
     {
@@ -749,7 +606,6 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
         struct Builder {
             const crt_scene_desc *s;
             std::vector<float4> &quads;
-            const std::vector<float> &loose_lo, &loose_hi;
             const std::vector<uint32_t> &compact_link;
             void children(uint32_t i, std::vector<uint32_t> &out) const {
                 const crt_node &n = s->nodes[i];
@@ -782,17 +638,14 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
                     slots.erase(slots.begin() + pick);
                     slots.insert(slots.begin() + pick, kids.begin(), kids.end());
                 }
-                const uint32_t q = (uint32_t)(quads.size() / 16);
-                quads.resize(quads.size() + 16, make_float4(0, 0, 0, 0));
-                float box[6][4], lbox[6][4];
+                const uint32_t q = (uint32_t)(quads.size() / 8);
+                quads.resize(quads.size() + 8, make_float4(0, 0, 0, 0));
+                float box[6][4];
                 uint32_t link[4] = {NONE, NONE, NONE, NONE}, clink[4] = {NONE, NONE, NONE, NONE};
-                for (int k = 0; k < 4; k++) for (int a = 0; a < 6; a++) { box[a][k] = 0.0f; lbox[a][k] = 0.0f; }
+                for (int k = 0; k < 4; k++) for (int a = 0; a < 6; a++) box[a][k] = 0.0f;
                 for (size_t k = 0; k < slots.size(); k++) {
                     const crt_node &n = s->nodes[slots[k]];
-                    for (int a = 0; a < 3; a++) {
-                        box[a][k] = n.lo[a]; box[3 + a][k] = n.hi[a];
-                        lbox[a][k] = loose_lo[(size_t)slots[k] * 3 + a]; lbox[3 + a][k] = loose_hi[(size_t)slots[k] * 3 + a];
-                    }
+                    for (int a = 0; a < 3; a++) { box[a][k] = n.lo[a]; box[3 + a][k] = n.hi[a]; }
                     if (is_leaf_link(n.link)) {
                         link[k] = n.link;  // LEAF + first entry
                         clink[k] = compact_link[slots[k]];  // ... and with the leaf's length (plan kernels)
@@ -803,19 +656,17 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
                         clink[k] = link[k];
                     }
                 }
-                for (int a = 0; a < 6; a++) quads[(size_t)q * 16 + a] = make_float4(box[a][0], box[a][1], box[a][2], box[a][3]);
-                for (int a = 0; a < 6; a++) quads[(size_t)q * 16 + 8 + a] = make_float4(lbox[a][0], lbox[a][1], lbox[a][2], lbox[a][3]);
+                for (int a = 0; a < 6; a++) quads[(size_t)q * 8 + a] = make_float4(box[a][0], box[a][1], box[a][2], box[a][3]);
                 float lb[4];
                 memcpy(lb, link, 16);
-                quads[(size_t)q * 16 + 6] = make_float4(lb[0], lb[1], lb[2], lb[3]);
+                quads[(size_t)q * 8 + 6] = make_float4(lb[0], lb[1], lb[2], lb[3]);
                 memcpy(lb, clink, 16);
-                quads[(size_t)q * 16 + 7] = make_float4(lb[0], lb[1], lb[2], lb[3]);
+                quads[(size_t)q * 8 + 7] = make_float4(lb[0], lb[1], lb[2], lb[3]);
                 return q;
             }
-        } builder{s, quads, nloose_lo, nloose_hi, compact_link};
+        } builder{s, quads, compact_link};
         for (uint32_t m = 0; m < s->n_meshes; m++) qroots[m] = builder.build(std::vector<uint32_t>{s->meshes[m].root});
-        ctx->n_quads = (uint32_t)(quads.size() / 16);
-        if (builder.too_deep || quads.size() / 16 >= (1u << 24)) ctx->use_quads = 0;
+        if (builder.too_deep || quads.size() / 8 >= (1u << 24)) ctx->quads_ok = false;
         if (upload(ctx, quads.data(), quads.size(), &A.quads)) return fail(CRT_ERR_HIP);
         if (upload(ctx, qroots.data(), qroots.size(), &A.quad_roots)) return fail(CRT_ERR_HIP);
     }
@@ -829,12 +680,11 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
         std::vector<crt_mesh> dm(s->meshes, s->meshes + s->n_meshes);
         std::vector<uint32_t> tiny_at, tiny_flags;
         uint64_t tiny_tris = 0;
-        const bool use_tiny = tune.tiny_meshes != 0;
         for (uint32_t m = 0; m < s->n_meshes; m++) {
             dm[m].pad = 0;
             const crt_node &root = s->nodes[s->meshes[m].root];
             const HeavyMesh &H = hmesh_host[m];
-            if (!use_tiny || !is_leaf_link(root.link) || H.n_levels != 1 || H.count[0] != 1 || tiny_at.size() >= 64) continue;
+            if (!is_leaf_link(root.link) || H.n_levels != 1 || H.count[0] != 1 || tiny_at.size() >= 64) continue;
             uint32_t cnt = 0;
             for (uint64_t e = root.link & ~CRT_LINK_LEAF; e < s->n_leaf_triangles; e++) { cnt++; if (s->leaf_triangles[e] & CRT_ENTRY_LAST) break; }
             if (tiny_tris + cnt > 512) continue;
@@ -932,12 +782,11 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
             masks.push_back(make_uint2(mlo, mhi));
         }
         if (masks.size() > 64) ok = false;
-        A.plan_ok = (ok && tune.plan && A.plan_compact) ? 1u : 0u;
+        A.plan_ok = (ok && A.plan_compact) ? 1u : 0u;
         A.plan_leaves = (uint32_t)masks.size();
         A.plan_shadow_bits = (uint32_t)order.size();
         A.plan_list_words = (s->n_meshes + 3u) / 4u;
         if (upload(ctx, boxes.data(), boxes.size(), &A.plan_boxes)) return fail(CRT_ERR_HIP);
-        if (upload(ctx, masks.data(), masks.size(), &A.plan_shadow_masks)) return fail(CRT_ERR_HIP);
         if (upload(ctx, order.data(), order.size(), &A.plan_shadow_mesh)) return fail(CRT_ERR_HIP);
     }
     A.bgx = s->background[0]; A.bgy = s->background[1]; A.bgz = s->background[2];
@@ -952,29 +801,17 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
     CK(hipMalloc((void **)&ctx->d_quant, (size_t)s->width * s->height * 3));
     CK(hipMalloc((void **)&ctx->d_sync, 4 * sizeof(uint32_t)));
     ctx->tuning = tune;
-    ctx->mode = tune.mode == CRT_MODE_PACKETS ? crt_ctx::MODE_PACKETS : (tune.mode == CRT_MODE_LANES ? crt_ctx::MODE_LANES : crt_ctx::MODE_STREAM);
-    ctx->debug_skip = tune.path_mask;
+    ctx->mode = tune.mode == CRT_MODE_LANES ? crt_ctx::MODE_LANES : crt_ctx::MODE_STREAM;
     if (ctx->step_budget) ctx->step_budget = tune.step_budget;  // (0: a mesh with too many leaves switched the wave-per-ray path off)
-    ctx->packet_budget = tune.packet_budget;
-    ctx->heavy_level_threshold = tune.heavy_level;
     ctx->lean_ok = s->n_nodes < (1u << 27) && s->n_leaf_triangles < (1ull << 26);
-    if (ctx->use_quads) ctx->use_quads = tune.quad & 7u;
-    ctx->bundle = tune.bundle;
-    ctx->fixed0 = tune.fixed0;
-    ctx->pass1_budget = tune.pass1_budget;
-    if (tune.heavy_blocks) ctx->heavy_blocks = tune.heavy_blocks;
-    ctx->prune = tune.prune & 3u;
-    ctx->quad_stack_depth = tune.quad_stack < 4 ? 4 : (tune.quad_stack > 60 ? 60 : tune.quad_stack);  // 60 KB of the workgroup's 64 KB
-    ctx->side_blocks_per_cu = tune.side_blocks;
-    ctx->shadow_budget = tune.shadow_budget;
     CK(hipMalloc((void **)&ctx->d_exec, 6 * sizeof(unsigned long long)));
     CK(hipMemset(ctx->d_exec, 0, 6 * sizeof(unsigned long long)));
     CK(hipMalloc((void **)&ctx->d_scounts, SC_ALLOC_WORDS * sizeof(uint32_t)));
     CK(hipMemset(ctx->d_scounts, 0, SC_ALLOC_WORDS * sizeof(uint32_t)));
-    CK(hipHostMalloc((void **)&ctx->h_overflow, sizeof(uint32_t)));
-    *ctx->h_overflow = 0;
-    CK(hipHostMalloc((void **)&ctx->h_counts, SC_ALLOC_WORDS * sizeof(uint32_t)));
-    memset(ctx->h_counts, 0, SC_ALLOC_WORDS * sizeof(uint32_t));
+    static_assert(crt_ctx::H_SLOT_WORDS == SC_ALLOC_WORDS + 1, "pinned slot = counter block + fallback total");
+    CK(hipHostMalloc((void **)&ctx->h_ring, (size_t)crt_ctx::EV_RING * crt_ctx::H_SLOT_WORDS * sizeof(uint32_t)));
+    memset(ctx->h_ring, 0, (size_t)crt_ctx::EV_RING * crt_ctx::H_SLOT_WORDS * sizeof(uint32_t));
+    ctx->last_counts.assign(SC_ALLOC_WORDS, 0u);
     CK(hipMalloc((void **)&ctx->d_fallback_total, sizeof(uint32_t)));
     CK(hipMemset(ctx->d_fallback_total, 0, sizeof(uint32_t)));
     ctx->n_lights = s->n_lights;
@@ -994,23 +831,16 @@ extern "C" void crt_destroy(crt_ctx *ctx) {
     if (ctx->d_quant) (void)hipFree(ctx->d_quant);
     if (ctx->d_items) (void)hipFree(ctx->d_items);
     if (ctx->d_sync) (void)hipFree(ctx->d_sync);
-    if (ctx->d_deferred) (void)hipFree(ctx->d_deferred);
     for (int i = 0; i < 2; i++) if (ctx->d_rayq[i]) (void)hipFree(ctx->d_rayq[i]);
     if (ctx->d_shadowq) (void)hipFree(ctx->d_shadowq);
     if (ctx->d_occluded) (void)hipFree(ctx->d_occluded);
-    if (ctx->d_shadow_plan) (void)hipFree(ctx->d_shadow_plan);
     if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
     if (ctx->d_scounts) (void)hipFree(ctx->d_scounts);
     if (ctx->d_exec) (void)hipFree(ctx->d_exec);
     if (ctx->d_heavy) (void)hipFree(ctx->d_heavy);
     if (ctx->d_sheavy) (void)hipFree(ctx->d_sheavy);
-    if (ctx->d_todo_tiles) (void)hipFree(ctx->d_todo_tiles);
-    if (ctx->d_todo_shadow) (void)hipFree(ctx->d_todo_shadow);
     if (ctx->d_hits) (void)hipFree(ctx->d_hits);
-    if (ctx->d_ready) (void)hipFree(ctx->d_ready);
-    if (ctx->d_ready2) (void)hipFree(ctx->d_ready2);
-    if (ctx->h_overflow) (void)hipHostFree(ctx->h_overflow);
-    if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
+    if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
     if (ctx->d_fallback_total) (void)hipFree(ctx->d_fallback_total);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_frames) (void)hipFree(ctx->d_frames);
@@ -1025,9 +855,6 @@ extern "C" void crt_destroy(crt_ctx *ctx) {
         if (ctx->ev_s1[i]) (void)hipEventDestroy(ctx->ev_s1[i]);
         if (ctx->ev_s2[i]) (void)hipEventDestroy(ctx->ev_s2[i]);
     }
-    for (int g = 0; g < MAX_GENERATIONS; g++) if (ctx->ev_level[g]) (void)hipEventDestroy(ctx->ev_level[g]);
-    if (ctx->ev_side2) (void)hipEventDestroy(ctx->ev_side2);
-    if (ctx->side2) (void)hipStreamDestroy(ctx->side2);
     if (ctx->ev_call0) (void)hipEventDestroy(ctx->ev_call0);
     if (ctx->ev_call1) (void)hipEventDestroy(ctx->ev_call1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1056,13 +883,11 @@ static int check_options(crt_ctx *ctx, const crt_options *o) {
 
 static int ensure_items(crt_ctx *ctx, size_t n) {
     if (n <= ctx->items_cap) return CRT_OK;
+    CRT_HIP_CHECK(ctx, hipDeviceSynchronize());  // nothing may still be reading the old items
     if (ctx->d_items) (void)hipFree(ctx->d_items);
-    if (ctx->d_deferred) (void)hipFree(ctx->d_deferred);
     ctx->d_items = nullptr;
-    ctx->d_deferred = nullptr;
     ctx->items_cap = 0;
     CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_items, n * sizeof(WorkItem)));
-    CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_deferred, n * 64 * sizeof(uint32_t)));
     ctx->items_cap = n;
     ctx->cached_rects.clear();
     ctx->cached_is_partition = false;
@@ -1084,34 +909,45 @@ static int ensure_frames(crt_ctx *ctx, uint32_t max_depth, bool gi) {
     return CRT_OK;
 }
 
-// Queues of the ray-stream pass, sized from the number of work items (64 pixels each): ray-tree nodes
-// 4x the pixels, each level's ray queue 3x, shadow rays n_lights per node.  A frame that needs more (deep
-// refractive stacks can reach 2^(MAX_DEPTH+1)-1 rays per pixel) raises the overflow word and is redone by
-// render_lanes, which needs no queues.
+// What the finished frames left behind.  Every frame copies its counter block and the fallback total into its own slot of
+// the pinned ring (launch_render); a slot is read here only once the frame's last event has completed, so the host never
+// reads a buffer a copy may still be writing, and what the next launch learns is a function of a COMPLETED frame.
+static void harvest_counts(crt_ctx *ctx) {
+    while (ctx->next_count_harvest < ctx->launches) {
+        const uint64_t j = ctx->next_count_harvest;
+        if (j + crt_ctx::EV_RING <= ctx->launches) { ctx->next_count_harvest++; continue; }  // its slot has been reused
+        const int slot = (int)(j % crt_ctx::EV_RING);
+        if (hipEventQuery(ctx->ev4[slot]) != hipSuccess) { (void)hipGetLastError(); break; }
+        const uint32_t *h = ctx->h_ring + (size_t)slot * crt_ctx::H_SLOT_WORDS;
+        if (ctx->slot_items[slot]) {  // (a frame without work items launched nothing and copied nothing)
+            ctx->last_counts.assign(h, h + SC_ALLOC_WORDS);
+            ctx->last_counts_items = ctx->slot_items[slot];
+            ctx->fallbacks_seen = h[SC_ALLOC_WORDS];
+        }
+        ctx->next_count_harvest++;
+    }
+}
+
 // Queues of the ray-stream pass.  What a frame needs depends on the scene and the camera -- a frame of diffuse surfaces
 // has no child rays at all, nested glass can reach 2^(MAX_DEPTH+1)-1 rays per pixel -- so the capacities FOLLOW the frames:
 // they start at px * {1.3 ray-tree nodes, 0.5 rays per level, n_lights * 1.125 shadow rays} (px = 64 pixels per work item),
-// grow by half when the previous frame used more than 70 % of one of them, and double (up to px * {4, 3, n_lights * 4})
+// grow by half when the last completed frame used more than 70 % of one of them, and double (up to px * {4, 3, n_lights * 4})
 // after a frame that overflowed.  Such a frame is not lost: its queues raise the overflow word and render_lanes, which
 // needs no queues, redoes it in the same call (crt_stats::fallback_frames counts them).
 static void adapt_queue_sizing(crt_ctx *ctx) {
-    if (!ctx->h_counts) return;
-    const uint32_t *c = ctx->h_counts;  // the previous frame's counter block (pinned copy; zero before the first frame)
-    const uint32_t fallbacks = *ctx->h_overflow;
-    if (fallbacks != ctx->sizing_seen_fallbacks) {
-        ctx->sizing_seen_fallbacks = fallbacks;
+    const uint32_t *c = ctx->last_counts.data();
+    if (ctx->fallbacks_seen != ctx->sizing_seen_fallbacks) {
+        ctx->sizing_seen_fallbacks = ctx->fallbacks_seen;
         ctx->node_mult = std::min(4.0, ctx->node_mult * 2.0);
         ctx->ray_mult = std::min(3.0, ctx->ray_mult * 2.0);
         ctx->shadow_extra = std::min(3.0, ctx->shadow_extra * 2.0);
         return;
     }
     const KernelArgs &A = ctx->args;
-    if (!A.s_node_cap || !ctx->last_items) return;
-    const uint64_t px = (uint64_t)ctx->last_items * 64;
+    if (!A.s_node_cap || !ctx->last_counts_items) return;
+    const uint64_t px = (uint64_t)ctx->last_counts_items * 64;
     uint64_t rays = 0, nodes = px;
     for (int g = 1; g < MAX_GENERATIONS; g++) { rays = std::max<uint64_t>(rays, c[SC_COUNT + g]); nodes += c[SC_COUNT + g]; }
-    if (c[SC_DEEP_NODES]) nodes = c[SC_DEEP_NODES];  // (the deep kernels allocate nodes from their own cursor)
-    rays = std::max<uint64_t>(rays, c[SC_DEEP_HQ_TAIL]);
     const uint64_t shadow = c[SC_SHADOW];
     // level 0 owns one node per pixel and n_lights fixed shadow slots per pixel: what can run out is the part beyond that
     const uint64_t base_shadow = px * (ctx->n_lights ? ctx->n_lights : 1);
@@ -1125,7 +961,6 @@ static void adapt_queue_sizing(crt_ctx *ctx) {
 static int ensure_stream(crt_ctx *ctx, uint32_t n_items) {
     KernelArgs &A = ctx->args;
     adapt_queue_sizing(ctx);
-    ctx->last_items = n_items;
     const uint64_t px = (uint64_t)n_items * 64;
     const uint64_t lights = ctx->n_lights ? ctx->n_lights : 1;
     const uint64_t floor_cap = 1u << 16;
@@ -1150,52 +985,26 @@ static int ensure_stream(crt_ctx *ctx, uint32_t n_items) {
             ray_cap = std::max<uint64_t>(ray_cap, A.s_ray_cap);
             shadow_cap = std::max<uint64_t>(shadow_cap, A.s_shadow_cap);
         }
-        for (int i = 0; i < 2; i++) { if (ctx->d_rayq[i]) (void)hipFree(ctx->d_rayq[i]); ctx->d_rayq[i] = nullptr; }
-        if (ctx->d_shadowq) (void)hipFree(ctx->d_shadowq);
-        if (ctx->d_occluded) (void)hipFree(ctx->d_occluded);
-        if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
-        ctx->d_shadowq = nullptr; ctx->d_occluded = nullptr; ctx->d_nodes = nullptr;
+        void **bufs[] = {(void **)&ctx->d_rayq[0], (void **)&ctx->d_rayq[1], (void **)&ctx->d_shadowq, (void **)&ctx->d_occluded,
+                         (void **)&ctx->d_nodes, (void **)&ctx->d_heavy, (void **)&ctx->d_sheavy, (void **)&ctx->d_hits};
+        for (void **b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
         ctx->stream_items = 0;
         A.s_node_cap = A.s_ray_cap = A.s_shadow_cap = 0;
         for (int i = 0; i < 2; i++) CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_rayq[i], ray_cap * 2 * sizeof(float4)));
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_shadowq, shadow_cap * 2 * sizeof(float4)));
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_occluded, shadow_cap));
-        if (ctx->d_shadow_plan) (void)hipFree(ctx->d_shadow_plan);
-        ctx->d_shadow_plan = nullptr;
-        if (ctx->tuning.preplan) CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_shadow_plan, shadow_cap * sizeof(uint2)));
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_nodes, node_cap * 2 * sizeof(float4)));
-        if (ctx->d_ready) (void)hipFree(ctx->d_ready);
-        ctx->d_ready = nullptr;
-        CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_ready, ray_cap * sizeof(uint32_t)));
-        CRT_HIP_CHECK(ctx, hipMemset(ctx->d_ready, 0, ray_cap * sizeof(uint32_t)));  // no epoch is 0
-        if (ctx->d_ready2) (void)hipFree(ctx->d_ready2);
-        ctx->d_ready2 = nullptr;
-        CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_ready2, ray_cap * sizeof(uint32_t)));
-        CRT_HIP_CHECK(ctx, hipMemset(ctx->d_ready2, 0, ray_cap * sizeof(uint32_t)));
-        if (ctx->d_heavy) (void)hipFree(ctx->d_heavy);
-        if (ctx->d_sheavy) (void)hipFree(ctx->d_sheavy);
-        if (ctx->d_hits) (void)hipFree(ctx->d_hits);
-        if (ctx->d_todo_tiles) (void)hipFree(ctx->d_todo_tiles);
-        if (ctx->d_todo_shadow) (void)hipFree(ctx->d_todo_shadow);
-        ctx->d_heavy = nullptr; ctx->d_sheavy = nullptr; ctx->d_hits = nullptr; ctx->d_todo_tiles = nullptr; ctx->d_todo_shadow = nullptr;
-        CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_todo_tiles, ((size_t)n_items + 1) * sizeof(uint32_t)));
-        // (the list of abandoned shadow walks is only written when level 0 runs as packets)
-        CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_todo_shadow, (ctx->packet_budget ? (size_t)shadow_cap : 1) * sizeof(uint32_t)));
         ctx->heavy_cap = (uint32_t)std::max<uint64_t>(floor_cap, ray_cap);  // (a full list only keeps a long walk where it is)
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_heavy, (size_t)ctx->heavy_cap * sizeof(uint32_t)));
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_sheavy, (size_t)ctx->heavy_cap * sizeof(uint32_t)));
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_hits, (size_t)ctx->heavy_cap * sizeof(float4)));
         A.s_ray_cap = (uint32_t)ray_cap; A.s_shadow_cap = (uint32_t)shadow_cap; A.s_node_cap = (uint32_t)node_cap;
         ctx->stream_items = n_items;
-        ctx->queue_bytes = ray_cap * 64 + shadow_cap * 33 + node_cap * 32 + ray_cap * 8 + (size_t)ctx->heavy_cap * 24 +
-                           (ctx->packet_budget ? shadow_cap * 4 : 4) + ((size_t)n_items + 1) * 4 + (ctx->d_shadow_plan ? shadow_cap * 8 : 0);
+        ctx->queue_bytes = ray_cap * 64 + shadow_cap * 33 + node_cap * 32 + (size_t)ctx->heavy_cap * 24;
     }
     A.s_rayq[0] = ctx->d_rayq[0]; A.s_rayq[1] = ctx->d_rayq[1];
     A.s_shadowq = ctx->d_shadowq; A.s_occluded = ctx->d_occluded; A.s_nodes = ctx->d_nodes;
     A.s_heavy = ctx->d_heavy; A.s_sheavy = ctx->d_sheavy; A.s_hits = ctx->d_hits; A.s_heavy_cap = ctx->heavy_cap;
-    A.s_todo_tiles = ctx->d_todo_tiles; A.s_todo_shadow = ctx->d_todo_shadow;
-    A.s_ready = ctx->d_ready;
-    A.s_ready2 = ctx->d_ready2;
     return CRT_OK;
 }
 
@@ -1268,8 +1077,12 @@ static void autotune_step(crt_ctx *ctx, uint32_t n_items, uint32_t depth, bool e
     T.tag[slot_now] = T.stage;
 }
 
-static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, float *d_out, uint32_t packed,
-                         hipStream_t stream, bool timed) {
+// One frame's launches.  Ray-stream path (kernel_stream.h), per recursion level g = 0 .. MAX_DEPTH on `stream`:
+//   the per-lane kernel (plan kernels; the faithful kernel for the counting build and for scenes without a plan),
+//   heavy_trace_closest for the walks it handed over (or the whole level), stream_shade_evicted for their hits;
+// the bulk shadow pass (level 0's shadow rays) on the side stream as soon as level 0 is done, then the deeper levels'
+// shadow rays, the wave-per-ray shadow walks, stream_resolve, and render_lanes, which only runs after a queue overflow.
+static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, float *d_out, uint32_t packed, hipStream_t stream) {
     const bool gi = o->use_gi != 0;  // the GI / multi-sample mode: rendered pixel by pixel by render_lanes<.., true> (kernel_lane.h)
     int rc = ensure_frames(ctx, o->max_depth, gi);
     if (rc) return rc;
@@ -1279,7 +1092,8 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
     A.rays_per_pixel = o->rays_per_pixel;
     A.monte_carlo_bias = o->monte_carlo_bias;
     A.gi_seed = o->gi_seed;
-    if (!gi && ctx->mode == crt_ctx::MODE_STREAM && o->max_depth + 1 > (uint32_t)MAX_GENERATIONS) {
+    const bool stream_mode = ctx->mode == crt_ctx::MODE_STREAM && !gi;
+    if (stream_mode && o->max_depth + 1 > (uint32_t)MAX_GENERATIONS) {
         ctx->error = "max_depth too large for the ray-stream pass";
         return CRT_ERR_INVALID;
     }
@@ -1290,104 +1104,86 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
     A.items = ctx->d_items;
     A.n_items = n_items;
     A.pixel_counter = ctx->d_sync + 0;
-    A.tile_counter = ctx->d_sync + 1;
-    A.deferred_count = ctx->d_sync + 2;
-    A.deferred = ctx->d_deferred;
     A.out = d_out;
     A.packed = packed;
     A.counters = ctx->d_counters;
     A.s_counts = ctx->d_scounts;
     A.only_if_overflow = 0;
     A.fallback_total = ctx->d_fallback_total;
-    A.use_deferred = 0;
-    A.packet_budget = ctx->packet_budget;
-    A.use_packets = 0;
     const bool count = o->collect_counters == 1;       // the counting build: every ray walked the reference's way
     const bool exec_count = o->collect_counters == 2;  // the production kernels, tallying the tests they execute
     CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_sync, 0, 4 * sizeof(uint32_t), stream));
     if (count) CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_counters, 0, 3 * C_N * sizeof(unsigned long long), stream));
-    if (n_items == 0) return CRT_OK;
+    harvest_counts(ctx);
     const int slot = (int)(ctx->launches % crt_ctx::EV_RING);
+    if (ctx->launches >= (uint64_t)crt_ctx::EV_RING) {
+        // the slot's previous frame (64 launches ago) must be complete before its events and its pinned words are reused
+        CRT_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev4[slot]));
+        harvest_counts(ctx);
+    }
+    ctx->slot_items[slot] = 0;
     ctx->at.tag[slot] = -2;  // (crt_tuning::autotune: not a frame it may learn from, unless autotune_step below says otherwise)
     const uint32_t lane_need = (n_items * 64u + BLOCK - 1) / BLOCK;
-    const uint32_t lane_blocks = lane_need < ctx->grid_blocks ? lane_need : ctx->grid_blocks;
-    if (timed) CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0[slot], stream));
-    if (ctx->mode == crt_ctx::MODE_STREAM && !gi) {
-        const uint32_t prev_items = ctx->last_items;  // (the previous frame's counter block describes a frame of this many work items)
+    const uint32_t lane_blocks = std::max(1u, lane_need < ctx->grid_blocks ? lane_need : ctx->grid_blocks);
+    CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0[slot], stream));
+    if (n_items == 0) {
+        // nothing to render: the events still bracket an (empty) frame, so that every reader of a slot finds recorded events
+        for (hipEvent_t e : {ctx->ev1[slot], ctx->ev_s0[slot], ctx->ev_s1[slot], ctx->ev_s2[slot], ctx->ev2[slot], ctx->ev3[slot], ctx->ev4[slot]})
+            CRT_HIP_CHECK(ctx, hipEventRecord(e, stream));
+        ctx->launches++;
+        return CRT_OK;
+    }
+    if (stream_mode) {
         rc = ensure_stream(ctx, n_items);
         if (rc) return rc;
         CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_scounts, 0, SC_ALLOC_WORDS * sizeof(uint32_t), stream));
-        // 1) closest-hit walks + material dispatch, one launch per recursion level
         // the wave-per-ray path needs nested boxes; the counting build walks every ray the reference's way
         const bool heavy = ctx->step_budget && A.nested_boxes && !count;
-        A.step_budget = heavy ? ctx->step_budget : 0u;
-        A.debug = ctx->debug_skip;
-        const bool lean = heavy && ctx->lean_ok && !(ctx->debug_skip & 256u);
-        A.heavy_level_threshold = lean ? ctx->heavy_level_threshold : 0u;
-        uint32_t at_side_blocks = 0;  // crt_tuning::autotune's choice of the bulk shadow pass's workgroups per CU (0: the tuning's)
+        // the plan kernels (kernel_plan.h): a small top-level tree (its leaves as a plan), 32-bit offsets, compact leaf links
+        const bool lean = heavy && ctx->lean_ok && A.plan_ok;
+        const bool quad = lean && ctx->tuning.quad && ctx->quads_ok;
+        A.heavy_level_threshold = lean ? ctx->tuning.heavy_level : 0u;
+        uint32_t side_per_cu = ctx->tuning.side_blocks;  // workgroups per CU of the bulk shadow pass beside the levels
         {
-            const bool eligible = ctx->tuning.autotune && timed && lean && !count && !exec_count && ctx->tuning.level0_budget == 0u &&
-                                  ctx->tuning.heavy_level == 100000u && ctx->tuning.step_budget == 256u && !ctx->tuning.deep;
+            const bool eligible = ctx->tuning.autotune && lean && !exec_count && ctx->tuning.level0_budget == 0u &&
+                                  ctx->tuning.heavy_level == 100000u && ctx->tuning.step_budget == 256u;
             autotune_step(ctx, n_items, o->max_depth, eligible);
             if (eligible && ctx->at.hl) A.heavy_level_threshold = ctx->at.hl;
-            at_side_blocks = eligible && ctx->at.sb && ctx->tuning.side_blocks == 3u ? ctx->at.sb : 0u;
+            if (eligible && ctx->at.sb && ctx->tuning.side_blocks == 3u) side_per_cu = ctx->at.sb;
         }
-        const uint32_t quad = lean ? ctx->use_quads : 0u;  // bit 0: the levels, bit 1: shadow pass 0, bit 2: shadow pass 1
-        A.quad_stack_depth = ctx->quad_stack_depth;
-        A.prune = ctx->prune;
+        A.quad_stack_depth = QUAD_STACK_DEPTH;
         A.exec_count = exec_count ? 1u : 0u;
         A.exec_counters = ctx->d_exec;
         A.exec_plan = ctx->d_exec + 4;
         if (exec_count) CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_exec, 0, 6 * sizeof(unsigned long long), stream));
-        // the plan kernels (kernel_plan.h) pay a wave-uniform loop per refill, whatever the number of new rays: refill in bundles
-        A.bundle = (A.plan_ok && ctx->bundle < 64u) ? ctx->bundle : 64u;
+        // the plan kernels pay a wave-uniform loop per refill, whatever the number of new rays: refill in bundles
+        A.bundle = REFILL_BUNDLE;
+        A.wave_prio = 3u;  // the levels' waves (the frame's critical path) ahead of the bulk shadow pass's, which share their SIMDs
+        A.force_whole = 0u;
         A.fixed0 = 0;
-        A.early_shadow = 0;
-        A.skip_unlit = ctx->tuning.skip_unlit ? 1u : 0u;
-        A.wave_prio = ctx->tuning.wave_priority > 3u ? 3u : ctx->tuning.wave_priority;
-        if (ctx->fixed0) {  // level 0 owns the first n_items * 64 * n_lights slots of the shadow queue; the deeper levels append
+        {   // level 0 owns the first n_items * 64 * n_lights slots of the shadow queue; the deeper levels append
             const uint64_t n0 = (uint64_t)n_items * 64u * ctx->n_lights;
             if (n0 <= A.s_shadow_cap) {
                 A.fixed0 = 1;
                 CRT_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->d_scounts + SC_SHADOW), (int)(uint32_t)n0, 1, stream));
-                // early_shadow: the bulk shadow pass is launched straight after the level-0 kernel and reads exactly the fixed region
-                if (lean && A.plan_ok && !(lean ? (ctx->use_quads & 2u) : 0u) && ctx->side_blocks_per_cu && ctx->tuning.early_shadow && !count &&
-                    ctx->packet_budget == 0) {
-                    A.early_shadow = 1;
-                    CRT_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->d_scounts + SC_SHADOW_SPLIT), (int)(uint32_t)n0, 1, stream));
-                }
             }
         }
-        const uint32_t qlds = ctx->quad_stack_depth * BLOCK * (uint32_t)sizeof(uint32_t);
+        const uint32_t qlds = quad ? QUAD_STACK_DEPTH * BLOCK * (uint32_t)sizeof(uint32_t) : 0u;
         const uint32_t plds = A.plan_list_words * BLOCK * (uint32_t)sizeof(uint32_t);  // kernel_plan.h: mesh lists
-        const uint32_t heavy_blocks = ctx->heavy_blocks;
-        const bool packets = lean && ctx->packet_budget != 0 && !(ctx->debug_skip & 512u);
-        if (packets) {
-            // 0) recursion level 0 for every tile whose rays stay coherent: packets, scalar-load path
-            A.use_packets = 1;
-            const uint32_t need = (n_items + BLOCK / 64 - 1) / (BLOCK / 64);
-            launch(stream_packets_gen0, need < ctx->grid_blocks ? need : ctx->grid_blocks, stream, A);
-            hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, stream, A, (uint32_t)SC_SHADOW_SPLIT, (uint32_t)SC_SHADOW);
-        }
-        A.pool_refill = ctx->tuning.pool_refill < 1u ? 1u : (ctx->tuning.pool_refill > 64u ? 64u : ctx->tuning.pool_refill);
-        A.pool_switch = ctx->tuning.pool_switch > 64u ? 64u : ctx->tuning.pool_switch;
-        A.tri_gather = ctx->tuning.tri_gather > 64u ? 64u : ctx->tuning.tri_gather;
-        A.node_repeat = ctx->tuning.node_repeat < 1u ? 1u : (ctx->tuning.node_repeat > 8u ? 8u : ctx->tuning.node_repeat);
-        KernelArgs S = A;  // argument block of the shadow passes
+        KernelArgs S = A;  // argument block of the bulk shadow pass
         S.wave_prio = 0u;
         S.counters = ctx->d_counters + C_N;
-        S.bundle = ctx->bundle;
-        S.exec_counters = ctx->d_exec + 2;  // shadow pass 0 tallies on its own
+        S.exec_counters = ctx->d_exec + 2;  // it tallies on its own
         S.exec_plan = ctx->d_exec + 5;
         {
-            // Pass 0 is one persistent launch: it ends when its longest walk ends, so the budget after which a walk is
+            // The pass is one persistent launch: it ends when its longest walk ends, so the budget after which a walk is
             // handed to heavy_trace_shadow should be about the steps one lane gets through in the whole launch --
             // rays per lane x ~130 steps per ray (measured average on the benchmark scenes) -- and no more than the cap
-            // (CRT_SHADOW_BUDGET).  A rank that renders 1/8 of the tiles gets 1/8 of the budget.
-            const uint64_t lanes = (uint64_t)ctx->num_cus * (ctx->side_blocks_per_cu ? ctx->side_blocks_per_cu : 8u) * BLOCK;
+            // (crt_tuning::shadow_budget).  A rank that renders 1/8 of the tiles gets 1/8 of the budget.
+            const uint64_t lanes = (uint64_t)ctx->num_cus * (side_per_cu ? side_per_cu : 8u) * BLOCK;
             const uint64_t est = (uint64_t)n_items * 64u * (ctx->n_lights ? ctx->n_lights : 1u) * 130u / (lanes ? lanes : 1u);
-            uint32_t budget = est > ctx->shadow_budget ? ctx->shadow_budget : (uint32_t)est;
-            if (budget < ctx->step_budget) budget = ctx->step_budget < ctx->shadow_budget ? ctx->step_budget : ctx->shadow_budget;
+            uint32_t budget = est > ctx->tuning.shadow_budget ? ctx->tuning.shadow_budget : (uint32_t)est;
+            if (budget < ctx->step_budget) budget = std::min(ctx->step_budget, ctx->tuning.shadow_budget);
             S.step_budget = heavy ? budget : 0u;
         }
         // the same reasoning for level 0 (one launch over all primary rays, ~70 steps per ray)
@@ -1395,228 +1191,101 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         uint32_t budget0 = est0 >= ctx->step_budget ? ctx->step_budget : (est0 < 64u ? 64u : (uint32_t)est0);
         if (ctx->tuning.level0_budget) budget0 = ctx->tuning.level0_budget;
         else if (ctx->at.b0 && ctx->at.tag[slot] >= -1 && ctx->at.b0 < budget0) budget0 = ctx->at.b0;  // crt_tuning::autotune
-        // the recursion levels >= 1: one persistent queue-driven launch (kernel_deep.h), or a launch triple per level
-        const uint32_t deep_first = ctx->tuning.deep_first < 1u ? 1u : ctx->tuning.deep_first;
-        const bool deep = heavy && ctx->tuning.deep && o->max_depth >= deep_first;
-        A.deep_first = deep_first;
-        ctx->epoch = ctx->epoch == 0xFFFFFFFFu ? 1u : ctx->epoch + 1u;
-        A.epoch = ctx->epoch;
-        // 2a) the shadow rays level 0 queued (the bulk of them), on the side stream beside the deeper levels: launched after level 0
-        //     is complete, or -- early_shadow -- straight after its per-lane kernel
-        auto fork_shadow0 = [&]() -> int {
-            // 2a) the shadow rays level 0 queued (the bulk of them) start now, beside the deeper levels
-            CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork[slot], stream));
-            CRT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork[slot], 0));
-            CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s0[slot], ctx->side));
-            // its persistent waves must leave wave slots on every CU for the level kernels running beside it
-            const uint32_t side_blocks = (uint32_t)ctx->num_cus * (at_side_blocks ? at_side_blocks : ctx->side_blocks_per_cu);
-            if (count) launch(stream_trace_shadow<true>, side_blocks, ctx->side, S, 0u);
-            else if (lean && (quad & 2u)) launch_lds(stream_trace_shadow_lean<0, true>, side_blocks, qlds, ctx->side, S);
-            else if (lean && A.plan_ok && ctx->tuning.pool) launch_lds(stream_trace_shadow_pool<0>, side_blocks, POOL_LDS_BYTES, ctx->side, S);
-            else if (lean && A.plan_ok && ctx->d_shadow_plan) {
-                // the plans first, one ray per thread (kernel_plan.h: stream_plan_shadow), then the walks with cheap refills
-                S.s_shadow_plan = ctx->d_shadow_plan;
-                S.pre_bundle = ctx->tuning.pre_bundle > 64u ? 64u : ctx->tuning.pre_bundle;
-                S.pre_trips = ctx->tuning.pre_trips < 1u ? 1u : (ctx->tuning.pre_trips > 64u ? 64u : ctx->tuning.pre_trips);
-                launch(stream_plan_shadow, lane_blocks, ctx->side, S);
-                launch(stream_trace_shadow_preplanned, side_blocks, ctx->side, S);
-            }
-            else if (lean && A.plan_ok) launch(stream_trace_shadow_plan<0>, side_blocks, ctx->side, S);
-            else if (lean) launch(stream_trace_shadow_lean<0, false>, side_blocks, ctx->side, S);
-            else launch(stream_trace_shadow<false>, side_blocks, ctx->side, S, 0u);
-            return CRT_OK;
-        };
-        // ... and, queued behind it on the side stream once the level loop has been issued: the walks it gave up, still beside
-        // the levels; the mark comes before the event the caller's stream waits for, so nothing the later pass appends is below it
-        auto finish_shadow0 = [&]() -> int {
-            if (heavy && !count) hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, ctx->side, S, (uint32_t)SC_SHEAVY_SPLIT, (uint32_t)SC_SHEAVY);
-            CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s1[slot], ctx->side));
-            if (heavy && !count) launch(heavy_trace_shadow, heavy_blocks, ctx->side, S, 0u);
-            CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s2[slot], ctx->side));
-            return CRT_OK;
-        };
-        // the deeper levels' shadow rays level by level on the side stream (plan kernels only), or all at once at the end
-        const bool level_shadows = lean && A.plan_ok && !(quad & 4u) && ctx->side_blocks_per_cu && !deep && !packets && ctx->tuning.level_shadows;
-        // level_shadows >= 2: only the levels 1 .. level_shadows, on a THIRD stream (beside the bulk pass, not behind it); the rest at the end
-        const uint32_t early_levels = level_shadows && ctx->tuning.level_shadows >= 2u ? std::min(ctx->tuning.level_shadows, (uint32_t)MAX_GENERATIONS - 2u) : 0u;
-        bool side2_used = false, forked = false;
-        const uint32_t level_shadow_blocks = (uint32_t)ctx->num_cus * 2u;
-        KernelArgs SL = S;  // their argument block: the second pass's budget (few rays, all tail)
-        {
-            const uint64_t est1 = (uint64_t)n_items * 16u * 130u / ((uint64_t)lane_blocks * BLOCK);
-            const uint32_t env1 = ctx->pass1_budget ? ctx->pass1_budget : ctx->step_budget;
-            SL.step_budget = heavy ? (est1 >= env1 ? env1 : (est1 < 64u ? 64u : (uint32_t)est1)) : 0u;
-            SL.counters = ctx->d_counters + 2 * C_N;
-            SL.bundle = A.bundle;
-            SL.exec_counters = ctx->d_exec;
-            SL.exec_plan = ctx->d_exec + 4;
-        }
-        for (uint32_t g = 0; g <= (deep ? deep_first - 1u : o->max_depth); g++) {
+        const uint32_t *prev = ctx->last_counts_items == n_items ? ctx->last_counts.data() : nullptr;  // a completed frame of this size
+        for (uint32_t g = 0; g <= o->max_depth; g++) {
             A.step_budget = heavy ? (g == 0 ? budget0 : ctx->step_budget) : 0u;
             // The per-lane kernel of a deeper level fetches its rays through a cursor, so any grid does the whole level; beside
             // the bulk shadow pass every workgroup of it waits for a free slot, and a level below heavy_level_threshold has
             // nothing for it to do (measured: 0.15 ms for an empty full-size grid).  Sized by what the level held a frame ago.
             uint32_t level_blocks = lane_blocks;
-            A.force_whole = 0u;
-            if (g >= 1 && lean && !count && ctx->tuning.level_grid && prev_items == n_items && ctx->h_counts) {
-                const uint32_t prev = ctx->h_counts[SC_COUNT + g];
-                const uint32_t want = prev < A.heavy_level_threshold ? 64u : std::max<uint32_t>((uint32_t)ctx->num_cus, (prev + prev / 2u + BLOCK - 1) / BLOCK);
+            if (g >= 1 && lean && prev) {
+                const uint32_t was = prev[SC_COUNT + g];
+                const uint32_t want = was < A.heavy_level_threshold ? 64u : std::max<uint32_t>((uint32_t)ctx->num_cus, (was + was / 2u + BLOCK - 1) / BLOCK);
                 level_blocks = std::min(lane_blocks, want);
-                // far below the threshold a frame ago (level_grid = 2): no per-lane launch at all; the wave-per-ray kernel and the
-                // shading of its hits are told to take the whole level whatever it holds now
-                if (ctx->tuning.level_grid >= 2u && heavy && (uint64_t)prev * 2u < A.heavy_level_threshold) A.force_whole = 1u;
             }
-            if (A.force_whole) {}
-            else if (count) launch(stream_trace_shade<true>, lane_blocks, stream, A, g);
-            else if (lean && A.plan_ok && (quad & 1u)) launch_lds(stream_trace_shade_plan<true>, level_blocks, qlds + plds, stream, A, g);
-            else if (lean && A.plan_ok) launch_lds(stream_trace_shade_plan<false>, level_blocks, plds, stream, A, g);
-            else if (lean && (quad & 1u)) launch_lds(stream_trace_shade_lean<true>, level_blocks, qlds, stream, A, g);
-            else if (lean) launch(stream_trace_shade_lean<false>, level_blocks, stream, A, g);
+            if (count) launch(stream_trace_shade<true>, lane_blocks, stream, A, g);
+            else if (lean && quad) launch_lds(stream_trace_shade_plan<true>, level_blocks, qlds + plds, stream, A, g);
+            else if (lean) launch_lds(stream_trace_shade_plan<false>, level_blocks, plds, stream, A, g);
             else launch(stream_trace_shade<false>, lane_blocks, stream, A, g);
-            if (g == 0 && A.early_shadow) { rc = fork_shadow0(); if (rc) return rc; forked = true; }
             if (heavy) {
-                if (ctx->tuning.heavy_waves == 7u && g > 0) launch(heavy_trace_closest<7>, heavy_blocks, stream, A, g);
-                else if (ctx->tuning.heavy_waves == 4u) launch(heavy_trace_closest<4>, heavy_blocks, stream, A, g);
-                else launch(heavy_trace_closest<5>, heavy_blocks, stream, A, g);
-                if (g == 0 && A.early_shadow) {  // the fixed shadow slots are being read already: queue these pixels' shadow rays
-                    KernelArgs AE = A;
-                    AE.fixed0 = 0u;
-                    launch(stream_shade_evicted<false>, 256u, stream, AE, g);
-                } else {
-                    launch(stream_shade_evicted<false>, 256u, stream, A, g);
+                launch(heavy_trace_closest, HEAVY_BLOCKS, stream, A, g);
+                launch(stream_shade_evicted<false>, 256u, stream, A, g);
+            }
+            if (g == 0) {
+                // where level 0's shadow rays end; they start now, on the side stream, beside the deeper levels
+                hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, stream, A, (uint32_t)SC_SHADOW_SPLIT, (uint32_t)SC_SHADOW);
+                hipStream_t where = side_per_cu ? ctx->side : stream;
+                if (side_per_cu) {
+                    CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork[slot], stream));
+                    CRT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork[slot], 0));
                 }
+                CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s0[slot], where));
+                // (beside the levels its persistent waves must leave wave slots on every CU for the level kernels)
+                const uint32_t blocks0 = side_per_cu ? (uint32_t)ctx->num_cus * side_per_cu : ctx->grid_blocks;
+                if (count) launch(stream_trace_shadow<true>, blocks0, where, S, 0u);
+                else if (lean) launch(stream_trace_shadow_plan<0>, blocks0, where, S);
+                else launch(stream_trace_shadow<false>, blocks0, where, S, 0u);
+                // ... and behind it the walks it gave up, still beside the levels; the mark comes before the event the
+                // caller's stream waits for, so nothing the later pass appends is below it
+                if (heavy) hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, where, S, (uint32_t)SC_SHEAVY_SPLIT, (uint32_t)SC_SHEAVY);
+                CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s1[slot], where));
+                if (heavy) launch(heavy_trace_shadow, HEAVY_BLOCKS, where, S, 0u);
+                CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s2[slot], where));
             }
-            if (g == 0 && !packets && !A.early_shadow) hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, stream, A, (uint32_t)SC_SHADOW_SPLIT, (uint32_t)SC_SHADOW);
-            if (level_shadows) {
-                // where level g's shadow rays end; from level 1 on they are walked on the side stream while the next level runs
-                hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, stream, A, (uint32_t)(SC_LSPLIT + g + 1), (uint32_t)SC_SHADOW);
-                if (g >= 1 && (!early_levels || g <= early_levels)) {
-                    hipStream_t where = ctx->side;
-                    if (early_levels) {
-                        if (!ctx->side2) CRT_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking));
-                        where = ctx->side2;
-                        side2_used = true;
-                    }
-                    if (!ctx->ev_level[g]) CRT_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_level[g], hipEventDisableTiming));
-                    CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_level[g], stream));
-                    CRT_HIP_CHECK(ctx, hipStreamWaitEvent(where, ctx->ev_level[g], 0));
-                    if (ctx->tuning.pool & 2u) launch_lds(stream_trace_shadow_pool_level, level_shadow_blocks, POOL_LDS_BYTES, where, SL, g);
-                    else launch(stream_trace_shadow_level, level_shadow_blocks, where, SL, g);
-                }
-            }
-            if (g == 0 && ctx->side_blocks_per_cu && !A.early_shadow) { rc = fork_shadow0(); if (rc) return rc; forked = true; }
-        }
-        if (forked) {
-            if (side2_used) {  // the third stream's passes append to the list of walks given up: complete before the mark
-                if (!ctx->ev_side2) CRT_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_side2, hipEventDisableTiming));
-                CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_side2, ctx->side2));
-                CRT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_side2, 0));
-            }
-            rc = finish_shadow0();
-            if (rc) return rc;
-        }
-        if (deep) {
-            A.step_budget = ctx->step_budget;
-            hipLaunchKernelGGL(deep_begin, dim3(1), dim3(64), 0, stream, A);
-            const uint32_t deep_blocks = ctx->tuning.deep_blocks ? ctx->tuning.deep_blocks : (uint32_t)ctx->num_cus * 4u;
-            A.deep_heavy_every = ctx->tuning.deep_heavy_every > 4u ? 4u : (ctx->tuning.deep_heavy_every < 2u ? 2u : ctx->tuning.deep_heavy_every);
-            if (ctx->tuning.deep == 2u && A.plan_ok) {  // one ray per lane, heavy waves for the long walks
-                if (ctx->tuning.deep_waves == 4u) launch_lds(deep_lanes<4>, deep_blocks, plds, stream, A);
-                else launch_lds(deep_lanes<3>, deep_blocks, plds, stream, A);
-            }
-            else if (ctx->tuning.deep_waves == 4u) launch(deep_trace<4>, deep_blocks, stream, A);
-            else launch(deep_trace<5>, deep_blocks, stream, A);
         }
         CRT_HIP_CHECK(ctx, hipGetLastError());
-        if (timed) CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev1[slot], stream));
-        if (!ctx->side_blocks_per_cu) {  // no overlap: pass 0 here, on the caller's stream
-            CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s0[slot], stream));
-            if (count) launch(stream_trace_shadow<true>, ctx->grid_blocks, stream, S, 0u);
-            else if (lean && (quad & 2u)) launch_lds(stream_trace_shadow_lean<0, true>, ctx->grid_blocks, qlds, stream, S);
-            else if (lean && A.plan_ok && ctx->tuning.pool) launch_lds(stream_trace_shadow_pool<0>, ctx->grid_blocks, POOL_LDS_BYTES, stream, S);
-            else if (lean && A.plan_ok) launch(stream_trace_shadow_plan<0>, ctx->grid_blocks, stream, S);
-            else if (lean) launch(stream_trace_shadow_lean<0, false>, ctx->grid_blocks, stream, S);
-            else launch(stream_trace_shadow<false>, ctx->grid_blocks, stream, S, 0u);
-            CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s1[slot], stream));
-        }
-        // 2b) the shadow rays of the deeper levels, then the evicted shadow walks of both passes
-        CRT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_s1[slot], 0));
-        S.counters = ctx->d_counters + 2 * C_N;
-        S.bundle = A.bundle;
-        S.exec_counters = ctx->d_exec;
-        S.exec_plan = ctx->d_exec + 4;
+        CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev1[slot], stream));
+        // the shadow rays of the deeper levels (queued behind level 0's), then the wave-per-ray walks of both passes
+        if (side_per_cu) CRT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_s1[slot], 0));
+        KernelArgs S1 = A;
+        S1.wave_prio = 0u;
+        S1.counters = ctx->d_counters + 2 * C_N;
         {
             // few rays, all tail: the short budget of the levels, or less when this launch is small (the deeper levels
             // queue about a quarter of a shadow ray per pixel on the benchmark scenes)
             const uint64_t est1 = (uint64_t)n_items * 16u * 130u / ((uint64_t)lane_blocks * BLOCK);
-            const uint32_t env1 = ctx->pass1_budget ? ctx->pass1_budget : ctx->step_budget;
-            S.step_budget = heavy ? (est1 >= env1 ? env1 : (est1 < 64u ? 64u : (uint32_t)est1)) : 0u;
+            S1.step_budget = heavy ? (est1 >= ctx->step_budget ? ctx->step_budget : (est1 < 64u ? 64u : (uint32_t)est1)) : 0u;
         }
-        if (early_levels) {
-            // the levels up to `early_levels` are done or under way on the third stream (the side stream, and through ev_s1 this
-            // one, waits for them): what the later levels queued
-            launch(stream_trace_shadow_rest, lane_blocks, stream, S, early_levels + 1u);
-        }
-        else if (level_shadows) {
-            // every level's shadow rays are on the side stream already: wait for the last of them
-            CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s2[slot], ctx->side));
-        }
-        else if (count) launch(stream_trace_shadow<true>, lane_blocks, stream, S, 1u);
-        else if (lean && (quad & 4u)) launch_lds(stream_trace_shadow_lean<1, true>, lane_blocks, qlds, stream, S);
-        else if (lean && A.plan_ok && (ctx->tuning.pool & 2u)) launch_lds(stream_trace_shadow_pool<1>, lane_blocks, POOL_LDS_BYTES, stream, S);
-        else if (lean && A.plan_ok) launch(stream_trace_shadow_plan<1>, lane_blocks, stream, S);
-        else if (lean) launch(stream_trace_shadow_lean<1, false>, lane_blocks, stream, S);
-        else launch(stream_trace_shadow<false>, lane_blocks, stream, S, 1u);
-        if (ctx->side_blocks_per_cu) CRT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_s2[slot], 0));
-        if (heavy) launch(heavy_trace_shadow, heavy_blocks, stream, S, 1u);
+        if (count) launch(stream_trace_shadow<true>, lane_blocks, stream, S1, 1u);
+        else if (lean) launch(stream_trace_shadow_plan<1>, lane_blocks, stream, S1);
+        else launch(stream_trace_shadow<false>, lane_blocks, stream, S1, 1u);
+        if (side_per_cu) CRT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_s2[slot], 0));
+        if (heavy) launch(heavy_trace_shadow, HEAVY_BLOCKS, stream, S1, 1u);
         CRT_HIP_CHECK(ctx, hipGetLastError());
-        if (timed) CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev2[slot], stream));
+        CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev2[slot], stream));
         A.counters = ctx->d_counters + 2 * C_N;
-        // 3) post-order combination per pixel, then the queue-less fallback, which only runs after an overflow
+        // post-order combination per pixel, then the queue-less fallback, which only runs after an overflow
         if (count) launch(stream_resolve<true>, lane_blocks, stream, A);
         else launch(stream_resolve<false>, lane_blocks, stream, A);
         A.only_if_overflow = 1;
         if (count) launch(render_lanes<true>, lane_blocks, stream, A);
         else launch(render_lanes<false>, lane_blocks, stream, A);
         CRT_HIP_CHECK(ctx, hipGetLastError());
-        CRT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_overflow, ctx->d_fallback_total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        CRT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_scounts, SC_ALLOC_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        if (timed) CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev3[slot], stream));
     } else {
-        if (ctx->mode == crt_ctx::MODE_PACKETS && !gi) {
-            // coherent work: one wave per 8x8 tile; what it defers goes to the lane kernel
-            const uint32_t need = (n_items + BLOCK / 64 - 1) / (BLOCK / 64);
-            const uint32_t blocks = need < ctx->grid_blocks ? need : ctx->grid_blocks;
-            if (count) launch(render_packets<true>, blocks, stream, A);
-            else launch(render_packets<false>, blocks, stream, A);
-            CRT_HIP_CHECK(ctx, hipGetLastError());
-            A.use_deferred = 1;
-        }
-        if (timed) CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev1[slot], stream));
+        CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev1[slot], stream));
         A.counters = ctx->d_counters + C_N;
         if (gi && count) launch(render_lanes<true, true>, lane_blocks, stream, A);
         else if (gi) launch(render_lanes<false, true>, lane_blocks, stream, A);
         else if (count) launch(render_lanes<true>, lane_blocks, stream, A);
         else launch(render_lanes<false>, lane_blocks, stream, A);
         CRT_HIP_CHECK(ctx, hipGetLastError());
-        if (timed) {
-            CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev2[slot], stream));
-            CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev3[slot], stream));
-            CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s0[slot], stream));
-            CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s1[slot], stream));
-        }
+        for (hipEvent_t e : {ctx->ev_s0[slot], ctx->ev_s1[slot], ctx->ev_s2[slot], ctx->ev2[slot]}) CRT_HIP_CHECK(ctx, hipEventRecord(e, stream));
     }
-    if (timed) {
-        CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev4[slot], stream));
-        ctx->launches++;
-    }
+    // what this frame leaves for the next ones: its counter block and the fallback total, into this frame's own pinned slot
+    uint32_t *h = ctx->h_ring + (size_t)slot * crt_ctx::H_SLOT_WORDS;
+    if (stream_mode) CRT_HIP_CHECK(ctx, hipMemcpyAsync(h, ctx->d_scounts, SC_ALLOC_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    CRT_HIP_CHECK(ctx, hipMemcpyAsync(h + SC_ALLOC_WORDS, ctx->d_fallback_total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    ctx->slot_items[slot] = stream_mode ? n_items : 0u;
+    CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev3[slot], stream));
+    CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev4[slot], stream));
+    ctx->launches++;
     return CRT_OK;
 }
 
-// Called after a synchronisation: the pinned copy of the last frame's overflow word tells whether the frame was redone
-// by the queue-less kernel.
+// Called after a synchronisation: the last frame's slot tells whether the frame was redone by the queue-less kernel.
 static void note_overflow(crt_ctx *ctx) {
-    if (ctx->h_overflow) ctx->overflows = *ctx->h_overflow;
+    harvest_counts(ctx);
+    ctx->overflows = ctx->fallbacks_seen;
     ctx->stats.fallback_frames = (uint32_t)ctx->overflows;
     ctx->stats.queue_bytes = ctx->queue_bytes;
 }
@@ -1631,8 +1300,8 @@ static int fetch_counters(crt_ctx *ctx, const crt_options *o, uint64_t pixels) {
         CRT_HIP_CHECK(ctx, hipMemcpy(c2, ctx->d_counters, sizeof(c2), hipMemcpyDeviceToHost));
         for (int k = 0; k < C_N; k++) {
             c[k] = c2[k] + c2[C_N + k] + c2[2 * C_N + k];
-            ctx->packet_counters[k] = c2[k];
-            ctx->lane_counters[k] = c2[C_N + k];
+            ctx->level_counters[k] = c2[k];
+            ctx->shadow0_counters[k] = c2[C_N + k];
         }
         ctx->stats.box_tests = c[C_BOX]; ctx->stats.tri_tests = c[C_TRI]; ctx->stats.leaf_index_reads = c[C_LEAFIDX];
         ctx->stats.shaded_hits = c[C_HIT]; ctx->stats.light_evals = c[C_LIGHT]; ctx->stats.texel_fetches = c[C_TEXEL];
@@ -1698,7 +1367,7 @@ static int render_enqueue(crt_ctx *ctx, const crt_options *o, const crt_rect *re
         CRT_HIP_CHECK(ctx, hipEventCreate(&ctx->ev_call1));
     }
     CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_call0, ctx->stream));
-    rc = launch_render(ctx, o, ctx->cached_n_items, ctx->d_frame, 0, ctx->stream, true);
+    rc = launch_render(ctx, o, ctx->cached_n_items, ctx->d_frame, 0, ctx->stream);
     if (rc) return rc;
     const size_t values = (size_t)ctx->width * ctx->height * 3;
     if (out_rgb) CRT_HIP_CHECK(ctx, hipMemcpyAsync(out_rgb, ctx->d_frame, values * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -1720,11 +1389,11 @@ static int render_finish(crt_ctx *ctx) {
     CRT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->pending = false;
     float ms = 0;
-    if (ctx->cached_n_items) {
+    {
         const int slot = (int)((ctx->launches - 1) % crt_ctx::EV_RING);
         CRT_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev0[slot], ctx->ev4[slot]));
-        ctx->stats.kernel_ms = ms;
-    } else ctx->stats.kernel_ms = 0;
+        ctx->stats.kernel_ms = ctx->cached_n_items ? ms : 0;
+    }
     CRT_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev_call0, ctx->ev_call1));
     ctx->stats.total_ms = ms;
     note_overflow(ctx);
@@ -1798,7 +1467,7 @@ extern "C" int crt_render_tiles_device(crt_ctx *ctx, const crt_options *o, uint3
         ctx->cached_n_items = n;
         ctx->cached_pixels = pixels;
     }
-    rc = launch_render(ctx, o, n, d_packed, 1, (hipStream_t)stream, true);
+    rc = launch_render(ctx, o, n, d_packed, 1, (hipStream_t)stream);
     if (rc) return rc;
     if (o->collect_counters) {  // counting renders are synchronous: the counters are read back here
         CRT_HIP_CHECK(ctx, hipStreamSynchronize((hipStream_t)stream));
@@ -1884,9 +1553,9 @@ extern "C" int crt_kernel_times_ms(crt_ctx *ctx, double *out_phase_ms, uint32_t 
     return CRT_OK;
 }
 
-extern "C" int crt_get_kernel_counters(crt_ctx *ctx, uint64_t packets[9], uint64_t lanes[9]) {
-    if (!ctx || !packets || !lanes) return CRT_ERR_INVALID;
-    for (int k = 0; k < C_PUBLIC; k++) { packets[k] = ctx->packet_counters[k]; lanes[k] = ctx->lane_counters[k]; }
+extern "C" int crt_get_kernel_counters(crt_ctx *ctx, uint64_t closest[9], uint64_t shadow[9]) {
+    if (!ctx || !closest || !shadow) return CRT_ERR_INVALID;
+    for (int k = 0; k < C_PUBLIC; k++) { closest[k] = ctx->level_counters[k]; shadow[k] = ctx->shadow0_counters[k]; }
     return CRT_OK;
 }
 
@@ -1916,37 +1585,22 @@ extern "C" int crt_debug_stream_counts(crt_ctx *ctx, uint32_t *out, uint32_t max
     return CRT_OK;
 }
 
-// diagnostics of the packet kernel's last counted render: wave-level node visits, triangle visits, walks
-extern "C" int crt_debug_packet_counters(crt_ctx *ctx, uint64_t out[3]) {
-    if (!ctx || !out) return CRT_ERR_INVALID;
-    out[0] = ctx->packet_counters[C_WAVE_NODES]; out[1] = ctx->packet_counters[C_WAVE_TRIS]; out[2] = ctx->packet_counters[C_WAVE_WALKS];
-    return CRT_OK;
-}
-
 // Which kernels a production frame of this context runs (bench.py names the roofline's kernel with it).
 extern "C" int crt_describe_kernels(const crt_ctx *ctx, char *out, size_t size) {
     if (!ctx || !out || size == 0) return CRT_ERR_INVALID;
     const KernelArgs &A = ctx->args;
     std::string d;
     if (ctx->mode == crt_ctx::MODE_LANES) d = "all=render_lanes<false>";
-    else if (ctx->mode == crt_ctx::MODE_PACKETS) d = "all=render_packets<false>+render_lanes<false>";
     else {
         const bool heavy = ctx->step_budget && A.nested_boxes;
-        const bool lean = heavy && ctx->lean_ok && !(ctx->debug_skip & 256u);
-        const uint32_t quad = lean ? ctx->use_quads : 0u;
-        d = "level0=";
-        d += !lean ? "stream_trace_shade<false>" : (A.plan_ok ? ((quad & 1u) ? "stream_trace_shade_plan<true>" : "stream_trace_shade_plan<false>")
-                                                              : ((quad & 1u) ? "stream_trace_shade_lean<true>" : "stream_trace_shade_lean<false>"));
-        d += ";shadow0=";
-        d += !lean ? "stream_trace_shadow<false>" : ((quad & 2u) ? "stream_trace_shadow_lean<0u, true>" : (A.plan_ok ? "stream_trace_shadow_plan<0u>" : "stream_trace_shadow_lean<0u, false>"));
-        d += ";levels=";
-        d += !heavy ? "stream_trace_shade<false>" : (ctx->tuning.deep == 1u ? "deep_trace" : (ctx->tuning.deep == 2u && A.plan_ok ? "deep_lanes" :
-             (ctx->tuning.heavy_waves == 7u ? "heavy_trace_closest<7>" : (ctx->tuning.heavy_waves == 4u ? "heavy_trace_closest<4>" : "heavy_trace_closest<5>"))));
-    }
-    if (ctx->mode == crt_ctx::MODE_STREAM) {
+        const bool lean = heavy && ctx->lean_ok && A.plan_ok;
+        const bool quad = lean && ctx->tuning.quad && ctx->quads_ok;
+        d = std::string("level0=") + (!lean ? "stream_trace_shade<false>" : (quad ? "stream_trace_shade_plan<true>" : "stream_trace_shade_plan<false>"));
+        d += std::string(";shadow0=") + (!lean ? "stream_trace_shadow<false>" : "stream_trace_shadow_plan<0u>");
+        d += std::string(";levels=") + (!heavy ? "stream_trace_shade<false>" : "heavy_trace_closest");
         char buf[160];
         snprintf(buf, sizeof(buf), ";autotune=%s level0_budget=%u heavy_level=%u side_blocks=%u", !ctx->tuning.autotune ? "off" : (ctx->at.stage < 0 ? "settled" : "measuring"),
-                 ctx->at.b0, ctx->at.hl ? ctx->at.hl : ctx->heavy_level_threshold, ctx->at.sb ? ctx->at.sb : ctx->side_blocks_per_cu);
+                 ctx->at.b0, ctx->at.hl ? ctx->at.hl : ctx->tuning.heavy_level, ctx->at.sb ? ctx->at.sb : ctx->tuning.side_blocks);
         d += buf;
     }
     snprintf(out, size, "%s", d.c_str());
@@ -2005,7 +1659,7 @@ static int multi_part_launch(crt_multi *M, uint32_t p) {
     crt_ctx *ctx = M->ctx[p];
     if (hipSetDevice(ctx->device) != hipSuccess) { ctx->error = "hipSetDevice failed"; return CRT_ERR_HIP; }
     const uint32_t n = (uint32_t)M->part_items[p].size();
-    int rc = launch_render(ctx, M->job_options, n, M->d_packed[p], 1, ctx->stream, true);
+    int rc = launch_render(ctx, M->job_options, n, M->d_packed[p], 1, ctx->stream);
     if (rc) return rc;
     if (p != 0 && n)  // part 0 renders straight into the staging buffer
         CRT_HIP_CHECK(ctx, hipMemcpyPeerAsync(M->d_staging + (size_t)M->slot_base[p] * 192, M->devices[0], M->d_packed[p],
@@ -2118,6 +1772,9 @@ extern "C" int crt_multi_render(crt_multi *M, const crt_options *o, const crt_re
     const bool same = M->cached_rects.size() == n_rects && n_rects > 0 &&
                       memcmp(M->cached_rects.data(), rects, n_rects * sizeof(crt_rect)) == 0;
     if (!same) {
+        // (a rebuild that fails half-way must be redone by the next call, not skipped because the rectangles look familiar)
+        M->cached_rects.clear();
+        M->n_all_items = 0;
         // the covered tiles, dealt round-robin: neighbouring tiles cost about the same, so every device gets every kind
         std::vector<WorkItem> items;
         M->pixels = coverage_items(c0->width, c0->height, rects, n_rects, items);

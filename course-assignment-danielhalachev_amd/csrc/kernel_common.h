@@ -1,5 +1,4 @@
-// kernel_common.h -- device-side constants, argument block and exact-arithmetic helpers shared by the
-// two render kernels (kernel_packet.h: coherent 8x8 packets; kernel_lane.h: one independent ray per lane).
+// kernel_common.h -- device-side constants, argument block and exact-arithmetic helpers shared by all render kernels.
 #pragma once
 
 constexpr uint32_t END = CRT_LINK_END;
@@ -15,10 +14,15 @@ constexpr float PI_F = 3.14159265358979323846f;  // M_PIf, RayTracer.cpp:27
 enum : int { RAY_PRIMARY = 0, RAY_SHADOW = 1, RAY_REFLECTION = 2, RAY_REFRACTION = 3 };  // Ray.h:14
 enum : int { ST_FETCH = 0, ST_TRAVERSE = 1, ST_DONE = 2 };
 enum : int { FR_REFLECT = 0, FR_REFRACT_WAIT_REFLECTION = 1, FR_REFRACT_WAIT_REFRACTION = 2, FR_REFRACT_NO_TRANSMISSION = 3 };
-enum : int { C_BOX = 0, C_TRI, C_LEAFIDX, C_HIT, C_LIGHT, C_TEXEL, C_PRIMARY, C_SECONDARY, C_SHADOW,
-              C_WAVE_NODES, C_WAVE_TRIS, C_WAVE_WALKS, C_N };  // the last three: packet-kernel diagnostics (wave-level visits)
-constexpr int C_PUBLIC = 9;
+enum : int { C_BOX = 0, C_TRI, C_LEAFIDX, C_HIT, C_LIGHT, C_TEXEL, C_PRIMARY, C_SECONDARY, C_SHADOW, C_N };  // crt_stats order
+constexpr int C_PUBLIC = C_N;
 constexpr int SC_OVERFLOW_WORD = 5 * 64 + 2;  // == SC_OVERFLOW of kernel_stream.h (static_assert there)
+
+// constant address space: loads with a wave-uniform address become scalar loads (one s_load for the whole wave)
+typedef const float __attribute__((address_space(4))) *kfp;
+typedef const uint32_t __attribute__((address_space(4))) *ku32p;
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef const v16f __attribute__((address_space(4))) *kv16p;
 
 // A node is a leaf when bit 31 of its link is set -- except the all-ones END value, which an inner node without
 // children (the root of an empty tree) carries as "nothing below, nothing after".
@@ -67,12 +71,6 @@ struct KernelArgs {
     float *frames;                // [wave][level][FRAME_DWORDS][64]
     uint64_t frame_wave_stride;   // floats per wave
     unsigned long long *counters; // C_N, counting build only
-    // hand-off between the two kernels: pixels the packet kernel does not finish (their primary hit is
-    // reflective or refractive) are appended here as q = item*64 + lane and rendered by the lane kernel
-    uint32_t *deferred;           // capacity n_items*64
-    uint32_t *deferred_count;
-    uint32_t use_deferred;        // lane kernel: 0 = walk all n_items*64 pixels, 1 = walk the deferred list
-    uint32_t *tile_counter;       // (unused since render_packets deals tiles out statically)
     uint32_t nested_boxes;        // every inner node's child boxes lie inside its own box (checked by crt_create)
     // ray-stream buffers (kernel_stream.h)
     float4 *s_rayq[2];            // closest-hit ray queues of alternating recursion levels, 2 x float4 per ray
@@ -92,14 +90,8 @@ struct KernelArgs {
     float4 *s_hits;               // closest-hit records of evicted rays: {t, triangle, mesh, have}
     uint32_t step_budget;         // a lane's walk is evicted after this many steps (0 = never)
     uint32_t heavy_level_threshold; // a recursion level with fewer rays than this goes to heavy_trace whole
-    uint32_t packet_budget;       // packet kernel: a tile's walk is abandoned after this many wave-level visits (0 = never)
-    uint32_t use_packets;         // recursion level 0 ran as stream_packets_gen0: the per-lane kernels take its leftovers
-    uint32_t *s_todo_tiles;       // work items whose primary packet walk was abandoned
-    uint32_t *s_todo_shadow;      // shadow-queue slots whose packet walk was abandoned
-    uint32_t debug;               // development switches
-    // quad nodes of the mesh trees (kernel_walk.h): 256 bytes each = {lo.x[4]} {lo.y[4]} {lo.z[4]} {hi.x[4]} {hi.y[4]} {hi.z[4]}
-    // {slot links: quad index | LEAF + first leaf entry | NONE} {the same with compact leaf links}, then the slots' LOOSE boxes in the same
-    // six-vector layout (crt_device.hip: triangle_loose_box) and two unused vectors
+    // quad nodes of the mesh trees (kernel_plan.h): 128 bytes each = {lo.x[4]} {lo.y[4]} {lo.z[4]} {hi.x[4]} {hi.y[4]} {hi.z[4]}
+    // {slot links: quad index | LEAF + first leaf entry | NONE} {the same with compact leaf links}
     const float4 *quads;
     const uint32_t *quad_roots;   // per mesh
     uint32_t quad_stack_depth;    // words of LDS stack per lane
@@ -119,9 +111,6 @@ struct KernelArgs {
     const uint32_t *tiny_at, *tiny_flags;
     uint32_t tiny_count;
     uint32_t fixed0;              // level 0's shadow rays go to fixed, tile-ordered slots (kernel_stream.h: level0_shadow_slot)
-    const float4 *hloose;         // loose boxes of the hbox entries, same indexing
-    float scene_scale;            // largest coordinate magnitude of the scene's triangles
-    uint32_t prune;               // closest-hit walks skip subtrees whose loose box lies beyond the best hit so far
     // The top-level tree as a PLAN for the per-lane kernels (kernel_plan.h), built by crt_create when the tree is small
     // (top_fast) and its boxes are nested: the top-level LEAVES in visit order.  A ray reaches a leaf exactly when the leaf's
     // own box passes (nesting + monotone slab test, as for the mesh trees), so a wave tests its rays against leaf k with k
@@ -129,7 +118,6 @@ struct KernelArgs {
     uint32_t plan_ok;             // the plan kernels may be used
     uint32_t plan_leaves;         // number of top-level leaves, <= 64
     const float4 *plan_boxes;     // 2 x float4 per leaf: {lo, first entry in leaf_meshes} {hi, number of entries}
-    const uint2 *plan_shadow_masks;  // per leaf: the non-refractive meshes it lists, as bits of the shadow order below
     const uint32_t *plan_shadow_mesh;  // shadow order: bit b = mesh plan_shadow_mesh[b] (big meshes first: likeliest occluders)
     uint32_t plan_shadow_bits;    // number of non-refractive meshes, <= 64
     // compact forms (crt_create): 3 x float4 per leaf entry {v0,nx} {v1,ny} {v2,nz}; the nodes again with leaf links
@@ -138,24 +126,10 @@ struct KernelArgs {
     const float4 *ptris;
     const float4 *pnodes;
     uint32_t plan_list_words;     // LDS words per lane of a closest-hit ray's mesh list: ceil(meshes / 4)
-    // kernel_deep.h: the level-free queue of the recursion levels >= 1
     uint32_t use_gi, gi_samples, rays_per_pixel, gi_seed;  // crt_options: the GI / multi-sample mode (kernel_lane.h, gi_random.h)
     float monte_carlo_bias;
-    uint2 *s_shadow_plan;         // kernel_plan.h: stream_plan_shadow's result per level-0 shadow slot (crt_tuning::preplan)
-    uint32_t pre_bundle;          // ... and the refill threshold of the walk kernel that reads it
-    uint32_t pre_trips;           // ... and its loop trips between two looks at the refill condition
     uint32_t force_whole;         // this level's per-lane kernel was not launched: the wave-per-ray kernel takes all its rays (kernel_stream.h)
-    uint32_t skip_unlit;          // kernel_plan.h: shadow rays whose light factor is exactly zero are not walked (crt_tuning::skip_unlit)
-    uint32_t deep_first;          // kernel_deep.h: the first recursion level the persistent launch handles
     uint32_t wave_prio;           // s_setprio of the recursion levels' waves (crt_tuning::wave_priority)
-    uint32_t early_shadow;        // level 0: the bulk shadow pass starts before the evicted primary walks are finished (kernel_plan.h)
-    uint32_t pool_refill, pool_switch;  // kernel_pool.h: lanes with a free place that make a refill round worth it; lanes below which the wave changes mode
-    uint32_t node_repeat;         // kernel_plan.h shadow walk: node steps per loop trip (>= 1)
-    uint32_t tri_gather;          // kernel_plan.h shadow walk: lanes wait at a leaf until this many do (0: every trip runs both blocks)
-    uint32_t *s_ready;            // one word per slot of s_rayq[1]: == epoch once the slot's record has been published
-    uint32_t *s_ready2;           // the same for the heavy queue (s_rayq[0] during the deep launch)
-    uint32_t deep_heavy_every;    // deep_lanes: every n-th wave of a workgroup is a heavy wave
-    uint32_t epoch;               // this frame's tag (never 0; s_ready starts zeroed and is not cleared between frames)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -208,35 +182,6 @@ __device__ __forceinline__ bool mesh_walk_is_repeat(SeenMeshes &seen, uint32_t m
     const bool repeat = (word & bit) != 0;
     word |= bit;
     return repeat;
-}
-
-// ---- distance pruning of closest-hit walks -------------------------------------------------------------
-// The reference walks every leaf whose box the ray passes, whatever it has found so far (KDTree.cpp:53-74).
-// Only a hit with a STRICTLY smaller distance ever replaces the best one (KDTree.cpp:81, :162), so a subtree
-// that cannot contain such a hit may be skipped without changing the result.  "Cannot" is decided on the
-// subtree's LOOSE box (crt_device.hip: triangle_loose_box), which contains every point o + d*t the triangle
-// test can accept for any of the subtree's triangles -- not on the kd cell, which triangles stick out of.
-// For an accepted hit, p_i = fl(o_i + fl(d_i*t)) lies in the loose box; on an axis with |d_i| >= 0.01 that
-// gives t >= (c_i - o_i)/d_i - 2u(|o_i| + |p_i|)/|d_i| with c_i the box face the ray meets first, and the
-// computed (c_i - o_i)*inv_i is within 4u of that quotient (u = 2^-24).  prune_bound() returns the largest
-// such bound minus a margin three orders of magnitude above those error terms; a subtree is skipped only when
-// that value is >= the best distance so far.  NaN and infinite distances never skip anything.
-struct Prune {
-    float margin;
-    uint32_t bits;  // 1,2,4: the axis is used (|d| >= 0.01); 8,16,32: d > 0 on that axis (the near face is `lo`)
-};
-__device__ __forceinline__ void prune_prepare(Prune &P, const Ray &R, float scene_scale) {
-    P.bits = (fabsf(R.dx) >= 0.01f ? 1u : 0u) | (fabsf(R.dy) >= 0.01f ? 2u : 0u) | (fabsf(R.dz) >= 0.01f ? 4u : 0u) |
-             (R.dx > 0 ? 8u : 0u) | (R.dy > 0 ? 16u : 0u) | (R.dz > 0 ? 32u : 0u);
-    P.margin = 1e-3f * fmaxf(fmaxf(scene_scale, fabsf(R.ox)), fmaxf(fabsf(R.oy), fabsf(R.oz)));
-}
-// (cx, cy, cz): per axis the loose box's `lo` where d > 0, else its `hi`
-__device__ __forceinline__ float prune_bound(const Prune &P, const Ray &R, float cx, float cy, float cz) {
-    const float tx = (P.bits & 1u) ? (cx - R.ox) * R.ix : -INFINITY;
-    const float ty = (P.bits & 2u) ? (cy - R.oy) * R.iy : -INFINITY;
-    const float tz = (P.bits & 4u) ? (cz - R.oz) * R.iz : -INFINITY;
-    const float lb = fmaxf(fmaxf(tx, ty), tz);
-    return lb - (fabsf(lb) * 1e-4f + P.margin);
 }
 
 // BoundingBox::hasIntersection (BoundingBox.h:85-108).  The reference returns early per axis; t0 only

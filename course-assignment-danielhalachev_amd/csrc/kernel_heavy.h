@@ -26,8 +26,6 @@ struct HeavyState {   // all wave-uniform
     float mmin, mt;
     uint32_t mtri;
     uint32_t guard;   // remaining loop iterations for this ray: every loop of the walk is bounded by it
-    float tmin_scene; // closest-hit walks: best distance over the meshes walked so far (distance pruning, kernel_common.h)
-    Prune prune;
     bool stop;        // shadow walks: an accepted hit within the light's distance ends the walk (kernel_walk.h: shadow_hit_occludes)
     float light_dist;
     uint32_t nbox, ntri;  // tests executed for this ray (KernelArgs::exec_count)
@@ -141,16 +139,6 @@ __device__ __forceinline__ void heavy_chunk(const KernelArgs &A, const Ray &R, c
                                             const uint32_t chunk, const ChunkBoxes &C, HeavyState &H, const uint32_t lane) {
     if (A.exec_count) { H.nbox += (uint32_t)__popcll(__ballot(C.valid)); H.n_chunks++; }
     bool hit = C.valid && slab_test(R, C.b0.x, C.b0.y, C.b0.z, C.b1.x, C.b1.y, C.b1.z);
-    if (!SHADOW && (A.prune & 2u)) {
-        const float bound = fminf(H.tmin_scene, H.mmin);  // wave-uniform
-        if (bound < INFINITY && __ballot(hit)) {
-            const uint32_t idx = chunk * 64u + lane;
-            const size_t at = (size_t)M.first[LEVEL] + (C.valid ? idx : 0u);
-            const float4 l0 = A.hloose[2 * at], l1 = A.hloose[2 * at + 1];
-            const float cx = (H.prune.bits & 8u) ? l0.x : l1.x, cy = (H.prune.bits & 16u) ? l0.y : l1.y, cz = (H.prune.bits & 32u) ? l0.z : l1.z;
-            hit = hit && !(prune_bound(H.prune, R, cx, cy, cz) >= bound);
-        }
-    }
     if constexpr (LEVEL == 0) {
         if (__ballot(hit)) heavy_leaves<SHADOW>(A, R, primary, hit, __float_as_uint(C.b0.w), __float_as_uint(C.b1.w), H, lane);
     } else {
@@ -309,8 +297,6 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const TopRegs &T
     H.stop = false;
     H.light_dist = light_dist;
     H.nbox = 0; H.ntri = 0; H.n_chunks = 0; H.n_batches = 0; H.n_meshes = 0;
-    H.tmin_scene = INFINITY;
-    if (!SHADOW) prune_prepare(H.prune, R, A.scene_scale);
     TinyResults T;
     heavy_tiny_meshes<SHADOW>(A, R, primary, T, H, lane);
     const bool fast = A.top_fast != 0;
@@ -369,7 +355,7 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const TopRegs &T
                         if (len3(px - R.ox, py - R.oy, pz - R.oz) <= light_dist) occluded = true;
                     } else {
                         if (!have) { have = true; bt = H.mt; btri = H.mtri; bmesh = mi; }
-                        if (H.mt < tmin) { tmin = H.mt; bt = H.mt; btri = H.mtri; bmesh = mi; H.tmin_scene = tmin; }
+                        if (H.mt < tmin) { tmin = H.mt; bt = H.mt; btri = H.mtri; bmesh = mi; }
                     }
                 }
             }
@@ -390,10 +376,8 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const TopRegs &T
 __device__ __forceinline__ float uniform_f(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
 
 // closest hits of the rays evicted from stream_trace_shade(gen); results go to s_hits[k] for list entry k
-template <int WAVES_PER_SIMD>  // register budget: 5 = what the compiler takes by itself (91 VGPRs); 7 = 72 VGPRs with spills, which
-                               // lets three of these waves per SIMD (not two) sit beside the bulk shadow pass's four
-__global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void heavy_trace_closest(const KernelArgs A, const uint32_t gen) {
-    if (A.wave_prio) __builtin_amdgcn_s_setprio(3);  // crt_tuning::wave_priority: ahead of the bulk shadow pass's waves on this SIMD
+__global__ __launch_bounds__(BLOCK, 5) void heavy_trace_closest(const KernelArgs A, const uint32_t gen) {
+    if (A.wave_prio) __builtin_amdgcn_s_setprio(3);  // ahead of the bulk shadow pass's waves on this SIMD
     __shared__ TopLdsStorage top_storage;  // used when the top-level tree is too large for the registers and small enough for this
     TopLds TL;
     TL.fast = false;

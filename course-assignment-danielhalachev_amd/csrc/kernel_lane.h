@@ -1,7 +1,7 @@
 // kernel_lane.h -- render_lanes: one independent ray per lane.
 //
-// This kernel can render any pixel (it is the complete hot path); the packet kernel hands it the pixels
-// whose rays lose coherence (primary hit on a reflective / refractive mesh).  A lane owns a pixel until
+// This kernel can render any pixel (it is the complete hot path, queue-less): the fallback of the ray-stream pass after a
+// queue overflow, the GI mode, and crt_tuning::mode = lanes.  A lane owns a pixel until
 // its colour is final, walking the reference's recursion with an explicit frame stack
 // (RayTracer.cpp:358-451); a lane that finishes fetches the next pixel from a global counter, so a
 // wavefront stays full until the work runs out.
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(BLOCK) void render_lanes(const KernelArgs A) {
         if (!A.s_counts[SC_OVERFLOW_WORD]) return;
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(A.fallback_total, 1u);  // reported as crt_stats::fallback_frames
     }
-    const uint32_t total_px = A.use_deferred ? *A.deferred_count : A.n_items * 64u;
+    const uint32_t total_px = A.n_items * 64u;
 
     for (;;) {
         // ------------------------------------------------------------------ fetch new pixels
@@ -221,7 +221,6 @@ __global__ __launch_bounds__(BLOCK) void render_lanes(const KernelArgs A) {
                 base = __shfl(base, __ffsll((long long)need) - 1);
                 uint32_t q = base + (uint32_t)rank;
                 if (q >= total_px) { state = ST_DONE; break; }
-                if (A.use_deferred) q = A.deferred[q];
                 const WorkItem wi = A.items[q >> 6];
                 const uint32_t sub = q & 63u;
                 const uint32_t px = (wi.tile % A.tiles_x) * TILE + (sub & 7u);

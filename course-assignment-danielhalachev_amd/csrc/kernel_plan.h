@@ -26,7 +26,6 @@
 #pragma once
 
 #include "kernel_common.h"
-#include "kernel_packet.h"
 #include "kernel_stream.h"
 #include "kernel_walk.h"
 
@@ -44,9 +43,7 @@ __device__ __forceinline__ uint32_t leaf_cursor_next(uint32_t c) { return (c >> 
 
 // ---------------------------------------------------------------------------------------------------------------- shadow
 // the shadow rays [first, first + total) of the queue; `cursor` hands them out
-// PRE: the plans were computed by stream_plan_shadow (below) and are read back per ray; a refill then costs the wave a few loads
-// instead of the loop over the top-level leaves, and free lanes are refilled as soon as `pre_bundle` of them wait.
-template <bool PRE = false>
+constexpr uint32_t SHADOW_NODE_REPEAT = 2;  // node steps per loop trip (measured: 2 beats 1, 3 and 4)
 __device__ __forceinline__ void shadow_plan_walks(const KernelArgs &A, const uint32_t first, const uint32_t total, uint32_t *cursor) {
     __shared__ uint32_t root_of_bit[64];  // shadow order -> root node of the mesh's tree
     if (threadIdx.x < 64u) root_of_bit[threadIdx.x] = threadIdx.x < A.plan_shadow_bits ? A.meshes[A.plan_shadow_mesh[threadIdx.x]].root : END;
@@ -66,7 +63,7 @@ __device__ __forceinline__ void shadow_plan_walks(const KernelArgs &A, const uin
     for (;;) {
         // ---- refill: free lanes wait until no more than `bundle` lanes still walk, then fetch together (the plan below
         //      costs the wave the same for one new ray as for 64)
-        const uint32_t bundle = PRE ? A.pre_bundle : A.bundle;
+        const uint32_t bundle = A.bundle;
         if (__ballot(state == ST_FETCH) && (bundle >= 64u || (uint32_t)__popcll(__ballot(state == ST_TRAVERSE)) <= bundle)) {
             bool fresh = false;
             while (state == ST_FETCH) {
@@ -79,7 +76,7 @@ __device__ __forceinline__ void shadow_plan_walks(const KernelArgs &A, const uin
                 // intensity / area * 0 = +-0 times the albedo, and adding +-0 to the light sum -- which starts at +0 and can
                 // therefore never be -0 -- changes no bit of it (RayTracer.cpp:319-328).  Occluded or not, the pixel is the same:
                 // no walk.  (A NaN factor -- the light AT the surface -- is not zero and is walked.)
-                if (A.skip_unlit && q1.w == 0.0f) { A.s_occluded[r] = 0; continue; }
+                if (q1.w == 0.0f) { A.s_occluded[r] = 0; continue; }
                 R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
                 R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;  // already normalised once; shadow rays skip shootRay (RayTracer.cpp:313-317)
                 ray_prepare(R);
@@ -92,9 +89,8 @@ __device__ __forceinline__ void shadow_plan_walks(const KernelArgs &A, const uin
                 fresh = true;
                 steps = 0;
                 state = ST_TRAVERSE;
-                if (PRE) { const uint2 m = A.s_shadow_plan[r]; mlo = m.x; mhi = m.y; wn = END; we = NONE; }
             }
-            if (!PRE && fresh) {
+            if (fresh) {
                 // the plan: which meshes does this ray have to walk?  (k is wave-uniform: scalar loads, no gathers)
                 uint32_t lo = 0, hi = 0;
                 for (uint32_t k = 0; k < A.plan_leaves; k++) {
@@ -129,20 +125,8 @@ __device__ __forceinline__ void shadow_plan_walks(const KernelArgs &A, const uin
                 wn = (hit && !leaf) ? link : miss;
                 return true;
             };
-            const int trips = PRE ? (int)A.pre_trips : 64;  // (a lane whose walk ends waits for the end of this block of trips)
-            for (int it = 0; it < trips; ++it) {
-                // What a trip costs the wave is its vector-memory instructions (a divergent gather occupies the vector L1 for
-                // ~64 cycles however few lanes take part): 4 for the triangle block, 2 for the node block.  With tri_gather
-                // set, a trip runs ONE of the blocks: lanes that have reached a leaf wait there until tri_gather of them
-                // do (or nobody has a node left to test), then the triangle block runs with many lanes instead of a few.
-                bool run_tri = we != NONE, run_node = we == NONE;
-                if (A.tri_gather) {
-                    const unsigned long long at_leaf = __ballot(we != NONE), active = __ballot(1);
-                    const bool tri_trip = (uint32_t)__popcll(at_leaf) >= A.tri_gather || at_leaf == active;
-                    run_tri = run_tri && tri_trip;
-                    run_node = run_node && !tri_trip;
-                }
-                if (run_tri) {
+            for (int it = 0; it < 64; ++it) {  // (a lane whose walk ends waits for the end of this block of trips)
+                if (we != NONE) {
                     steps++;
                     // ---- one triangle of the current leaf (Ray.cpp:9-31, Triangle.cpp:37-57), branch-free
                     const float4 *T = reinterpret_cast<const float4 *>(ptris_b + (size_t)(leaf_cursor_entry(we) * 48u));
@@ -170,15 +154,15 @@ __device__ __forceinline__ void shadow_plan_walks(const KernelArgs &A, const uin
                     const bool ok = !(t < 0) && !(s0 < -FLT_EPSILON) && !(s1 < -FLT_EPSILON) && !(s2 < -FLT_EPSILON);
                     we = leaf_cursor_next(we);
                     if (ok && t < INFINITY && shadow_hit_occludes(R, px, py, pz, light_dist)) { occluded = true; done = true; break; }
-                } else if (run_node) {
+                } else {
                     steps++;
                     if (!node_step()) { done = true; break; }
                 }
                 // Further node steps in the same trip for the lanes that are (still) between leaves: a ray takes about two
                 // node steps per triangle step, and a node step costs the wave a third of a triangle step, so a trip of
                 // [triangle, node, node] keeps more lanes busy in the expensive block than [triangle, node] does.
-                for (uint32_t rep = 1; rep < A.node_repeat; rep++) {
-                    if (we == NONE && !(A.tri_gather && !run_node)) {
+                for (uint32_t rep = 1; rep < SHADOW_NODE_REPEAT; rep++) {
+                    if (we == NONE) {
                         steps++;
                         if (!node_step()) { done = true; break; }
                     }
@@ -204,55 +188,6 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shadow_plan(const KernelAr
     const uint32_t split = A.s_counts[SC_SHADOW_SPLIT];
     shadow_plan_walks(A, pass == 0 ? 0u : split, pass == 0 ? split : A.s_counts[SC_SHADOW] - split,
                       A.s_counts + (pass == 0 ? SC_SHADOW_FETCH : SC_SHADOW_FETCH2));
-}
-
-// The plans of pass 0's rays, one ray per thread with every lane busy: which meshes (bits of the shadow order) does the ray have
-// to walk?  Inside the walk kernel the same loop runs once per REFILL of a wave, whatever the number of lanes refilled, which is
-// why that kernel waits for many free lanes before it refills (KernelArgs::bundle) -- and why its lanes idle.  (crt_tuning::preplan)
-__global__ __launch_bounds__(BLOCK) void stream_plan_shadow(const KernelArgs A) {
-    if (A.s_counts[SC_OVERFLOW]) return;
-    const uint32_t split = A.s_counts[SC_SHADOW_SPLIT];
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t nplan = 0;
-    for (uint32_t base = (blockIdx.x * BLOCK + (threadIdx.x & ~63u)); base < split; base += gridDim.x * BLOCK) {  // wave-uniform trip count
-        const uint32_t r = base + lane;
-        const bool in = r < split;
-        const float4 q0 = A.s_shadowq[2 * (size_t)(in ? r : 0u)], q1 = A.s_shadowq[2 * (size_t)(in ? r : 0u) + 1];
-        Ray R;
-        R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
-        R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;
-        ray_prepare(R);
-        // (slots the walk kernel skips or hands to the wave-per-ray kernel get a plan nobody reads)
-        const bool used = in && __float_as_uint(q0.w) != SHADOW_SLOT_UNUSED && R.parmask == 0 && !(A.skip_unlit && q1.w == 0.0f);
-        if (__ballot(used)) {
-            uint32_t lo = 0, hi = 0;
-            for (uint32_t k = 0; k < A.plan_leaves; k++) {
-                const v16f L = plan_leaf(A, k);
-                const bool hit = slab_test_no_parallel(R, L[0], L[1], L[2], L[4], L[5], L[6]);
-                lo |= hit ? __float_as_uint(L[8]) : 0u;
-                hi |= hit ? __float_as_uint(L[9]) : 0u;
-            }
-            if (used) { A.s_shadow_plan[r] = make_uint2(lo, hi); if (A.exec_count) nplan += A.plan_leaves; }
-        }
-    }
-    exec_counters_flush(A, 0u, 0u, lane, nplan);
-}
-__global__ __launch_bounds__(BLOCK) void stream_trace_shadow_preplanned(const KernelArgs A) {
-    shadow_plan_walks<true>(A, 0u, A.s_counts[SC_SHADOW_SPLIT], A.s_counts + SC_SHADOW_FETCH);
-}
-
-// the shadow rays recursion level `gen` queued, alone: slots [SC_LSPLIT + gen, SC_LSPLIT + gen + 1).  Launched on the side
-// stream as soon as that level is done, beside the next levels, so that only the last level's shadow rays are left for the
-// end of the frame.
-__global__ __launch_bounds__(BLOCK) void stream_trace_shadow_level(const KernelArgs A, const uint32_t gen) {
-    const uint32_t begin = A.s_counts[SC_LSPLIT + gen], end = A.s_counts[SC_LSPLIT + gen + 1];
-    shadow_plan_walks(A, begin, end > begin ? end - begin : 0u, A.s_counts + SC_LFETCH + gen);
-}
-
-// ... and everything from recursion level `gen` on, at the end of the frame (crt_tuning::level_shadows >= 2)
-__global__ __launch_bounds__(BLOCK) void stream_trace_shadow_rest(const KernelArgs A, const uint32_t gen) {
-    const uint32_t begin = gen <= A.max_depth + 1u ? A.s_counts[SC_LSPLIT + gen] : A.s_counts[SC_SHADOW], end = A.s_counts[SC_SHADOW];
-    shadow_plan_walks(A, begin, end > begin ? end - begin : 0u, A.s_counts + SC_LFETCH + gen);
 }
 
 // ---------------------------------------------------------------------------------------------------------- closest hit
@@ -300,13 +235,6 @@ __device__ __forceinline__ uint32_t plan_list_pop(PlanList &PL) {
     return (PL.words[(i >> 2) * BLOCK] >> (8u * (i & 3u))) & 255u;
 }
 
-// early_shadow: the bulk shadow pass starts right after this kernel, before the wave-per-ray kernel has finished the primary
-// walks handed to it.  A primary ray that leaves here therefore gives its fixed shadow slots back (the pass skips them);
-// stream_shade_evicted queues that pixel's shadow rays behind the fixed region, where the later shadow pass finds them.
-__device__ __forceinline__ void early_shadow_release(const KernelArgs &A, const uint32_t gen, const uint32_t r) {
-    if (gen == 0u && A.early_shadow) level0_release_shadow_slots(A, r);
-}
-
 // Every ray of recursion level `gen`, one per lane: plan, walk of the listed meshes (quad or binary nodes), material
 // dispatch.  Same results and same queues as stream_trace_shade_lean; rays with a parallel axis, walks longer than the
 // step budget and (QUAD) walks that outgrow the LDS stack go to heavy_trace_closest.
@@ -327,15 +255,12 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArg
     const uint32_t child_base = node_base + count;
     const float4 *in_q = A.s_rayq[gen & 1u];
     const bool primary = gen == 0;
-    const bool todo = gen == 0 && A.use_packets;  // level 0 after stream_packets_gen0: only the tiles that kernel gave up on
-    const uint32_t fetch_count = todo ? A.s_counts[SC_TODO_TILES] * 64u : count;
     if (stream_level_is_whole_heavy(A, gen, count)) return;
     const char *nodes_b = reinterpret_cast<const char *>(A.pnodes);
     const char *quads_b = reinterpret_cast<const char *>(A.quads);
     const char *ptris_b = reinterpret_cast<const char *>(A.ptris);
 
     Ray R;
-    Prune prune;
     uint32_t wq = NONE, we = NONE, sp = 0, top = NONE;  // QUAD: quad to test, leaf entry, stack; binary: wq = next node (END: none)
     uint32_t mesh = NONE, mtri = 0, btri = 0, bmesh = 0;
     float mmin = INFINITY, mt = 0, tmin = INFINITY, bt = 0;
@@ -348,8 +273,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArg
             bool fresh = false;
             while (state == ST_FETCH) {
                 r = wave_fetch(A.s_counts + SC_FETCH + gen, lane);
-                if (r >= fetch_count) { state = ST_DONE; break; }
-                if (todo) r = A.s_todo_tiles[r >> 6] * 64u + (r & 63u);
+                if (r >= count) { state = ST_DONE; break; }
                 if (gen == 0) {
                     const WorkItem wi = A.items[r >> 6];
                     const uint32_t sub = r & 63u;
@@ -369,7 +293,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArg
                     ray_prepare(R);
                 }
                 if (R.parmask != 0) {
-                    if (evict_ray(A.s_heavy, A.s_heavy_cap, A.s_counts + SC_HEAVY + gen, r, lane)) { early_shadow_release(A, gen, r); continue; }
+                    if (evict_ray(A.s_heavy, A.s_heavy_cap, A.s_counts + SC_HEAVY + gen, r, lane)) continue;
                     A.s_counts[SC_OVERFLOW] = 1;  // cannot walk it here: let the fallback redo the frame
                     continue;
                 }
@@ -379,7 +303,6 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArg
             }
             if (fresh) {
                 plan_closest_meshes(A, R, PL, nplan);
-                if (QUAD) prune_prepare(prune, R, A.scene_scale);
                 wq = QUAD ? NONE : END; we = NONE; sp = 0; top = NONE; mesh = NONE;
                 mhave = false; mmin = INFINITY; mt = 0; mtri = 0;
                 have = false; tmin = INFINITY; bt = 0; btri = 0; bmesh = 0;
@@ -443,7 +366,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArg
                     if constexpr (QUAD) {
                         // ---- one quad: four boxes (BoundingBox.h:85-108), the slots that pass go on the stack, last first
                         if (sp + 4 > A.quad_stack_depth) { stack_full = true; break; }
-                        const float4 *Q = reinterpret_cast<const float4 *>(quads_b + (size_t)(uint32_t)(wq << 8));
+                        const float4 *Q = reinterpret_cast<const float4 *>(quads_b + (size_t)(uint32_t)(wq << 7));
                         const float4 lx = Q[0], ly = Q[1], lz = Q[2], hx = Q[3], hy = Q[4], hz = Q[5];
                         const uint4 lk = reinterpret_cast<const uint4 *>(Q)[7];  // slot links with compact leaf links
                         if (A.exec_count) nbox += (lk.x != NONE) + (lk.y != NONE) + (lk.z != NONE) + (lk.w != NONE);
@@ -451,16 +374,6 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArg
                         bool h1 = lk.y != NONE && slab_test_no_parallel(R, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y);
                         bool h2 = lk.z != NONE && slab_test_no_parallel(R, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z);
                         bool h3 = lk.w != NONE && slab_test_no_parallel(R, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w);
-                        if (A.prune & 1u) {
-                            const float bound = fminf(tmin, mmin);  // only a strictly smaller distance changes anything
-                            if (bound < INFINITY) {
-                                const float4 cx = Q[(prune.bits & 8u) ? 8 : 11], cy = Q[(prune.bits & 16u) ? 9 : 12], cz = Q[(prune.bits & 32u) ? 10 : 13];
-                                h0 = h0 && !(prune_bound(prune, R, cx.x, cy.x, cz.x) >= bound);
-                                h1 = h1 && !(prune_bound(prune, R, cx.y, cy.y, cz.y) >= bound);
-                                h2 = h2 && !(prune_bound(prune, R, cx.z, cy.z, cz.z) >= bound);
-                                h3 = h3 && !(prune_bound(prune, R, cx.w, cy.w, cz.w) >= bound);
-                            }
-                        }
 #define CRT_PPUSH(x)                                              \
     do {                                                          \
         if (sp > 0) stk[(sp - 1) * BLOCK] = top;                  \
@@ -505,10 +418,9 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArg
                 state = ST_FETCH;
             } else if (stack_full) {  // restart it in the wave-per-ray kernel, which needs no stack
                 if (!evict_ray(A.s_heavy, A.s_heavy_cap, A.s_counts + SC_HEAVY + gen, r, lane)) A.s_counts[SC_OVERFLOW] = 1;
-                else early_shadow_release(A, gen, r);
                 state = ST_FETCH;
             } else if (steps >= A.step_budget) {
-                if (evict_ray(A.s_heavy, A.s_heavy_cap, A.s_counts + SC_HEAVY + gen, r, lane)) { early_shadow_release(A, gen, r); state = ST_FETCH; }
+                if (evict_ray(A.s_heavy, A.s_heavy_cap, A.s_counts + SC_HEAVY + gen, r, lane)) state = ST_FETCH;
                 steps = 0;
             }
         }

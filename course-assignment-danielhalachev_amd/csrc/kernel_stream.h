@@ -21,7 +21,6 @@
 #include "kernel_common.h"
 #include "kernel_lane.h"
 #include "kernel_walk.h"
-#include "kernel_packet.h"
 
 struct TNode {          // one node of a pixel's ray tree, 32 bytes
     float cx, cy, cz;   // DIFFUSE: texture/albedo colour; REFLECT: albedo; after resolve of a REFRACT node: reflection colour
@@ -39,18 +38,11 @@ constexpr int MAX_GENERATIONS = 64;
 //   [SC_HEAVY + g] rays evicted to the heavy kernel at level g, [SC_HEAVY_FETCH + g] / [SC_EVICT_FETCH + g] their cursors
 enum : int { SC_COUNT = 0, SC_FETCH = MAX_GENERATIONS, SC_HEAVY = 2 * MAX_GENERATIONS, SC_HEAVY_FETCH = 3 * MAX_GENERATIONS,
              SC_EVICT_FETCH = 4 * MAX_GENERATIONS, SC_SHADOW = 5 * MAX_GENERATIONS, SC_SHADOW_FETCH, SC_OVERFLOW, SC_SHEAVY,
-             SC_SHEAVY_FETCH, SC_GUARD, SC_SHADOW_SPLIT, SC_SHADOW_FETCH2,
-             SC_TODO_TILES, SC_TODO_SHADOW, SC_TILE_FETCH, SC_SHEAVY_SPLIT,
-             SC_DEEP_TAIL0, SC_DEEP_CHAINED,  // kernel_deep.h
+             SC_SHEAVY_FETCH, SC_GUARD, SC_SHADOW_SPLIT, SC_SHADOW_FETCH2, SC_SHEAVY_SPLIT,
              SC_WORDS,
-             // kernel_deep.h's hot counters, each on a 128-byte line of its own (atomics on one line are served one by one)
-             SC_DEEP_HQ_HEAD = 352, SC_DEEP_DONE = 384, SC_DEEP_NODES = 416, SC_DEEP_WAITS = 448, SC_DEEP_HQ_TAIL = 480,
-             // per recursion level: where its shadow rays begin in the shadow queue ([g + 1] = where they end), fetch cursors
-             SC_LSPLIT = 512, SC_LFETCH = SC_LSPLIT + MAX_GENERATIONS + 1 + 31,
-             SC_HEAVY_DIAG = 704,  // diagnostics of a collect_counters == 2 render (kernel_heavy.h): 8 words closest-hit walks, 8 words shadow walks
-             SC_ALLOC_WORDS = 1024 };
-static_assert(SC_LFETCH + MAX_GENERATIONS <= SC_ALLOC_WORDS, "counter block too small");
-static_assert(SC_WORDS <= 352, "the deep kernel's counters start at word 384");
+             SC_HEAVY_DIAG = 384,  // diagnostics of a collect_counters == 2 render (kernel_heavy.h): 8 words closest-hit walks, 8 words shadow walks
+             SC_ALLOC_WORDS = 512 };
+static_assert(SC_WORDS <= SC_HEAVY_DIAG, "counter block too small");
 
 static_assert(SC_OVERFLOW == SC_OVERFLOW_WORD, "kernel_common.h SC_OVERFLOW_WORD must match");
 
@@ -167,11 +159,6 @@ __device__ __forceinline__ void shade_hit(const KernelArgs &A, const uint32_t ge
                     const size_t slot = (size_t)base + (size_t)li * cntd + rank;
                     A.s_shadowq[2 * slot] = make_float4(SR.ox, SR.oy, SR.oz, dist);
                     A.s_shadowq[2 * slot + 1] = make_float4(SR.dx, SR.dy, SR.dz, kfac);
-                    // after stream_packets_gen0, shadow pass 0 only walks the listed slots: a tile that kernel gave up
-                    // is shaded here by the per-lane kernel, which lists what it emits
-                    if (gen == 0 && A.fixed0 && A.use_packets && !out_diffuse &&
-                        !evict_ray(A.s_todo_shadow, A.s_shadow_cap, A.s_counts + SC_TODO_SHADOW, (uint32_t)slot, lane))
-                        A.s_counts[SC_OVERFLOW] = 1;
                 }
             }
         } else if (S.M.type == CRT_MAT_REFLECTIVE || S.M.type == CRT_MAT_REFRACTIVE) {
@@ -288,7 +275,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade(const KernelArgs A, 
     LaneWalk L;
     int state = ST_FETCH;
     uint32_t r = 0;
-    uint32_t steps = 0, max_steps = 0;  // counting build: longest single walk (diagnostic)
+    uint32_t steps = 0;
 
     for (;;) {
         // ------------------------------------------------------------------ fetch
@@ -337,7 +324,6 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade(const KernelArgs A, 
         // ------------------------------------------------------------------ shade, or hand a long walk to heavy_trace
         if (finished) {
             shade_and_emit<COUNT>(A, gen, r, node_base, child_base, R, L.have, L.bt, L.btri, L.bmesh, cnt, lane);
-            if (COUNT) { max_steps = steps > max_steps ? steps : max_steps; }
             steps = 0;
             state = ST_FETCH;
         } else if (state == ST_TRAVERSE && A.step_budget && steps >= A.step_budget) {
@@ -355,8 +341,6 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade(const KernelArgs A, 
     }
 
     if (COUNT) {
-        for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_down(max_steps, off); max_steps = o > max_steps ? o : max_steps; }
-        if (lane == 0) atomicMax(&A.counters[C_WAVE_NODES], (unsigned long long)max_steps);
         for (int k = 0; k < C_N; k++) {
             unsigned long long v = cnt[k];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
@@ -365,216 +349,10 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade(const KernelArgs A, 
     }
 }
 
-// stream_trace_shade with the lean walk (kernel_walk.h): the non-counting build when heavy_trace is available.
-// Rays with a parallel axis and walks longer than step_budget go to heavy_trace_closest.
-template <bool QUAD>
-__global__ __launch_bounds__(BLOCK) void stream_trace_shade_lean(const KernelArgs A, const uint32_t gen) {
-    if (A.wave_prio) __builtin_amdgcn_s_setprio(3);  // crt_tuning::wave_priority: ahead of the bulk shadow pass's waves on this SIMD
-    extern __shared__ uint32_t qstack[];  // QUAD: A.quad_stack_depth x BLOCK words
-    __shared__ TopLdsStorage top_storage;
-    const TopLds TL = top_lds_load(A, top_storage);  // (a barrier inside: before any return)
-    uint32_t *const stk = qstack + threadIdx.x;
-    const uint32_t lane = threadIdx.x & 63u;
-    if (A.s_counts[SC_OVERFLOW]) return;
-    const uint32_t count = stream_level_count(A, gen);
-    const uint32_t node_base = stream_level_base(A, gen);
-    const uint32_t child_base = node_base + count;
-    const float4 *in_q = A.s_rayq[gen & 1u];
-    const bool primary = gen == 0;
-    // level 0 after stream_packets_gen0: only the tiles that kernel gave up on
-    const bool todo = gen == 0 && A.use_packets;
-    const uint32_t fetch_count = todo ? A.s_counts[SC_TODO_TILES] * 64u : count;
-    // a small level is all tail: heavy_trace_closest walks every ray of it (it applies the same rule)
-    if (stream_level_is_whole_heavy(A, gen, count)) return;
-
-    Ray R;
-    typename std::conditional<QUAD, QuadWalk, LeanWalk>::type W;
-    W.nbox = 0; W.ntri = 0;
-    int state = ST_FETCH;
-    uint32_t r = 0, steps = 0;
-    for (;;) {
-        if (__ballot(state == ST_FETCH)) {
-            while (state == ST_FETCH) {
-                r = wave_fetch(A.s_counts + SC_FETCH + gen, lane);
-                if (r >= fetch_count) { state = ST_DONE; break; }
-                if (todo) r = A.s_todo_tiles[r >> 6] * 64u + (r & 63u);
-                if (gen == 0) {
-                    const WorkItem wi = A.items[r >> 6];
-                    const uint32_t sub = r & 63u;
-                    const uint32_t px = (wi.tile % A.tiles_x) * TILE + (sub & 7u);
-                    const uint32_t py = (wi.tile / A.tiles_x) * TILE + (sub >> 3);
-                    if (!((wi.mask >> sub) & 1ull) || px >= A.width || py >= A.height) {
-                        reinterpret_cast<uint32_t *>(A.s_nodes + 2 * (size_t)r)[3] = TN_SKIP;
-                        level0_release_shadow_slots(A, r);
-                        continue;
-                    }
-                    primary_ray(A, px, py, R);
-                } else {
-                    const float4 q0 = in_q[2 * (size_t)r], q1 = in_q[2 * (size_t)r + 1];
-                    R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
-                    R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;
-                    normalize3(R.dx, R.dy, R.dz);  // shootRay entry (RayTracer.cpp:420)
-                    ray_prepare(R);
-                }
-                if (R.parmask != 0) {
-                    if (evict_ray(A.s_heavy, A.s_heavy_cap, A.s_counts + SC_HEAVY + gen, r, lane)) continue;
-                    if (R.parmask != 0) { A.s_counts[SC_OVERFLOW] = 1; continue; }  // cannot walk it here: let the fallback redo the frame
-                }
-                lean_begin(W, A.top_root);
-                if constexpr (QUAD) prune_prepare(W.prune, R, A.scene_scale);
-                steps = 0;
-                state = ST_TRAVERSE;
-            }
-        }
-        if (!__ballot(state != ST_DONE)) break;
-        if (state == ST_TRAVERSE) {
-            const int w = quad_walk<false>(W, R, primary, A, TL, 64, steps, stk);
-            if (w == WALK_DONE) {
-                shade_and_emit<false>(A, gen, r, node_base, child_base, R, W.have, W.bt, W.btri, W.bmesh, nullptr, lane);
-                state = ST_FETCH;
-            } else if (w == WALK_STACK_FULL) {  // restart it in the wave-per-ray kernel, which needs no stack
-                if (!evict_ray(A.s_heavy, A.s_heavy_cap, A.s_counts + SC_HEAVY + gen, r, lane)) A.s_counts[SC_OVERFLOW] = 1;
-                state = ST_FETCH;
-            } else if (steps >= A.step_budget) {
-                if (evict_ray(A.s_heavy, A.s_heavy_cap, A.s_counts + SC_HEAVY + gen, r, lane)) state = ST_FETCH;
-                steps = 0;
-            }
-        }
-    }
-    exec_counters_flush(A, W.nbox, W.ntri, lane);
-}
-
-template <uint32_t pass, bool QUAD>  // `pass` is a template parameter so that the two passes are two kernels in a profile
-__global__ __launch_bounds__(BLOCK) void stream_trace_shadow_lean(const KernelArgs A) {
-    extern __shared__ uint32_t qstack[];  // QUAD: A.quad_stack_depth x BLOCK words
-    __shared__ TopLdsStorage top_storage;
-    const TopLds TL = top_lds_load(A, top_storage);  // (a barrier inside: before any return)
-    uint32_t *const stk = qstack + threadIdx.x;
-    const uint32_t lane = threadIdx.x & 63u;
-    if (A.s_counts[SC_OVERFLOW]) return;
-    // pass 0: after stream_packets_gen0, the shadow walks that kernel gave up on (a list of queue slots);
-    //         otherwise the queue below the split mark.  pass 1: the queue from the split mark on.
-    const uint32_t split = A.s_counts[SC_SHADOW_SPLIT];
-    const bool listed = pass == 0 && A.use_packets;
-    const uint32_t first = pass == 0 ? 0u : split;
-    const uint32_t total = listed ? A.s_counts[SC_TODO_SHADOW] : (pass == 0 ? split : A.s_counts[SC_SHADOW] - split);
-    uint32_t *cursor = A.s_counts + (pass == 0 ? SC_SHADOW_FETCH : SC_SHADOW_FETCH2);
-    Ray R;
-    typename std::conditional<QUAD, QuadWalk, LeanWalk>::type W;
-    W.nbox = 0; W.ntri = 0;
-    int state = ST_FETCH;
-    uint32_t r = 0, steps = 0;
-    for (;;) {
-        // Refill: free lanes wait until no more than `bundle` lanes of the wave are still walking, then all of them fetch at
-        // once -- consecutive slots, i.e. (pass 0) neighbouring pixels' rays towards one light, which stay together in the
-        // tree.  bundle >= 64: every lane fetches as soon as it is free.
-        if (__ballot(state == ST_FETCH) && (A.bundle >= 64u || (uint32_t)__popcll(__ballot(state == ST_TRAVERSE)) <= A.bundle)) {
-            while (state == ST_FETCH) {
-                r = wave_fetch(cursor, lane);
-                if (r >= total) { state = ST_DONE; break; }
-                r = listed ? A.s_todo_shadow[r] : r + first;
-                const float4 q0 = A.s_shadowq[2 * (size_t)r], q1 = A.s_shadowq[2 * (size_t)r + 1];
-                if (__float_as_uint(q0.w) == SHADOW_SLOT_UNUSED) continue;  // a level-0 pixel without a diffuse hit
-                R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
-                R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;  // already normalised once; shadow rays skip shootRay (RayTracer.cpp:313-317)
-                ray_prepare(R);
-                if (R.parmask != 0) {
-                    if (evict_ray(A.s_sheavy, A.s_heavy_cap, A.s_counts + SC_SHEAVY, r, lane)) continue;
-                    A.s_counts[SC_OVERFLOW] = 1;
-                    continue;
-                }
-                lean_begin(W, A.top_root);
-                W.light_dist = q0.w;
-                steps = 0;
-                state = ST_TRAVERSE;
-            }
-        }
-        if (!__ballot(state != ST_DONE)) break;
-        if (state == ST_TRAVERSE) {
-            const int w = quad_walk<true>(W, R, false, A, TL, 64, steps, stk);
-            if (w == WALK_DONE) {
-                A.s_occluded[r] = W.occluded ? 1 : 0;
-                state = ST_FETCH;
-            } else if (w == WALK_STACK_FULL) {
-                if (!evict_ray(A.s_sheavy, A.s_heavy_cap, A.s_counts + SC_SHEAVY, r, lane)) A.s_counts[SC_OVERFLOW] = 1;
-                state = ST_FETCH;
-            } else if (steps >= A.step_budget) {
-                if (evict_ray(A.s_sheavy, A.s_heavy_cap, A.s_counts + SC_SHEAVY, r, lane)) state = ST_FETCH;
-                steps = 0;
-            }
-        }
-    }
-    exec_counters_flush(A, W.nbox, W.ntri, lane);
-}
-
-// Recursion level 0 by PACKETS (kernel_packet.h): one wave per 8x8 tile walks the tree once for the tile's 64
-// primary rays and once per light for the shadow rays of its diffuse hits, fetching nodes and triangles with
-// scalar loads -- a different memory path from the per-lane kernels' vector gathers.  A walk that needs more
-// than packet_budget wave-level visits is abandoned (its rays have lost coherence, and one wave would hold the
-// launch): an abandoned primary walk puts the tile on s_todo_tiles for stream_trace_shade_lean(0), an abandoned
-// shadow walk puts its queue slots on s_todo_shadow for stream_trace_shadow_lean pass 0.  Everything else --
-// ray-tree nodes, child rays, shadow-ray records -- is produced by the same shade_and_emit as the other kernels.
-__global__ __launch_bounds__(BLOCK) void stream_packets_gen0(const KernelArgs A) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t count = A.n_items * 64u;
-    // static round-robin over the tiles: wave w takes items w, w + n_waves, ...  (no `continue` / `break` on
-    // wave-uniform conditions inside this loop: see DESIGN.md "compiler notes")
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
-    const uint32_t n_waves = gridDim.x * (BLOCK / 64);
-    for (uint32_t item = wave; item < A.n_items; item += n_waves) {
-        const WorkItem wi = A.items[item];
-        const uint32_t px = (wi.tile % A.tiles_x) * TILE + (lane & 7u);
-        const uint32_t py = (wi.tile / A.tiles_x) * TILE + (lane >> 3);
-        const bool on = ((wi.mask >> lane) & 1ull) && px < A.width && py < A.height;
-        const uint32_t r = item * 64u + lane;
-        Ray R;
-        primary_ray(A, px, py, R);
-        bool have, occluded;
-        float bt = 0;
-        uint32_t btri = 0, bmesh = 0;
-        int budget = (int)A.packet_budget;
-        packet_walk<false, true, false>(A, R, on, 0.0f, have, bt, btri, bmesh, occluded, nullptr, budget);
-        const bool gave_up = __builtin_amdgcn_readfirstlane(budget < 0 ? 1 : 0) != 0;
-        if (gave_up) {  // the whole tile goes to the per-lane kernel
-            if (lane == 0) A.s_todo_tiles[atomicAdd(A.s_counts + SC_TODO_TILES, 1u)] = item;
-        } else {
-            bool diffuse = false;
-            uint32_t first = 0, stride = 0;
-            if (on) shade_and_emit<false>(A, 0u, r, 0u, count, R, have, bt, btri, bmesh, nullptr, lane, &diffuse, &first, &stride);
-            else { reinterpret_cast<uint32_t *>(A.s_nodes + 2 * (size_t)r)[3] = TN_SKIP; level0_release_shadow_slots(A, r); }
-            if (__ballot(diffuse)) {
-                for (uint32_t li = 0; li < A.n_lights; li++) {
-                    const size_t slot = (size_t)first + (size_t)li * stride;
-                    Ray SR;
-                    float dist = 0;
-                    if (diffuse) {  // the record shade_and_emit has just written (this lane's own store)
-                        const float4 q0 = A.s_shadowq[2 * slot], q1 = A.s_shadowq[2 * slot + 1];
-                        SR.ox = q0.x; SR.oy = q0.y; SR.oz = q0.z; dist = q0.w;
-                        SR.dx = q1.x; SR.dy = q1.y; SR.dz = q1.z;
-                    } else { SR.ox = SR.oy = SR.oz = 0; SR.dx = SR.dy = 0; SR.dz = 1; }
-                    ray_prepare(SR);
-                    bool shave, socc;
-                    float st;
-                    uint32_t stri, smesh;
-                    int sbudget = (int)A.packet_budget;
-                    packet_walk<true, false, false>(A, SR, diffuse, dist, shave, st, stri, smesh, socc, nullptr, sbudget);
-                    const bool sgave_up = __builtin_amdgcn_readfirstlane(sbudget < 0 ? 1 : 0) != 0;
-                    if (diffuse) {
-                        if (!sgave_up) A.s_occluded[slot] = socc ? 1 : 0;
-                        else evict_ray(A.s_todo_shadow, A.s_shadow_cap, A.s_counts + SC_TODO_SHADOW, (uint32_t)slot, lane);
-                    }
-                }
-            }
-        }
-    }
-}
-
 // Shading of the rays stream_trace_shade(gen) evicted, after heavy_trace_closest(gen) has found their hits.
 template <bool COUNT>
 __global__ __launch_bounds__(BLOCK) void stream_shade_evicted(const KernelArgs A, const uint32_t gen) {
-    if (A.wave_prio) __builtin_amdgcn_s_setprio(3);  // crt_tuning::wave_priority: ahead of the bulk shadow pass's waves on this SIMD
-    // (early_shadow, kernel_plan.h: level 0's fixed shadow slots are being read already, so the host passes level 0's launch
-    // a copy of the arguments with fixed0 = 0 and this pixel's shadow rays are queued)
+    if (A.wave_prio) __builtin_amdgcn_s_setprio(3);  // ahead of the bulk shadow pass's waves on this SIMD
     const uint32_t lane = threadIdx.x & 63u;
     if (A.s_counts[SC_OVERFLOW]) return;
     const uint32_t count = stream_level_count(A, gen);

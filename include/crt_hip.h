@@ -173,69 +173,25 @@ typedef struct crt_ctx crt_ctx;
 
 /* Kernel selection and sizing.  Nothing here changes a pixel: every combination renders the same frame bit for
  * bit (tests/test_gpu_parity.py runs the matrix); the defaults are what bench.py measures.  The reference has no
- * counterpart (its only tunables are RenderOptions, above); the library reads NO environment variables. */
-enum { CRT_MODE_STREAM = 0, CRT_MODE_PACKETS = 1, CRT_MODE_LANES = 2 };
+ * counterpart (its only tunables are RenderOptions, above); the library reads NO environment variables.
+ * (Round 2's 43 fields selected between ~20 kernel variants; the variants that lost their measurements were removed --
+ * DESIGN.md section 7 keeps the numbers, git keeps the code -- and their constants are now constants.) */
+enum { CRT_MODE_STREAM = 0, CRT_MODE_LANES = 1 };
 typedef struct crt_tuning {
     uint32_t size;            /* sizeof(crt_tuning), filled in by crt_tuning_defaults */
-    uint32_t mode;            /* CRT_MODE_STREAM (ray stream, default) | _PACKETS (wave per 8x8 tile) | _LANES (full recursion per lane) */
+    uint32_t mode;            /* CRT_MODE_STREAM (ray stream, default) | CRT_MODE_LANES (full recursion per lane, queue-less) */
     uint32_t step_budget;     /* 256: steps after which a closest-hit walk goes to the wave-per-ray kernel; 0 = faithful kernels only */
     uint32_t shadow_budget;   /* 4096: cap of the same for the bulk shadow pass (the launch scales it down with its size) */
-    uint32_t pass1_budget;    /* 0 (= step_budget): cap for the second shadow pass */
+    uint32_t level0_budget;   /* 0 (= min(step_budget, what a lane gets through in the launch)): the same for PRIMARY rays */
     uint32_t heavy_level;     /* 100000: recursion levels with fewer rays skip the per-lane kernel */
-    uint32_t heavy_blocks;    /* 4096: grid of the wave-per-ray kernels */
     uint32_t side_blocks;     /* 3: workgroups per CU of the bulk shadow pass on the side stream; 0 = no side stream */
-    uint32_t quad;            /* 1: which lean kernels walk quad nodes (bit 0 levels, 1 bulk shadow pass, 2 second shadow pass) */
-    uint32_t quad_stack;      /* 16: LDS words per lane of the quad walk's stack (4..60) */
-    uint32_t prune;           /* 0: exact distance pruning of closest-hit walks (bit 0 quad walk, bit 1 wave-per-ray) */
-    uint32_t bundle;          /* 16: the bulk shadow pass refills a wave when at most this many lanes still walk (64: lane by lane) */
-    uint32_t fixed0;          /* 1: level 0's shadow rays in fixed tile-ordered slots (0: queued like the deeper levels') */
-    uint32_t packet_budget;   /* 0: level 0 by packets first, giving a tile up after this many wave-level visits */
-    uint32_t path_mask;       /* 0: path selection for tests: 256 = no lean kernels, 512 = no packets */
-    uint32_t top_in_registers; /* 1: small top-level trees are held in registers / LDS */
-    uint32_t tiny_meshes;     /* 1: single-leaf meshes are tested in one step by the wave-per-ray kernels */
-    uint32_t node_cap, ray_cap, shadow_cap; /* 0 = sized from the frame (4x / 3x / n_lights x 4x the pixels, at least 2^20);
-                                             * smaller values make queue overflow -- and the fallback -- reachable in tests */
-    uint32_t deep;            /* 0: one launch triple per recursion level; 1: recursion levels >= 1 run as ONE persistent
-                               * queue-driven launch (no level barriers), one ray per wave; 2: the same with one ray per lane
-                               * and heavy waves for the long walks */
-    uint32_t deep_blocks;     /* 0 (= 4 per CU): workgroups of that launch */
-    uint32_t plan;            /* 1: the per-lane kernels evaluate a small top-level tree as a plan (its leaves tested in a
-                               * wave-uniform loop) instead of walking it node by node per lane */
-    uint32_t deep_waves;      /* 5: register budget of that launch in waves per SIMD (4 or 5) */
-    uint32_t tri_gather;      /* 0: the planned shadow walk runs its triangle and its node block on every loop trip; N: one block
-                               * per trip, lanes wait at a leaf until N of them do (fewer, fuller triangle trips) */
-    uint32_t deep_heavy_every; /* 4: deep == 2 only: every n-th wave of a workgroup (n = 2..4) takes the long walks, one ray per wave */
-    uint32_t level0_budget;   /* 0 (= min(step_budget, what a lane gets through in the launch)): steps after which a PRIMARY ray's
-                               * walk goes to the wave-per-ray kernel */
-    uint32_t node_repeat;     /* 2: node steps per loop trip of the planned shadow walk (one triangle step per trip) */
-    uint32_t heavy_waves;     /* 5: register budget of the deeper levels' wave-per-ray launches in waves per SIMD (4, 5 or 7) */
-    uint32_t level_shadows;   /* 0: all the deeper levels' shadow rays in one pass at the end of the frame; 1: a deeper level's shadow
-                               * rays are queued on the side stream (behind the bulk pass) as soon as the level is done; n >= 2: the shadow
-                               * rays of the levels 1..n each on a THIRD stream as soon as the level is done, beside the bulk pass, and one
-                               * pass over the later levels' at the end */
-    uint32_t pool;            /* shadow walks with three rays per lane (kernel_pool.h): bit 0 the bulk pass, bit 1 the deeper levels' */
-    uint32_t pool_refill;     /* 48: lanes with a free place that make a refill round of that kernel worth it */
-    uint32_t pool_switch;     /* 24: lanes below which its wave changes between node and triangle mode */
-    uint32_t early_shadow;    /* 0; 1: the bulk shadow pass starts straight after level 0's per-lane kernel, and the primary walks handed to
-                               * the wave-per-ray kernel queue their shadow rays for the later pass instead of using their fixed slots */
-    uint32_t deep_first;      /* 1: with `deep`, the first recursion level the persistent launch handles (the levels before it run level by
-                               * level) */
-    uint32_t level_grid;      /* 1: the per-lane launch of a deeper level is sized by the rays that level held in the previous frame; 2: and
-                               * left out altogether when that was less than half of heavy_level (the wave-per-ray kernel then takes the
-                               * whole level whatever it holds; measured: no gain over 1); 0: always the full grid */
-    uint32_t skip_unlit;      /* 1: a shadow ray towards a light behind its surface (light factor exactly 0: the pixel is the same occluded or
-                               * not) is not walked by the planned shadow kernels */
-    uint32_t autotune;        /* 1: three settings whose best value depends on the scene (level 0's step budget, heavy_level, side_blocks 3 / 4) are tried on the frames
-                               * themselves -- a dozen frames each, timed by the events every frame records -- and the faster setting is kept
-                               * (crt_device.hip: autotune_step); off when level0_budget, heavy_level or step_budget are given explicitly; side_blocks is only
-                               * tried from its default of 3 */
-    uint32_t preplan;         /* 1: the bulk shadow pass's plans (which meshes a ray must walk) are computed by a launch of their own, one ray
-                               * per thread, and read back by the walk kernel, whose refills then cost a few loads (8 B per shadow slot) */
-    uint32_t pre_bundle;      /* 48: that walk kernel refills a wave when at most this many lanes still walk */
-    uint32_t pre_trips;       /* 16: ... and looks at that condition every so many loop trips (the kernel that plans inside the walk: 64) */
-    uint32_t wave_priority;   /* 3 (0..3): s_setprio of the recursion levels' waves (the frame's critical path) over the bulk shadow pass's, which
-                               * shares the SIMDs with them */
-    uint32_t side_priority;   /* 1 (0 = default priority): the side stream (bulk shadow pass) is created with the lowest stream priority */
+    uint32_t quad;            /* 1: the levels' per-lane kernel walks quad nodes; 0: binary nodes */
+    uint32_t node_cap, ray_cap, shadow_cap; /* 0 = the queues follow the frames; explicit values make
+                                             * queue overflow -- and the fallback -- reachable in tests */
+    uint32_t autotune;        /* 1: three settings whose best value depends on the scene (level 0's step budget, heavy_level, side_blocks 3 / 4)
+                               * are tried on the frames themselves -- a dozen frames each, timed by the events every frame records -- and
+                               * the faster setting is kept (crt_device.hip: autotune_step); off when level0_budget, heavy_level or
+                               * step_budget are given explicitly; side_blocks is only tried from its default of 3 */
 } crt_tuning;
 void crt_tuning_defaults(crt_tuning *tuning);
 
@@ -362,13 +318,11 @@ int crt_test_gi(int device, uint32_t what, const uint32_t *a, const uint32_t *b,
 
 /* Diagnostics for the development tools under tools/ (no counterpart in the reference; not needed to render):
  * the ray-stream pass's queue counters of the last frame (rays per recursion level, walks handed to the
- * wave-per-ray kernels, ...: the SC_* layout of csrc/kernel_stream.h, at most 512 words), and the packet kernel's
- * wave-level visit counts {nodes, triangles, walks} of the last counted render. */
+ * wave-per-ray kernels, ...: the SC_* layout of csrc/kernel_stream.h, at most 512 words). */
 int crt_debug_stream_counts(crt_ctx *ctx, uint32_t *out_words, uint32_t max_words);
 /* which kernels a production frame of this context runs, e.g. "level0=stream_trace_shade_plan<true>;shadow0=stream_trace_shadow_plan<0u>;
  * levels=heavy_trace_closest<5>" (names as rocprofv3 prints them) */
 int crt_describe_kernels(const crt_ctx *ctx, char *out, size_t size);
-int crt_debug_packet_counters(crt_ctx *ctx, uint64_t out[3]);
 
 #ifdef __cplusplus
 }

@@ -53,48 +53,18 @@ def test_ppm_file_matches_reference_bytes(pkg, scenes, tmp_path):
     assert open(path, "rb").read() == g["ppm"]
 
 
-# kernel paths, selected through crt_tuning (include/crt_hip.h); mode: 1 = packets, 2 = lanes
+# kernel paths, selected through crt_tuning (include/crt_hip.h); mode: 1 = lanes
 KERNEL_PATHS = [
-    dict(mode=2),                                                # recursive one-ray-per-lane kernel for every pixel
-    dict(mode=1),                                                # wave-per-tile packets + lanes for the deferred pixels
-    dict(step_budget=8, shadow_budget=8),                        # nearly every walk through the wave-per-ray kernels
+    dict(mode=1),                                                # recursive one-ray-per-lane kernel for every pixel (the queue-less fallback)
+    dict(step_budget=8, shadow_budget=8, level0_budget=8),       # nearly every walk through the wave-per-ray kernels
     dict(step_budget=0),                                         # wave-per-ray kernels off: faithful stream kernels
     dict(heavy_level=1000000),                                   # deeper levels entirely by the wave-per-ray kernel
-    dict(packet_budget=60, step_budget=64),                      # level 0 by packets, most walks abandoned to the stream
-    dict(packet_budget=100000),                                  # level 0 by packets, nothing abandoned
+    dict(heavy_level=0),                                         # ... entirely by the per-lane kernel first
+    dict(heavy_level=3000),                                      # ... some levels straddle the threshold
     dict(side_blocks=0),                                         # no side stream
-    dict(quad=7, heavy_level=0),                                 # quad-node walk in every lean kernel
-    dict(quad=7, quad_stack=4, heavy_level=0),                   # ... with a stack so short that walks overflow into heavy_trace
-    dict(quad=0, heavy_level=0),                                 # binary lean walk
-    dict(prune=3),                                               # closest-hit walks with distance pruning
-    dict(step_budget=100000, shadow_budget=100000, heavy_level=0),  # nothing evicted: lean kernels alone
-    dict(deep=0),                                                # one launch triple per recursion level (no persistent deep kernel)
-    dict(deep=0, heavy_level=0),                                 # ... with the per-lane kernels at every level
-    dict(deep=1, deep_blocks=3),                                 # persistent deep kernel on a tiny grid
-    dict(deep=1, deep_waves=4, deep_blocks=4096),                # ... with its natural register budget, on a grid larger than the chip
-    dict(deep=1, deep_first=3),                                  # ... only from recursion level 3 on (levels 0-2 level by level)
-    dict(deep=1, deep_first=2, wave_priority=0, side_priority=0),# ... from level 2 on; no wave / stream priorities
-    dict(deep=1, deep_first=20),                                 # ... beyond the recursion depth: never launched
-    dict(deep=2),                                                # persistent deep kernel, one ray per lane + heavy waves
-    dict(deep=2, deep_first=2),                                  # ... from level 2 on (the queues swap roles)
-    dict(deep=2, step_budget=8),                                 # ... nearly every walk handed to the heavy waves
-    dict(deep=2, deep_blocks=2, deep_heavy_every=2, bundle=64),  # ... two workgroups, half the waves heavy, lanes refill one by one
-    dict(deep=2, deep_waves=4, deep_blocks=4096, bundle=0),      # ... a grid larger than the chip; lanes refill only when the wave is empty
-    dict(top_in_registers=0, tiny_meshes=0),                     # top-level tree and single-leaf meshes read from memory
-    dict(fixed0=0, bundle=64),                                   # level 0's shadow rays queued; lanes refill one by one
-    dict(node_repeat=1), dict(node_repeat=4, tri_gather=24),     # shadow walk: node steps per trip, exclusive triangle trips
-    dict(pool=3), dict(pool=1, pool_refill=1, pool_switch=64),   # shadow walks with three rays per lane (kernel_pool.h)
-    dict(pool=3, pool_refill=64, pool_switch=1, level_shadows=1),
-    dict(early_shadow=1), dict(early_shadow=1, level0_budget=16, shadow_cap=1 << 20),  # bulk shadow pass after / before the evicted primary walks
-    dict(level_grid=2),                                          # the deeper levels' per-lane launches left out where the level was small a frame ago
-    dict(level_grid=2, heavy_level=3000),                        # ... here some levels straddle the threshold
-    dict(preplan=1),                                             # the bulk shadow pass's plans by a launch of their own
-    dict(preplan=1, pre_bundle=63, shadow_budget=8),             # ... lanes refilled one by one; nearly every walk handed to the wave-per-ray kernel
-    dict(skip_unlit=0),                                          # shadow rays towards lights behind their surface walked like the others
-    dict(level_shadows=2),                                       # levels 1-2's shadow rays on a third stream beside the bulk pass, the rest at the end
-    dict(level_shadows=4, wave_priority=2, level_grid=0),        # ... levels 1-4's
-    dict(level_shadows=1),                                       # the deeper levels' shadow rays in one pass at the end
-    dict(heavy_waves=7),                                         # deeper levels' wave-per-ray launches on a 72-register budget
+    dict(quad=0, heavy_level=0),                                 # binary per-lane walk
+    dict(step_budget=100000, shadow_budget=100000, heavy_level=0),  # nothing evicted: per-lane kernels alone
+    dict(autotune=0, side_blocks=4),                             # fixed settings
 ]
 
 
@@ -118,37 +88,14 @@ def test_queue_overflow_hands_the_frame_to_the_fallback(pkg, scenes, oracle, cap
     whole frame without queues.  Same pixels, and crt_stats says that the fallback ran."""
     scene, depth, _ = small_case(scenes, "hw11")
     want, _ = oracle.OracleScene(scenes.to_blob(scene)).render(depth)
-    for deep in (0, 1, 2):
-        tracer = make_tracer(pkg, scenes, scene, tuning=dict(caps, deep=deep))
-        assert_same_floats(tracer.render(max_depth=depth), want, "overflow %r deep=%d" % (caps, deep))
-        assert tracer.stats().fallback_frames == 1
-        assert_same_floats(tracer.render(max_depth=depth), want, "overflow again %r" % (caps,))
-        assert tracer.stats().fallback_frames == 2
+    tracer = make_tracer(pkg, scenes, scene, tuning=caps)
+    assert_same_floats(tracer.render(max_depth=depth), want, "overflow %r" % (caps,))
+    assert tracer.stats().fallback_frames == 1
+    assert_same_floats(tracer.render(max_depth=depth), want, "overflow again %r" % (caps,))
+    assert tracer.stats().fallback_frames == 2
     roomy = make_tracer(pkg, scenes, scene)
     assert_same_floats(roomy.render(max_depth=depth), want, "default capacities")
     assert roomy.stats().fallback_frames == 0
-
-
-def test_deep_queue_overflow_hands_the_frame_to_the_fallback(pkg, scenes, oracle):
-    """The persistent deep kernel (kernel_deep.h) runs out of queue slots / ray-tree nodes in the middle of its work: every
-    wave must still leave (none may wait for a ray that will never be published) and the fallback redoes the frame."""
-    SC_DEEP_TAIL0, SC_LEVEL1_SLOTS = 332, 1                                # csrc/kernel_stream.h
-    scene, depth, _ = small_case(scenes, "hw11")
-    want, _ = oracle.OracleScene(scenes.to_blob(scene)).render(depth)
-    roomy = make_tracer(pkg, scenes, scene, tuning=dict(deep=1))
-    assert_same_floats(roomy.render(max_depth=depth), want, "roomy")
-    assert roomy.stats().fallback_frames == 0
-    counts = roomy.stream_counts()
-    level1, slots = int(counts[SC_DEEP_TAIL0]), int(counts[SC_LEVEL1_SLOTS])
-    assert 0 < level1 < slots                                              # transmission rays were published behind level 1's
-    pixels = scene["settings"]["image_settings"]["width"] * scene["settings"]["image_settings"]["height"]
-    padded = ((scene["settings"]["image_settings"]["width"] + 7) // 8) * ((scene["settings"]["image_settings"]["height"] + 7) // 8) * 64
-    for deep in (1, 2):
-        for caps in (dict(ray_cap=level1 + 7), dict(ray_cap=(level1 + slots) // 2), dict(node_cap=padded + level1 + 5)):
-            tracer = make_tracer(pkg, scenes, scene, tuning=dict(caps, deep=deep))
-            assert_same_floats(tracer.render(max_depth=depth), want, "deep overflow %r" % (caps,))
-            assert tracer.stats().fallback_frames == 1, (deep, caps)
-    assert pixels <= padded
 
 
 def test_depth_rule_and_bias_options(pkg, scenes, oracle):
