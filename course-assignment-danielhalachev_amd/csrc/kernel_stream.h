@@ -38,7 +38,7 @@ constexpr int MAX_GENERATIONS = 64;
 //   [SC_HEAVY + g] rays evicted to the heavy kernel at level g, [SC_HEAVY_FETCH + g] / [SC_EVICT_FETCH + g] their cursors
 enum : int { SC_COUNT = 0, SC_FETCH = MAX_GENERATIONS, SC_HEAVY = 2 * MAX_GENERATIONS, SC_HEAVY_FETCH = 3 * MAX_GENERATIONS,
              SC_EVICT_FETCH = 4 * MAX_GENERATIONS, SC_SHADOW = 5 * MAX_GENERATIONS, SC_SHADOW_FETCH, SC_OVERFLOW, SC_SHEAVY,
-             SC_SHEAVY_FETCH, SC_GUARD, SC_SHADOW_SPLIT, SC_SHADOW_FETCH2, SC_SHEAVY_SPLIT,
+             SC_SHEAVY_FETCH, SC_SHEAVY_FETCH2, SC_GUARD, SC_SHADOW_SPLIT, SC_SHADOW_FETCH2, SC_SHEAVY_SPLIT,
              SC_WORDS,
              SC_HEAVY_DIAG = 384,  // diagnostics of a collect_counters == 2 render (kernel_heavy.h): 8 words closest-hit walks, 8 words shadow walks
              SC_ALLOC_WORDS = 512 };

@@ -192,6 +192,7 @@ typedef struct crt_tuning {
                                * are tried on the frames themselves -- a dozen frames each, timed by the events every frame records -- and
                                * the faster setting is kept (crt_device.hip: autotune_step); off when level0_budget, heavy_level or
                                * step_budget are given explicitly; side_blocks is only tried from its default of 3 */
+    uint32_t bfs;             /* 1: the walks a recursion level hands over run level-synchronously (csrc/kernel_bfs.h); 0: one ray per wave */
 } crt_tuning;
 void crt_tuning_defaults(crt_tuning *tuning);
 

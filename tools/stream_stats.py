@@ -17,15 +17,13 @@ L = pkg.lib(); L.crt_debug_stream_counts.argtypes = [C.c_void_p, C.POINTER(C.c_u
 L.crt_debug_stream_counts(tr.ctx, out, 512)
 print('rays per level   ', [out[g] for g in range(depth + 2)])
 print('evicted per level', [out[128 + g] for g in range(depth + 1)])
-print('todo tiles', out[328], 'todo shadow slots', out[329], 'split', out[326])
-print('shadow rays', out[320], 'evicted shadow', out[323], 'overflow', out[322], 'guard', out[325])
-print('deep queue: level-1 rays', out[332], 'slots', out[1], 'claimed', out[65], 'done', out[384], 'chained rays', out[333], 'nodes', out[416], 'claims that waited', out[448], 'fallback frames', tr.stats().fallback_frames)
+print('shadow rays', out[320], 'level-0 split', out[327], 'evicted shadow', out[323], 'overflow', out[322], 'guard', out[326], 'fallback frames', tr.stats().fallback_frames)
 
-# what the wave-per-ray walks of a frame consist of (a render with counters=2 tallies them)
+# what the group-per-ray (or wave-per-ray) walks of a frame consist of (a render with counters=2 tallies them)
 tr.render(max_depth=depth, counters=2)
-big = (C.c_uint32 * 1024)()
-L.crt_debug_stream_counts(tr.ctx, big, 1024)
-for label, o in (('closest-hit', 704), ('shadow', 712)):
-    n = max(big[o], 1)
-    print('wave-per-ray %s walks: %d rays; per ray %.1f chunk tests (64 boxes each), %.1f triangle batches, %.1f mesh trees entered, %.1f loop trips'
-          % (label, big[o], big[o + 1] / n, big[o + 2] / n, big[o + 3] / n, big[o + 4] / n))
+L.crt_debug_stream_counts(tr.ctx, out, 512)
+for label, o in (('closest-hit', 384), ('shadow', 392)):
+    n = max(out[o], 1)
+    print('%s walks by the group / wave-per-ray kernel: %d rays; per ray %.1f steps (wave-per-ray: chunk tests), %.1f triangle batches, %.1f mesh trees entered'
+          % (label, out[o], out[o + 1] / n, out[o + 2] / n, out[o + 3] / n))
+print('kernels', tr.kernels())
