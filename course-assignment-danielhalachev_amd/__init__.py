@@ -103,8 +103,8 @@ MODE_STREAM, MODE_LANES = range(2)
 class Tuning(C.Structure):
     """crt_tuning (include/crt_hip.h): kernel selection and sizing; no setting changes a pixel."""
     _fields_ = [(n, C.c_uint32) for n in (
-        "size", "mode", "step_budget", "shadow_budget", "level0_budget", "heavy_level", "side_blocks", "quad",
-        "node_cap", "ray_cap", "shadow_cap", "autotune", "bfs")]
+        "size", "mode", "step_budget", "shadow_budget", "level0_budget", "heavy_level", "side_blocks",
+        "node_cap", "ray_cap", "shadow_cap", "autotune")]
 
 
 def make_tuning(**fields):

@@ -7,14 +7,13 @@
 //
 // Design (DESIGN.md has the measurements behind it):
 //  * default path (kernel_stream.h): the reference's recursion unrolled BY RECURSION LEVEL.  Level g is one
-//    launch of a per-lane walk kernel (kernel_walk.h: quad nodes for the levels, binary threaded nodes for the
-//    shadow passes) whose lanes are refilled from a queue; it writes ray-tree nodes, child rays for level g+1
-//    and shadow rays.  Walks that outlast a step budget, and whole small levels, go to a wave-per-ray kernel
+//    launch of a per-lane walk kernel (kernel_plan.h: binary threaded nodes, the top-level tree as a plan) whose
+//    lanes are refilled from a queue; it writes ray-tree nodes, child rays for level g+1 and shadow rays.  Walks that outlast a step budget, and whole small levels, go to a wave-per-ray kernel
 //    (kernel_heavy.h).  The shadow rays of level 0 -- the bulk of the frame -- run on a side stream beside the
 //    deeper levels.  stream_resolve evaluates every pixel's ray tree in the reference's post-order, so that
 //    every float is combined in the same order;
 //  * the reference's stack DFS has a FIXED visit order and no distance pruning, so the trees are flattened into
-//    hit/miss links (crt_node) and walked without a stack; the quad and leaf-sequence forms rest on the boxes
+//    hit/miss links (crt_node) and walked without a stack; the plan and leaf-sequence forms rest on the boxes
 //    being nested, which crt_create verifies;
 //  * fallback, bit-exact and tested: render_lanes (kernel_lane.h: the full recursion per lane on an
 //    explicit frame stack; redoes a frame whose queues overflowed, and renders the GI mode);
@@ -49,7 +48,6 @@ namespace {
 #include "kernel_stream.h"
 #include "kernel_heavy.h"
 #include "kernel_plan.h"
-#include "kernel_bfs.h"
 
 // scatter gathered packed tiles into the row-major frame
 __global__ void unpack_kernel(const float *packed, uint32_t n_parts, uint64_t part_stride, float *frame, uint32_t width,
@@ -131,12 +129,6 @@ struct crt_ctx {
     uint32_t *d_heavy = nullptr;      // evicted ray ids
     uint32_t *d_sheavy = nullptr;     // evicted shadow ray ids
     float4 *d_hits = nullptr;         // their closest hits
-    uint4 *d_bitems[4] = {nullptr, nullptr, nullptr, nullptr};  // kernel_bfs.h: item queues of the levels' walks [0, 1] and of the shadow walks [2, 3] (they overlap in time)
-    float4 *d_bprep = nullptr, *d_bprep_shadow = nullptr;
-    unsigned long long *d_bbest = nullptr;
-    uint32_t *d_bfirstnf = nullptr, *d_bcounts = nullptr;
-    uint32_t bfs_levels = 0;          // levels of the deepest leaf sequence (kernel_bfs.h: box passes per walk)
-    double item_mult = 4.0;           // item-queue capacity as a multiple of the ray-queue capacity
     hipStream_t side = nullptr;       // shadow pass 0 overlaps the deeper recursion levels on this stream
     // What a finished frame tells the next ones (queue sizing, launch sizes, fallback count): every frame copies its counter
     // block and the fallback total to ITS slot of this pinned ring, and the host reads a slot only once that frame's last
@@ -171,7 +163,6 @@ struct crt_ctx {
     uint32_t heavy_cap = 0;
     uint32_t step_budget = 256;       // crt_tuning::step_budget (0 = never evict: also set when a mesh has too many leaves for the wave-per-ray walk)
     bool lean_ok = true;              // 32-bit byte offsets reach every node and leaf entry
-    bool quads_ok = true;             // the quad collapse succeeded
     uint64_t stream_items = 0;        // work items the stream buffers are sized for
     uint64_t overflows = 0;           // frames redone by the fallback (diagnostic)
     uint32_t n_lights = 0;
@@ -186,7 +177,6 @@ struct crt_ctx {
 
 // constants that round 2 carried as crt_tuning fields (DESIGN.md section 7 has the measurements)
 static constexpr uint32_t HEAVY_BLOCKS = 4096;   // grid of the wave-per-ray kernels (more blocks than fit: late ones balance the load)
-static constexpr uint32_t QUAD_STACK_DEPTH = 16; // LDS words per lane of the quad walk's stack
 static constexpr uint32_t REFILL_BUNDLE = 16;    // the plan kernels refill a wave when at most this many lanes still walk
 
 static std::string g_create_error;
@@ -377,10 +367,8 @@ extern "C" void crt_tuning_defaults(crt_tuning *t) {
     t->mode = CRT_MODE_STREAM;
     t->step_budget = 256; t->shadow_budget = 4096; t->level0_budget = 0;
     t->heavy_level = 100000; t->side_blocks = 3;
-    t->quad = 1;
     t->node_cap = t->ray_cap = t->shadow_cap = 0;
     t->autotune = 1;
-    t->bfs = 0;
 }
 
 extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) { return crt_create_tuned(s, device, nullptr, out); }
@@ -519,9 +507,9 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
         if (upload(ctx, pn.data(), pn.size(), &A.pnodes)) return fail(CRT_ERR_HIP);
     }
     std::vector<HeavyMesh> hmesh_host;  // filled with the leaf sequences below, read again for the single-leaf mesh table
+    std::vector<bool> is_top(s->n_nodes, false);
     {
         // the top-level tree's nodes: reachable from top_root (links point forward, so the walk is finite)
-        std::vector<bool> is_top(s->n_nodes, false);
         std::vector<uint32_t> stack{s->top_root};
         while (!stack.empty()) {
             const uint32_t i = stack.back();
@@ -604,79 +592,6 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
         }
         if (upload(ctx, hbox.data(), hbox.size(), &A.hbox)) return fail(CRT_ERR_HIP);
         if (upload(ctx, hm.data(), hm.size(), &A.hmesh)) return fail(CRT_ERR_HIP);
-    }
-    {
-        // Quad nodes of the mesh trees (kernel_walk.h).  quad(i) for an inner node i: its children in visit order
-        // -- link(i) first, then that child's miss link unless it already leaves i's subtree -- and, while fewer
-        // than four slots are filled, the inner slot with the largest box replaced by its own children, in place.
-        std::vector<float4> quads;
-        std::vector<uint32_t> qroots(s->n_meshes, 0);
-        struct Builder {
-            const crt_scene_desc *s;
-            std::vector<float4> &quads;
-            const std::vector<uint32_t> &compact_link;
-            void children(uint32_t i, std::vector<uint32_t> &out) const {
-                const crt_node &n = s->nodes[i];
-                if (is_leaf_link(n.link) || n.link == CRT_LINK_END) return;
-                const uint32_t c1 = n.link;
-                out.push_back(c1);
-                const uint32_t c2 = s->nodes[c1].miss;
-                if (c2 != n.miss && c2 != CRT_LINK_END) out.push_back(c2);
-            }
-            static float area(const crt_node &n) {
-                const float dx = n.hi[0] - n.lo[0], dy = n.hi[1] - n.lo[1], dz = n.hi[2] - n.lo[2];
-                return dx * dy + dy * dz + dz * dx;
-            }
-            bool too_deep = false;
-            uint32_t build(std::vector<uint32_t> slots, int depth = 0) {
-                if (depth > 128) { too_deep = true; return NONE; }  // not a tree the reference's builder makes (depth <= 25)
-                for (;;) {
-                    if (slots.size() >= 4) break;
-                    int pick = -1;
-                    float best = -1.0f;
-                    for (size_t k = 0; k < slots.size(); k++) {
-                        const crt_node &n = s->nodes[slots[k]];
-                        if (is_leaf_link(n.link)) continue;
-                        const float a = area(n);
-                        if (pick < 0 || a > best) { pick = (int)k; best = a; }
-                    }
-                    if (pick < 0) break;
-                    std::vector<uint32_t> kids;
-                    children(slots[pick], kids);
-                    slots.erase(slots.begin() + pick);
-                    slots.insert(slots.begin() + pick, kids.begin(), kids.end());
-                }
-                const uint32_t q = (uint32_t)(quads.size() / 8);
-                quads.resize(quads.size() + 8, make_float4(0, 0, 0, 0));
-                float box[6][4];
-                uint32_t link[4] = {NONE, NONE, NONE, NONE}, clink[4] = {NONE, NONE, NONE, NONE};
-                for (int k = 0; k < 4; k++) for (int a = 0; a < 6; a++) box[a][k] = 0.0f;
-                for (size_t k = 0; k < slots.size(); k++) {
-                    const crt_node &n = s->nodes[slots[k]];
-                    for (int a = 0; a < 3; a++) { box[a][k] = n.lo[a]; box[3 + a][k] = n.hi[a]; }
-                    if (is_leaf_link(n.link)) {
-                        link[k] = n.link;  // LEAF + first entry
-                        clink[k] = compact_link[slots[k]];  // ... and with the leaf's length (plan kernels)
-                    } else {
-                        std::vector<uint32_t> kids;
-                        children(slots[k], kids);
-                        link[k] = build(kids, depth + 1);
-                        clink[k] = link[k];
-                    }
-                }
-                for (int a = 0; a < 6; a++) quads[(size_t)q * 8 + a] = make_float4(box[a][0], box[a][1], box[a][2], box[a][3]);
-                float lb[4];
-                memcpy(lb, link, 16);
-                quads[(size_t)q * 8 + 6] = make_float4(lb[0], lb[1], lb[2], lb[3]);
-                memcpy(lb, clink, 16);
-                quads[(size_t)q * 8 + 7] = make_float4(lb[0], lb[1], lb[2], lb[3]);
-                return q;
-            }
-        } builder{s, quads, compact_link};
-        for (uint32_t m = 0; m < s->n_meshes; m++) qroots[m] = builder.build(std::vector<uint32_t>{s->meshes[m].root});
-        if (builder.too_deep || quads.size() / 8 >= (1u << 24)) ctx->quads_ok = false;
-        if (upload(ctx, quads.data(), quads.size(), &A.quads)) return fail(CRT_ERR_HIP);
-        if (upload(ctx, qroots.data(), qroots.size(), &A.quad_roots)) return fail(CRT_ERR_HIP);
     }
     if (upload(ctx, s->triangle_vertices, (size_t)s->n_triangles * 3, &A.tri_verts)) return fail(CRT_ERR_HIP);
     if (upload(ctx, s->vertex_normals, (size_t)s->n_vertices * 3, &A.vnormals)) return fail(CRT_ERR_HIP);
@@ -791,112 +706,11 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
         }
         // the per-lane plan kernels keep a ray's leaves and meshes in two 64-bit words
         A.plan_ok = (contiguous && A.top_fast && n_leaves <= 64u && s->n_meshes <= 64u && A.plan_compact) ? 1u : 0u;
-        // the level-synchronous kernels keep them in LDS tables (kernel_bfs.h: BFS_PLAN_*)
-        A.bfs_ok = (contiguous && A.plan_compact && n_leaves <= (uint32_t)BFS_PLAN_LEAVES && s->n_leaf_meshes <= (uint32_t)BFS_PLAN_ENTRIES &&
-                    s->n_meshes <= (uint32_t)BFS_PLAN_MESHES && tune.bfs != 0u) ? 1u : 0u;
         A.plan_leaves = n_leaves;
         A.plan_shadow_bits = (uint32_t)std::min<size_t>(order.size(), 64);
         A.plan_list_words = (s->n_meshes + 3u) / 4u;
         if (upload(ctx, boxes.data(), boxes.size(), &A.plan_boxes)) return fail(CRT_ERR_HIP);
         if (upload(ctx, order.data(), order.size(), &A.plan_shadow_mesh)) return fail(CRT_ERR_HIP);
-    }
-    {
-        // kernel_bfs.h: leaf sequences with a fan-out of 16, their levels per mesh, and the mesh of every triangle
-        std::vector<uint2> glevels((size_t)s->n_meshes * BFS_LEVELS, make_uint2(0, 0));
-        bool ok = A.bfs_ok != 0u;
-        uint32_t deepest = 0;
-        std::vector<float4> bbox;   // the 16-ary hierarchy (the group kernels' own fan-out may differ)
-        std::vector<uint4> bmesh(s->n_meshes);
-        std::vector<uint32_t> roots;
-        roots.push_back(s->top_root);
-        for (uint32_t m = 0; m < s->n_meshes; m++) roots.push_back(s->meshes[m].root);
-        std::sort(roots.begin(), roots.end());
-        for (uint32_t m = 0; m < s->n_meshes; m++) {
-            const uint32_t root = s->meshes[m].root;
-            auto it = std::upper_bound(roots.begin(), roots.end(), root);
-            const uint32_t end = it == roots.end() ? s->n_nodes : *it;
-            std::vector<float4> level;
-            for (uint32_t i = root; i < end; i++) {
-                const crt_node &n = s->nodes[i];
-                if (!is_leaf_link(n.link)) continue;
-                const uint32_t begin = n.link & ~CRT_LINK_LEAF;
-                uint32_t count = 0;
-                if (begin < s->n_leaf_triangles) {
-                    uint64_t e = begin;
-                    do { count++; } while (!(s->leaf_triangles[e++] & CRT_ENTRY_LAST) && e < s->n_leaf_triangles);
-                }
-                float bb, cb;
-                memcpy(&bb, &begin, 4);
-                memcpy(&cb, &count, 4);
-                level.push_back(make_float4(n.lo[0], n.lo[1], n.lo[2], bb));
-                level.push_back(make_float4(n.hi[0], n.hi[1], n.hi[2], cb));
-            }
-            const uint32_t first0 = (uint32_t)(bbox.size() / 2), count0 = (uint32_t)(level.size() / 2);
-            uint32_t tiny = NONE;
-            if (count0 == 1) {  // a single leaf of at most 255 triangles: LEAF | (triangles - 1) << 24 | first leaf entry
-                uint32_t begin, cnt;
-                memcpy(&begin, &level[0].w, 4);
-                memcpy(&cnt, &level[1].w, 4);
-                if (cnt >= 1 && cnt <= 128u && begin < (1u << 24)) tiny = CRT_LINK_LEAF | ((cnt - 1u) << 24) | begin;
-            }
-            bmesh[m] = make_uint4(first0, count0, s->meshes[m].flags & 255u, tiny);
-            uint32_t levels = 0;
-            while (!level.empty()) {
-                const uint32_t cnt = (uint32_t)(level.size() / 2);
-                if (levels >= (uint32_t)BFS_LEVELS) { ok = false; break; }
-                glevels[(size_t)m * BFS_LEVELS + levels] = make_uint2((uint32_t)(bbox.size() / 2), cnt);
-                bbox.insert(bbox.end(), level.begin(), level.end());
-                levels++;
-                if (cnt <= (uint32_t)BFS_F) break;
-                std::vector<float4> up;
-                for (uint32_t g = 0; g < cnt; g += BFS_F) {
-                    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-                    for (uint32_t k = g; k < cnt && k < g + BFS_F; k++) {
-                        const float4 &a = level[2 * k], &b = level[2 * k + 1];
-                        lo[0] = a.x < lo[0] ? a.x : lo[0]; lo[1] = a.y < lo[1] ? a.y : lo[1]; lo[2] = a.z < lo[2] ? a.z : lo[2];
-                        hi[0] = b.x > hi[0] ? b.x : hi[0]; hi[1] = b.y > hi[1] ? b.y : hi[1]; hi[2] = b.z > hi[2] ? b.z : hi[2];
-                    }
-                    up.push_back(make_float4(lo[0], lo[1], lo[2], 0.0f));
-                    up.push_back(make_float4(hi[0], hi[1], hi[2], 0.0f));
-                }
-                level.swap(up);
-            }
-            deepest = std::max(deepest, levels);
-        }
-        // leaf entries must ascend in visit order inside every mesh (the tie rule of kernel_bfs.h rests on it)
-        for (uint32_t m = 0; ok && m < s->n_meshes; m++) {
-            const uint2 l0 = glevels[(size_t)m * BFS_LEVELS];
-            uint32_t prev_end = 0;
-            for (uint32_t i = 0; i < l0.y; i++) {
-                uint32_t begin, cnt;
-                memcpy(&begin, &bbox[2 * (size_t)(l0.x + i)].w, 4);
-                memcpy(&cnt, &bbox[2 * (size_t)(l0.x + i) + 1].w, 4);
-                if (i && begin < prev_end) { ok = false; break; }
-                prev_end = begin + cnt;
-            }
-        }
-        std::vector<uint32_t> tri_mesh(s->n_triangles, 0u);
-        std::vector<uint8_t> tri_seen(s->n_triangles, 0);
-        for (uint32_t m = 0; ok && m < s->n_meshes; m++) {
-            const uint2 l0 = glevels[(size_t)m * BFS_LEVELS];
-            for (uint32_t i = 0; ok && i < l0.y; i++) {
-                uint32_t begin, cnt;
-                memcpy(&begin, &bbox[2 * (size_t)(l0.x + i)].w, 4);
-                memcpy(&cnt, &bbox[2 * (size_t)(l0.x + i) + 1].w, 4);
-                for (uint32_t e = begin; e < begin + cnt && e < s->n_leaf_triangles; e++) {
-                    const uint32_t tri = s->leaf_triangles[e] & ~CRT_ENTRY_LAST;
-                    if (tri_seen[tri] && tri_mesh[tri] != m) ok = false;  // a triangle listed by two meshes: its mesh cannot be looked up
-                    tri_seen[tri] = 1; tri_mesh[tri] = m;
-                }
-            }
-        }
-        if (bbox.size() / 2 >= (1u << 24)) ok = false;  // (an item carries a box index in 24 bits)
-        ctx->bfs_levels = deepest;
-        A.bfs_ok = ok ? 1u : 0u;
-        if (upload(ctx, bbox.data(), bbox.size(), &A.gbox)) return fail(CRT_ERR_HIP);
-        if (upload(ctx, bmesh.data(), bmesh.size(), &A.gmesh)) return fail(CRT_ERR_HIP);
-        if (upload(ctx, glevels.data(), glevels.size(), &A.glevels)) return fail(CRT_ERR_HIP);
-        if (upload(ctx, tri_mesh.data(), tri_mesh.size(), &A.tri_mesh)) return fail(CRT_ERR_HIP);
     }
     A.bgx = s->background[0]; A.bgy = s->background[1]; A.bgz = s->background[2];
     A.width = s->width; A.height = s->height; A.tiles_x = ctx->tiles_x;
@@ -921,7 +735,6 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
     CK(hipHostMalloc((void **)&ctx->h_ring, (size_t)crt_ctx::EV_RING * crt_ctx::H_SLOT_WORDS * sizeof(uint32_t)));
     memset(ctx->h_ring, 0, (size_t)crt_ctx::EV_RING * crt_ctx::H_SLOT_WORDS * sizeof(uint32_t));
     ctx->last_counts.assign(SC_ALLOC_WORDS, 0u);
-    CK(hipMalloc((void **)&ctx->d_bcounts, (size_t)BFS_SETS * BFS_ROWS * BFS_SHARDS * BFS_COUNTER_STRIDE * sizeof(uint32_t)));
     CK(hipMalloc((void **)&ctx->d_fallback_total, sizeof(uint32_t)));
     CK(hipMemset(ctx->d_fallback_total, 0, sizeof(uint32_t)));
     ctx->n_lights = s->n_lights;
@@ -950,12 +763,6 @@ extern "C" void crt_destroy(crt_ctx *ctx) {
     if (ctx->d_heavy) (void)hipFree(ctx->d_heavy);
     if (ctx->d_sheavy) (void)hipFree(ctx->d_sheavy);
     if (ctx->d_hits) (void)hipFree(ctx->d_hits);
-    for (int i = 0; i < 4; i++) if (ctx->d_bitems[i]) (void)hipFree(ctx->d_bitems[i]);
-    if (ctx->d_bprep) (void)hipFree(ctx->d_bprep);
-    if (ctx->d_bprep_shadow) (void)hipFree(ctx->d_bprep_shadow);
-    if (ctx->d_bbest) (void)hipFree(ctx->d_bbest);
-    if (ctx->d_bfirstnf) (void)hipFree(ctx->d_bfirstnf);
-    if (ctx->d_bcounts) (void)hipFree(ctx->d_bcounts);
     if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
     if (ctx->d_fallback_total) (void)hipFree(ctx->d_fallback_total);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
@@ -1057,7 +864,6 @@ static void adapt_queue_sizing(crt_ctx *ctx) {
         ctx->node_mult = std::min(4.0, ctx->node_mult * 2.0);
         ctx->ray_mult = std::min(3.0, ctx->ray_mult * 2.0);
         ctx->shadow_extra = std::min(3.0, ctx->shadow_extra * 2.0);
-        ctx->item_mult = std::min(64.0, ctx->item_mult * 2.0);
         return;
     }
     const KernelArgs &A = ctx->args;
@@ -1093,8 +899,7 @@ static int ensure_stream(crt_ctx *ctx, uint32_t n_items) {
     shadow_cap = std::min<uint64_t>(shadow_cap, 0x7FFFFFF0ull);
     if (px > node_cap) { ctx->error = "frame too large for the ray-stream buffers"; return CRT_ERR_INVALID; }
     const bool fixed_caps = ctx->tuning.node_cap || ctx->tuning.ray_cap || ctx->tuning.shadow_cap;
-    const bool items_grow = A.bfs_ok && A.b_shard_cap && (uint64_t)(std::max<uint64_t>(floor_cap, ray_cap) * ctx->item_mult) / BFS_SHARDS > A.b_shard_cap;
-    const bool grow = node_cap > A.s_node_cap || ray_cap > A.s_ray_cap || shadow_cap > A.s_shadow_cap || n_items > ctx->stream_items || items_grow ||
+    const bool grow = node_cap > A.s_node_cap || ray_cap > A.s_ray_cap || shadow_cap > A.s_shadow_cap || n_items > ctx->stream_items ||
                       (fixed_caps && (node_cap != A.s_node_cap || ray_cap != A.s_ray_cap || shadow_cap != A.s_shadow_cap));
     if (grow) {
         CRT_HIP_CHECK(ctx, hipDeviceSynchronize());  // nothing may still be using the old buffers
@@ -1104,8 +909,7 @@ static int ensure_stream(crt_ctx *ctx, uint32_t n_items) {
             shadow_cap = std::max<uint64_t>(shadow_cap, A.s_shadow_cap);
         }
         void **bufs[] = {(void **)&ctx->d_rayq[0], (void **)&ctx->d_rayq[1], (void **)&ctx->d_shadowq, (void **)&ctx->d_occluded,
-                         (void **)&ctx->d_nodes, (void **)&ctx->d_heavy, (void **)&ctx->d_sheavy, (void **)&ctx->d_hits,
-                         (void **)&ctx->d_bitems[0], (void **)&ctx->d_bitems[1], (void **)&ctx->d_bitems[2], (void **)&ctx->d_bitems[3], (void **)&ctx->d_bprep, (void **)&ctx->d_bprep_shadow, (void **)&ctx->d_bbest, (void **)&ctx->d_bfirstnf};
+                         (void **)&ctx->d_nodes, (void **)&ctx->d_heavy, (void **)&ctx->d_sheavy, (void **)&ctx->d_hits};
         for (void **b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
         ctx->stream_items = 0;
         A.s_node_cap = A.s_ray_cap = A.s_shadow_cap = 0;
@@ -1118,28 +922,13 @@ static int ensure_stream(crt_ctx *ctx, uint32_t n_items) {
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_heavy, (size_t)ctx->heavy_cap * sizeof(uint32_t) + 64));
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_sheavy, (size_t)ctx->heavy_cap * sizeof(uint32_t) + 64));
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_hits, (size_t)ctx->heavy_cap * sizeof(float4)));
-        // kernel_bfs.h: two item queues (BFS_SHARDS regions each), a prepared ray and a result per hand-over list entry
-        uint64_t shard_cap = 0;
-        if (A.bfs_ok) {
-            shard_cap = std::max<uint64_t>(1u << 12, (uint64_t)(ctx->heavy_cap * ctx->item_mult) / BFS_SHARDS);
-            shard_cap = std::min<uint64_t>(shard_cap, 0x7FFFFFF0ull / BFS_SHARDS);
-            for (int i = 0; i < 4; i++) CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_bitems[i], shard_cap * BFS_SHARDS * sizeof(uint4)));
-            CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_bprep, (size_t)ctx->heavy_cap * 3 * sizeof(float4)));
-            CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_bprep_shadow, (size_t)ctx->heavy_cap * 3 * sizeof(float4)));
-            CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_bbest, (size_t)ctx->heavy_cap * sizeof(unsigned long long)));
-            CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_bfirstnf, (size_t)ctx->heavy_cap * sizeof(uint32_t)));
-        }
-        A.b_shard_cap = (uint32_t)shard_cap;
         A.s_ray_cap = (uint32_t)ray_cap; A.s_shadow_cap = (uint32_t)shadow_cap; A.s_node_cap = (uint32_t)node_cap;
         ctx->stream_items = n_items;
-        ctx->queue_bytes = ray_cap * 64 + shadow_cap * 33 + node_cap * 32 + (size_t)ctx->heavy_cap * 24 +
-                           (A.bfs_ok ? shard_cap * BFS_SHARDS * 64 + (size_t)ctx->heavy_cap * 108 : 0);
+        ctx->queue_bytes = ray_cap * 64 + shadow_cap * 33 + node_cap * 32 + (size_t)ctx->heavy_cap * 24;
     }
     A.s_rayq[0] = ctx->d_rayq[0]; A.s_rayq[1] = ctx->d_rayq[1];
     A.s_shadowq = ctx->d_shadowq; A.s_occluded = ctx->d_occluded; A.s_nodes = ctx->d_nodes;
     A.s_heavy = ctx->d_heavy; A.s_sheavy = ctx->d_sheavy; A.s_hits = ctx->d_hits; A.s_heavy_cap = ctx->heavy_cap;
-    A.b_items[0] = ctx->d_bitems[0]; A.b_items[1] = ctx->d_bitems[1]; A.b_prep = ctx->d_bprep; A.b_best = ctx->d_bbest; A.b_firstnf = ctx->d_bfirstnf;
-    A.b_counts = ctx->d_bcounts;
     return CRT_OK;
 }
 
@@ -1212,20 +1001,6 @@ static void autotune_step(crt_ctx *ctx, uint32_t n_items, uint32_t depth, bool e
     T.tag[slot_now] = T.stage;
 }
 
-// development: crt_tuning::bfs = 1 / 2 / 4 items in flight per 16-lane group
-static void launch_bfs_pass(crt_ctx *ctx, bool shadow, uint32_t blocks, hipStream_t stream, const KernelArgs &A, uint32_t set, uint32_t pass, uint32_t primary) {
-    const uint32_t ipg = ctx->tuning.bfs;
-    if (shadow) {
-        if (ipg == 4) launch(bfs_pass<true, 4>, blocks, stream, A, set, pass, primary);
-        else if (ipg == 2) launch(bfs_pass<true, 2>, blocks, stream, A, set, pass, primary);
-        else launch(bfs_pass<true, 1>, blocks, stream, A, set, pass, primary);
-    } else {
-        if (ipg == 4) launch(bfs_pass<false, 4>, blocks, stream, A, set, pass, primary);
-        else if (ipg == 2) launch(bfs_pass<false, 2>, blocks, stream, A, set, pass, primary);
-        else launch(bfs_pass<false, 1>, blocks, stream, A, set, pass, primary);
-    }
-}
-
 // One frame's launches.  Ray-stream path (kernel_stream.h), per recursion level g = 0 .. MAX_DEPTH on `stream`:
 //   the per-lane kernel (plan kernels; the faithful kernel for the counting build and for scenes without a plan),
 //   heavy_trace_closest for the walks it handed over (or the whole level), stream_shade_evicted for their hits;
@@ -1286,13 +1061,10 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         rc = ensure_stream(ctx, n_items);
         if (rc) return rc;
         CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_scounts, 0, SC_ALLOC_WORDS * sizeof(uint32_t), stream));
-        if (A.bfs_ok) CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_bcounts, 0, (size_t)BFS_SETS * BFS_ROWS * BFS_SHARDS * BFS_COUNTER_STRIDE * sizeof(uint32_t), stream));
-        const uint32_t bfs_blocks = (uint32_t)ctx->num_cus * 8u / BFS_SHARDS * BFS_SHARDS;  // (a multiple of BFS_SHARDS)
         // the wave-per-ray path needs nested boxes; the counting build walks every ray the reference's way
         const bool heavy = ctx->step_budget && A.nested_boxes && !count;
         // the plan kernels (kernel_plan.h): a small top-level tree (its leaves as a plan), 32-bit offsets, compact leaf links
         const bool lean = heavy && ctx->lean_ok && A.plan_ok;
-        const bool quad = lean && ctx->tuning.quad && ctx->quads_ok;
         A.heavy_level_threshold = lean ? ctx->tuning.heavy_level : 0u;
         uint32_t side_per_cu = ctx->tuning.side_blocks;  // workgroups per CU of the bulk shadow pass beside the levels
         {
@@ -1302,7 +1074,6 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
             if (eligible && ctx->at.hl) A.heavy_level_threshold = ctx->at.hl;
             if (eligible && ctx->at.sb && ctx->tuning.side_blocks == 3u) side_per_cu = ctx->at.sb;
         }
-        A.quad_stack_depth = QUAD_STACK_DEPTH;
         A.exec_count = exec_count ? 1u : 0u;
         A.exec_counters = ctx->d_exec;
         A.exec_plan = ctx->d_exec + 4;
@@ -1319,11 +1090,9 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
                 CRT_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->d_scounts + SC_SHADOW), (int)(uint32_t)n0, 1, stream));
             }
         }
-        const uint32_t qlds = quad ? QUAD_STACK_DEPTH * BLOCK * (uint32_t)sizeof(uint32_t) : 0u;
         const uint32_t plds = A.plan_list_words * BLOCK * (uint32_t)sizeof(uint32_t);  // kernel_plan.h: mesh lists
         KernelArgs S = A;  // argument block of the bulk shadow pass
         S.wave_prio = 0u;
-        S.b_items[0] = ctx->d_bitems[2]; S.b_items[1] = ctx->d_bitems[3]; S.b_prep = ctx->d_bprep_shadow;  // (its walks overlap the levels' in time)
         S.counters = ctx->d_counters + C_N;
         S.exec_counters = ctx->d_exec + 2;  // it tallies on its own
         S.exec_plan = ctx->d_exec + 5;
@@ -1355,19 +1124,10 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
                 const uint32_t want = was < A.heavy_level_threshold ? 64u : std::max<uint32_t>((uint32_t)ctx->num_cus, (was + was / 2u + BLOCK - 1) / BLOCK);
                 level_blocks = std::min(lane_blocks, want);
             }
-            // with the level-synchronous walks a deeper level needs no per-lane kernel at all: every ray of it is handed over
-            A.force_whole = (heavy && A.bfs_ok && g >= 1) ? 1u : 0u;
-            if (A.force_whole) {}
-            else if (count) launch(stream_trace_shade<true>, lane_blocks, stream, A, g);
-            else if (lean && quad) launch_lds(stream_trace_shade_plan<true>, level_blocks, qlds + plds, stream, A, g);
-            else if (lean) launch_lds(stream_trace_shade_plan<false>, level_blocks, plds, stream, A, g);
+            if (count) launch(stream_trace_shade<true>, lane_blocks, stream, A, g);
+            else if (lean) launch_lds(stream_trace_shade_plan, level_blocks, plds, stream, A, g);
             else launch(stream_trace_shade<false>, lane_blocks, stream, A, g);
-            if (heavy && A.bfs_ok) {
-                // the level-synchronous walk (kernel_bfs.h): the rays' meshes, one pass per level of the deepest leaf sequence, the triangles, the shading
-                launch(bfs_plan<false>, bfs_blocks, stream, A, g);
-                for (uint32_t pass = 0; pass <= ctx->bfs_levels; pass++) launch_bfs_pass(ctx, false, bfs_blocks, stream, A, g, pass, g == 0 ? 1u : 0u);
-                launch(bfs_shade, 256u, stream, A, g);
-            } else if (heavy) {
+            if (heavy) {
                 launch(heavy_trace_closest, HEAVY_BLOCKS, stream, A, g);
                 launch(stream_shade_evicted<false>, 256u, stream, A, g);
             }
@@ -1389,10 +1149,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
                 // caller's stream waits for, so nothing the later pass appends is below it
                 if (heavy) hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, where, S, (uint32_t)SC_SHEAVY_SPLIT, (uint32_t)SC_SHEAVY);
                 CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s1[slot], where));
-                if (heavy && A.bfs_ok) {
-                    launch(bfs_plan<true>, bfs_blocks, where, S, 0u);
-                    for (uint32_t pass = 0; pass <= ctx->bfs_levels; pass++) launch_bfs_pass(ctx, true, bfs_blocks, where, S, (uint32_t)MAX_GENERATIONS, pass, 0u);
-                } else if (heavy) launch(heavy_trace_shadow, HEAVY_BLOCKS, where, S, 0u);
+                if (heavy) launch(heavy_trace_shadow, HEAVY_BLOCKS, where, S, 0u);
                 CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s2[slot], where));
             }
         }
@@ -1402,7 +1159,6 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         if (side_per_cu) CRT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_s1[slot], 0));
         KernelArgs S1 = A;
         S1.wave_prio = 0u;
-        S1.b_items[0] = ctx->d_bitems[2]; S1.b_items[1] = ctx->d_bitems[3]; S1.b_prep = ctx->d_bprep_shadow;
         S1.counters = ctx->d_counters + 2 * C_N;
         {
             // few rays, all tail: the short budget of the levels, or less when this launch is small (the deeper levels
@@ -1414,10 +1170,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         else if (lean) launch(stream_trace_shadow_plan<1>, lane_blocks, stream, S1);
         else launch(stream_trace_shadow<false>, lane_blocks, stream, S1, 1u);
         if (side_per_cu) CRT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_s2[slot], 0));
-        if (heavy && A.bfs_ok) {
-            launch(bfs_plan<true>, bfs_blocks, stream, S1, 1u);
-            for (uint32_t pass = 0; pass <= ctx->bfs_levels; pass++) launch_bfs_pass(ctx, true, bfs_blocks, stream, S1, (uint32_t)MAX_GENERATIONS + 1u, pass, 0u);
-        } else if (heavy) launch(heavy_trace_shadow, HEAVY_BLOCKS, stream, S1, 1u);
+        if (heavy) launch(heavy_trace_shadow, HEAVY_BLOCKS, stream, S1, 1u);
         CRT_HIP_CHECK(ctx, hipGetLastError());
         CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev2[slot], stream));
         A.counters = ctx->d_counters + 2 * C_N;
@@ -1752,15 +1505,6 @@ extern "C" int crt_debug_stream_counts(crt_ctx *ctx, uint32_t *out, uint32_t max
     return CRT_OK;
 }
 
-// DEBUG: the first `n` records of s_hits and s_heavy
-extern "C" int crt_debug_read_hits(crt_ctx *ctx, float *hits, uint32_t *ids, uint32_t n) {
-    if (!ctx) return CRT_ERR_INVALID;
-    CRT_HIP_CHECK(ctx, hipDeviceSynchronize());
-    CRT_HIP_CHECK(ctx, hipMemcpy(hits, ctx->d_hits, (size_t)n * 16, hipMemcpyDeviceToHost));
-    CRT_HIP_CHECK(ctx, hipMemcpy(ids, ctx->d_heavy, (size_t)n * 4, hipMemcpyDeviceToHost));
-    return CRT_OK;
-}
-
 // Which kernels a production frame of this context runs (bench.py names the roofline's kernel with it).
 extern "C" int crt_describe_kernels(const crt_ctx *ctx, char *out, size_t size) {
     if (!ctx || !out || size == 0) return CRT_ERR_INVALID;
@@ -1770,10 +1514,9 @@ extern "C" int crt_describe_kernels(const crt_ctx *ctx, char *out, size_t size) 
     else {
         const bool heavy = ctx->step_budget && A.nested_boxes;
         const bool lean = heavy && ctx->lean_ok && A.plan_ok;
-        const bool quad = lean && ctx->tuning.quad && ctx->quads_ok;
-        d = std::string("level0=") + (!lean ? "stream_trace_shade<false>" : (quad ? "stream_trace_shade_plan<true>" : "stream_trace_shade_plan<false>"));
+        d = std::string("level0=") + (!lean ? "stream_trace_shade<false>" : "stream_trace_shade_plan");
         d += std::string(";shadow0=") + (!lean ? "stream_trace_shadow<false>" : "stream_trace_shadow_plan<0u>");
-        d += std::string(";levels=") + (!heavy ? "stream_trace_shade<false>" : (A.bfs_ok ? "bfs_pass<false>" : "heavy_trace_closest"));
+        d += std::string(";levels=") + (!heavy ? "stream_trace_shade<false>" : "heavy_trace_closest");
         char buf[160];
         snprintf(buf, sizeof(buf), ";autotune=%s level0_budget=%u heavy_level=%u side_blocks=%u", !ctx->tuning.autotune ? "off" : (ctx->at.stage < 0 ? "settled" : "measuring"),
                  ctx->at.b0, ctx->at.hl ? ctx->at.hl : ctx->tuning.heavy_level, ctx->at.sb ? ctx->at.sb : ctx->tuning.side_blocks);

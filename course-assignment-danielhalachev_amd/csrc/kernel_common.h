@@ -82,21 +82,6 @@ struct KernelArgs {
     uint32_t only_if_overflow;    // lane kernel: run only when the stream pass overflowed its queues
     uint32_t *fallback_total;     // frames redone that way since crt_create (never reset)
     // heavy-ray path (kernel_heavy.h): leaf boxes in visit order + 64-ary group boxes above them
-    // leaf sequences with a fan-out of 16 (kernel_bfs.h): per mesh the leaves' own boxes in visit order {lo, first leaf entry}
-    // {hi, triangles}, then union boxes of 16 consecutive entries per level until at most 16 are left; gmesh: per mesh
-    // {first entry of its level 0, leaves, crt_mesh::flags, single-leaf meshes: compact leaf link, else NONE}
-    const float4 *gbox;
-    const uint4 *gmesh;
-    // level-synchronous walks (kernel_bfs.h)
-    const uint2 *glevels;         // per mesh BFS_LEVELS x {first entry of the level in gbox, entries}
-    const uint32_t *tri_mesh;     // per triangle: its mesh
-    uint4 *b_items[2];            // the two item queues, BFS_SHARDS regions of b_shard_cap items each
-    uint32_t b_shard_cap;
-    uint32_t *b_counts;           // [set][row][shard] item counters, one cache line each, zeroed before every frame
-    float4 *b_prep;               // prepared rays, 3 x float4 per hand-over list entry
-    unsigned long long *b_best;   // per list entry: min over accepted hits of (distance bits << 32 | mesh visit rank << 24 | leaf entry)
-    uint32_t *b_firstnf;          // per list entry: min (rank << 24 | leaf entry) over accepted hits without a finite distance
-    uint32_t bfs_ok;              // the level-synchronous kernels may be used
     const float4 *hbox;           // 2 x float4 per entry: {lo, begin|-} {hi, count|-}
     const HeavyMesh *hmesh;       // per mesh
     uint32_t *s_heavy;            // evicted ray ids of the current recursion level
@@ -105,11 +90,6 @@ struct KernelArgs {
     float4 *s_hits;               // closest-hit records of evicted rays: {t, triangle, mesh, have}
     uint32_t step_budget;         // a lane's walk is evicted after this many steps (0 = never)
     uint32_t heavy_level_threshold; // a recursion level with fewer rays than this goes to heavy_trace whole
-    // quad nodes of the mesh trees (kernel_plan.h): 128 bytes each = {lo.x[4]} {lo.y[4]} {lo.z[4]} {hi.x[4]} {hi.y[4]} {hi.z[4]}
-    // {slot links: quad index | LEAF + first leaf entry | NONE} {the same with compact leaf links}
-    const float4 *quads;
-    const uint32_t *quad_roots;   // per mesh
-    uint32_t quad_stack_depth;    // words of LDS stack per lane
     // crt_options::collect_counters == 2: the production kernels tally the box and triangle tests they EXECUTE (the exact
     // shortcuts make that fewer than the reference's, which the counting build tallies): {box tests, triangle tests}
     unsigned long long *exec_counters;
@@ -136,7 +116,7 @@ struct KernelArgs {
     const uint32_t *plan_shadow_mesh;  // shadow order: bit b = mesh plan_shadow_mesh[b] (big meshes first: likeliest occluders)
     uint32_t plan_shadow_bits;    // number of non-refractive meshes, <= 64
     // compact forms (crt_create): 3 x float4 per leaf entry {v0,nx} {v1,ny} {v2,nz}; the nodes again with leaf links
-    // LEAF | (entries - 1) << 24 | first entry; quads carry the same links in their vector 7
+    // LEAF | (entries - 1) << 24 | first entry
     uint32_t plan_compact;
     const float4 *ptris;
     const float4 *pnodes;

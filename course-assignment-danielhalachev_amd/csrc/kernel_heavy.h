@@ -332,7 +332,7 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const TopRegs &T
             crt_mesh m;
             if (fast) { m.flags = lane_value(TR.mflags, (int)mi); m.pad = lane_value(TR.mpad, (int)mi); m.root = 0; m.material = 0; }
             else if (TL && TL->fast) {
-                const lds_v4u v = TL->meshes[mi];  // {flags, tree root, quad root, pad}
+                const lds_v4u v = TL->meshes[mi];  // {flags, tree root, -, pad}
                 m.flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[0]); m.pad = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[3]);
                 m.root = 0; m.material = 0;
             }

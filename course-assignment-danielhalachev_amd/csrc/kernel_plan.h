@@ -184,7 +184,7 @@ __device__ __forceinline__ void shadow_plan_walks(const KernelArgs &A, const uin
 
 // pass 0: the level-0 shadow rays (queue slots below the split mark); pass 1: all the deeper levels' at once
 template <uint32_t pass>  // (a template parameter so that the passes are separate kernels in a profile)
-__global__ __launch_bounds__(BLOCK) void stream_trace_shadow_plan(const KernelArgs A) {
+__global__ __launch_bounds__(BLOCK, 8) void stream_trace_shadow_plan(const KernelArgs A) {
     const uint32_t split = A.s_counts[SC_SHADOW_SPLIT];
     shadow_plan_walks(A, pass == 0 ? 0u : split, pass == 0 ? split : A.s_counts[SC_SHADOW] - split,
                       A.s_counts + (pass == 0 ? SC_SHADOW_FETCH : SC_SHADOW_FETCH2));
@@ -235,18 +235,18 @@ __device__ __forceinline__ uint32_t plan_list_pop(PlanList &PL) {
     return (PL.words[(i >> 2) * BLOCK] >> (8u * (i & 3u))) & 255u;
 }
 
-// Every ray of recursion level `gen`, one per lane: plan, walk of the listed meshes (quad or binary nodes), material
-// dispatch.  Same results and same queues as stream_trace_shade_lean; rays with a parallel axis, walks longer than the
-// step budget and (QUAD) walks that outgrow the LDS stack go to heavy_trace_closest.
-template <bool QUAD>
+// Every ray of recursion level `gen`, one per lane, in the reference's own order: plan, walk of the listed meshes over the binary
+// threaded nodes, material dispatch.  Rays with a parallel axis and walks longer than the step budget go to heavy_trace_closest.
+// (Measured and removed, DESIGN.md section 7: 4-wide quad nodes with an LDS stack -- the same frame time; the same nearest slot
+// first with exact distance pruning on loose boxes -- grazing rays, the long walks, have nothing to prune before they hit.)
 __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArgs A, const uint32_t gen) {
-    if (A.wave_prio) __builtin_amdgcn_s_setprio(3);  // crt_tuning::wave_priority: ahead of the bulk shadow pass's waves on this SIMD
-    extern __shared__ uint32_t plan_lds[];  // [quad stack: A.quad_stack_depth x BLOCK (QUAD only)] [mesh lists: A.plan_list_words x BLOCK]
-    __shared__ TopLdsStorage top_storage;
-    const TopLds TL = top_lds_load(A, top_storage);  // mesh records {flags, tree root, quad root} (a barrier inside)
-    uint32_t *const stk = plan_lds + threadIdx.x;
+    if (A.wave_prio) __builtin_amdgcn_s_setprio(3);  // ahead of the bulk shadow pass's waves on this SIMD
+    extern __shared__ uint32_t plan_lds[];  // mesh lists: A.plan_list_words x BLOCK
+    __shared__ uint32_t s_tree_root[64];    // per mesh (plan kernels: at most 64 meshes)
+    if (threadIdx.x < 64u) s_tree_root[threadIdx.x] = threadIdx.x < A.top_meshes ? A.meshes[threadIdx.x].root : END;
+    __syncthreads();
     PlanList PL;
-    PL.words = plan_lds + (QUAD ? A.quad_stack_depth * BLOCK : 0u) + threadIdx.x;
+    PL.words = plan_lds + threadIdx.x;
     PL.count = 0; PL.next = 0;
     const uint32_t lane = threadIdx.x & 63u;
     if (A.s_counts[SC_OVERFLOW]) return;
@@ -257,11 +257,10 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArg
     const bool primary = gen == 0;
     if (stream_level_is_whole_heavy(A, gen, count)) return;
     const char *nodes_b = reinterpret_cast<const char *>(A.pnodes);
-    const char *quads_b = reinterpret_cast<const char *>(A.quads);
     const char *ptris_b = reinterpret_cast<const char *>(A.ptris);
 
     Ray R;
-    uint32_t wq = NONE, we = NONE, sp = 0, top = NONE;  // QUAD: quad to test, leaf entry, stack; binary: wq = next node (END: none)
+    uint32_t wn = END, we = NONE;   // next mesh-tree node (END: none), leaf cursor
     uint32_t mesh = NONE, mtri = 0, btri = 0, bmesh = 0;
     float mmin = INFINITY, mt = 0, tmin = INFINITY, bt = 0;
     bool mhave = false, have = false;
@@ -303,18 +302,16 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArg
             }
             if (fresh) {
                 plan_closest_meshes(A, R, PL, nplan);
-                wq = QUAD ? NONE : END; we = NONE; sp = 0; top = NONE; mesh = NONE;
+                wn = END; we = NONE; mesh = NONE;
                 mhave = false; mmin = INFINITY; mt = 0; mtri = 0;
                 have = false; tmin = INFINITY; bt = 0; btri = 0; bmesh = 0;
             }
         }
         if (!__ballot(state != ST_DONE)) break;
         if (state == ST_TRAVERSE) {
-            bool done = false, stack_full = false;
+            bool done = false;
             for (int it = 0; it < 64; ++it) {
                 steps++;
-                bool next = false;
-                uint32_t cur = NONE;
                 if (we != NONE) {
                     // ---- one triangle of the current leaf (Ray.cpp:9-31, Triangle.cpp:37-57), branch-free
                     const uint32_t entry = leaf_cursor_entry(we);
@@ -348,9 +345,8 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArg
                     mmin = less ? t : mmin;
                     mhave = mhave || ok;
                     we = leaf_cursor_next(we);
-                    if (QUAD) next = we == NONE;
                 } else {
-                    if (QUAD ? (wq == NONE) : (wq == END)) {
+                    if (wn == END) {
                         // ---- a mesh ended (scene-level rule, KDTree.cpp:156-167), the next one begins
                         if (mesh != NONE && mhave) {
                             if (!have) { have = true; bt = mt; btri = mtri; bmesh = mesh; }
@@ -358,66 +354,24 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArg
                         }
                         if (PL.next >= PL.count) { done = true; break; }
                         mesh = plan_list_pop(PL);
-                        const lds_v4u m = TL.meshes[mesh];
-                        wq = QUAD ? m[2] : m[1];
+                        wn = s_tree_root[mesh];
                         mhave = false;
                         mmin = INFINITY;
                     }
-                    if constexpr (QUAD) {
-                        // ---- one quad: four boxes (BoundingBox.h:85-108), the slots that pass go on the stack, last first
-                        if (sp + 4 > A.quad_stack_depth) { stack_full = true; break; }
-                        const float4 *Q = reinterpret_cast<const float4 *>(quads_b + (size_t)(uint32_t)(wq << 7));
-                        const float4 lx = Q[0], ly = Q[1], lz = Q[2], hx = Q[3], hy = Q[4], hz = Q[5];
-                        const uint4 lk = reinterpret_cast<const uint4 *>(Q)[7];  // slot links with compact leaf links
-                        if (A.exec_count) nbox += (lk.x != NONE) + (lk.y != NONE) + (lk.z != NONE) + (lk.w != NONE);
-                        bool h0 = lk.x != NONE && slab_test_no_parallel(R, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x);
-                        bool h1 = lk.y != NONE && slab_test_no_parallel(R, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y);
-                        bool h2 = lk.z != NONE && slab_test_no_parallel(R, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z);
-                        bool h3 = lk.w != NONE && slab_test_no_parallel(R, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w);
-#define CRT_PPUSH(x)                                              \
-    do {                                                          \
-        if (sp > 0) stk[(sp - 1) * BLOCK] = top;                  \
-        top = (x);                                                \
-        sp++;                                                     \
-    } while (0)
-                        if (h3) cur = lk.w;
-                        if (h2) { if (cur != NONE) CRT_PPUSH(cur); cur = lk.z; }
-                        if (h1) { if (cur != NONE) CRT_PPUSH(cur); cur = lk.y; }
-                        if (h0) { if (cur != NONE) CRT_PPUSH(cur); cur = lk.x; }
-#undef CRT_PPUSH
-                        wq = NONE;
-                        next = true;
-                    } else {
-                        // ---- one mesh-tree node (KDTree.cpp:53-74, BoundingBox.h:85-108), branch-free
-                        const float4 *N = reinterpret_cast<const float4 *>(nodes_b + (size_t)(uint32_t)(wq << 5));
-                        const float4 q0 = N[0], q1 = N[1];
-                        if (A.exec_count) nbox++;
-                        const uint32_t miss = __float_as_uint(q0.w), link = __float_as_uint(q1.w);
-                        const bool hit = slab_test_no_parallel(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
-                        const bool leaf = is_leaf_link(link);
-                        we = (hit && leaf) ? (link & ~LEAF) : NONE;
-                        wq = (hit && !leaf) ? link : miss;
-                    }
-                }
-                if (QUAD && next) {
-                    // the next slot: the first one that passed just now, else the most recent pending one
-                    if (cur == NONE && sp > 0) {
-                        cur = top;
-                        sp--;
-                        if (sp > 0) top = stk[(sp - 1) * BLOCK];
-                    }
-                    if (cur != NONE) {
-                        if (cur & LEAF) we = cur & ~LEAF;
-                        else wq = cur;
-                    }
+                    // ---- one mesh-tree node (KDTree.cpp:53-74, BoundingBox.h:85-108), branch-free
+                    const float4 *N = reinterpret_cast<const float4 *>(nodes_b + (size_t)(uint32_t)(wn << 5));
+                    const float4 q0 = N[0], q1 = N[1];
+                    if (A.exec_count) nbox++;
+                    const uint32_t miss = __float_as_uint(q0.w), link = __float_as_uint(q1.w);
+                    const bool hit = slab_test_no_parallel(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
+                    const bool leaf = is_leaf_link(link);
+                    we = (hit && leaf) ? (link & ~LEAF) : NONE;
+                    wn = (hit && !leaf) ? link : miss;
                 }
             }
             if (done) {
                 if (have) btri = A.leaf_tris[btri] & ~LAST;  // leaf entry -> triangle
                 shade_and_emit<false>(A, gen, r, node_base, child_base, R, have, bt, btri, bmesh, nullptr, lane);
-                state = ST_FETCH;
-            } else if (stack_full) {  // restart it in the wave-per-ray kernel, which needs no stack
-                if (!evict_ray(A.s_heavy, A.s_heavy_cap, A.s_counts + SC_HEAVY + gen, r, lane)) A.s_counts[SC_OVERFLOW] = 1;
                 state = ST_FETCH;
             } else if (steps >= A.step_budget) {
                 if (evict_ray(A.s_heavy, A.s_heavy_cap, A.s_counts + SC_HEAVY + gen, r, lane)) state = ST_FETCH;
@@ -427,3 +381,4 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArg
     }
     exec_counters_flush(A, nbox, ntri, lane, nplan);
 }
+

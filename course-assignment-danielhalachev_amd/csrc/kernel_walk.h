@@ -27,7 +27,7 @@ typedef const __attribute__((address_space(3))) uint32_t *lds_u32;
 constexpr int TOP_LDS_NODES = 256, TOP_LDS_ENTRIES = 1024, TOP_LDS_MESHES = 256;  // 16 KB per workgroup (KernelArgs::top_lds)
 struct TopLdsStorage {
     lds_v4f nodes[TOP_LDS_NODES * 2];
-    lds_v4u meshes[TOP_LDS_MESHES];    // {flags, tree root, quad root, -}
+    lds_v4u meshes[TOP_LDS_MESHES];    // {flags, tree root, -, index + 1 among the single-leaf meshes}
     uint32_t entries[TOP_LDS_ENTRIES];
 };
 struct TopLds {
@@ -53,7 +53,7 @@ __device__ __forceinline__ TopLds top_lds_load(const KernelArgs &A, TopLdsStorag
         for (uint32_t i = threadIdx.x; i < A.top_leaf_entries; i += blockDim.x) S.entries[i] = A.leaf_meshes[i];
         for (uint32_t i = threadIdx.x; i < A.top_meshes; i += blockDim.x) {
             const crt_mesh m = A.meshes[i];
-            S.meshes[i] = lds_v4u{m.flags, m.root, A.quad_roots[i], m.pad};  // (pad: index + 1 among the single-leaf meshes, kernel_heavy.h)
+            S.meshes[i] = lds_v4u{m.flags, m.root, 0u, m.pad};  // (pad: index + 1 among the single-leaf meshes, kernel_heavy.h)
         }
         __syncthreads();
     }

@@ -185,14 +185,12 @@ typedef struct crt_tuning {
     uint32_t level0_budget;   /* 0 (= min(step_budget, what a lane gets through in the launch)): the same for PRIMARY rays */
     uint32_t heavy_level;     /* 100000: recursion levels with fewer rays skip the per-lane kernel */
     uint32_t side_blocks;     /* 3: workgroups per CU of the bulk shadow pass on the side stream; 0 = no side stream */
-    uint32_t quad;            /* 1: the levels' per-lane kernel walks quad nodes; 0: binary nodes */
     uint32_t node_cap, ray_cap, shadow_cap; /* 0 = the queues follow the frames; explicit values make
                                              * queue overflow -- and the fallback -- reachable in tests */
     uint32_t autotune;        /* 1: three settings whose best value depends on the scene (level 0's step budget, heavy_level, side_blocks 3 / 4)
                                * are tried on the frames themselves -- a dozen frames each, timed by the events every frame records -- and
                                * the faster setting is kept (crt_device.hip: autotune_step); off when level0_budget, heavy_level or
                                * step_budget are given explicitly; side_blocks is only tried from its default of 3 */
-    uint32_t bfs;             /* 1: the walks a recursion level hands over run level-synchronously (csrc/kernel_bfs.h); 0: one ray per wave */
 } crt_tuning;
 void crt_tuning_defaults(crt_tuning *tuning);
 

@@ -62,7 +62,6 @@ KERNEL_PATHS = [
     dict(heavy_level=0),                                         # ... entirely by the per-lane kernel first
     dict(heavy_level=3000),                                      # ... some levels straddle the threshold
     dict(side_blocks=0),                                         # no side stream
-    dict(quad=0, heavy_level=0),                                 # binary per-lane walk
     dict(step_budget=100000, shadow_budget=100000, heavy_level=0),  # nothing evicted: per-lane kernels alone
     dict(autotune=0, side_blocks=4),                             # fixed settings
 ]
