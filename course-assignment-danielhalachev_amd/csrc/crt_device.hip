@@ -105,7 +105,10 @@ struct crt_ctx {
     hipEvent_t ev_fork[EV_RING] = {}, ev_s0[EV_RING] = {}, ev_s1[EV_RING] = {}, ev_s2[EV_RING] = {};        // ... of its side stream
     uint64_t launches = 0;
     uint32_t width = 0, height = 0, tiles_x = 0, tiles_y = 0;
-    KernelArgs args{};
+    SceneArgs scene{};                // host copy of what crt_create uploads to d_scene
+    FrameArgs frame{};                // host copy of the NEXT frame's block (camera, queues ...)
+    SceneArgs *d_scene = nullptr;
+    FrameArgs *d_frame_ring = nullptr, *h_frame_ring = nullptr;  // one slot per launch in flight (EV_RING): device, and the pinned source of its copy
     std::vector<void *> allocs;
     float *d_frame = nullptr;
     uint8_t *d_quant = nullptr;
@@ -144,19 +147,6 @@ struct crt_ctx {
     double node_mult = 1.3, ray_mult = 0.5, shadow_extra = 0.125;
     uint32_t sizing_seen_fallbacks = 0;
     uint64_t queue_bytes = 0;         // bytes of the per-frame buffers as allocated now
-    // crt_tuning::autotune (see autotune_step): settings whose best value depends on the scene are tried on the frames
-    // themselves and the faster setting kept.  No setting changes a pixel.
-    struct AutoTune {
-        uint32_t b0 = 0, hl = 0, sb = 0;    // the settings in force: level-0 step budget, heavy_level threshold, workgroups of the bulk shadow pass per CU (0 = the defaults)
-        int stage = 0;                      // 0: measuring the defaults; 1..N_CAND: trying candidate stage - 1; -1: settled
-        double best_ms = 0;
-        float samples[16] = {};
-        uint32_t best_b0 = 0, best_hl = 0, best_sb = 0;
-        int n = 0, seen = 0;
-        uint64_t next_harvest = 0;          // the next launch whose events have not been read yet
-        int tag[EV_RING] = {};              // the stage each slot's frame was launched in (-2: not a frame of this workload)
-        uint32_t items = 0, depth = 0;      // the workload being tuned (a change starts over)
-    } at;
     hipEvent_t ev_call0 = nullptr, ev_call1 = nullptr;  // around the last crt_render / crt_render_async call's device work
     bool pending = false;             // a frame enqueued by crt_render_async has not been waited for
     crt_options pending_options{};
@@ -368,7 +358,6 @@ extern "C" void crt_tuning_defaults(crt_tuning *t) {
     t->step_budget = 256; t->shadow_budget = 4096; t->level0_budget = 0;
     t->heavy_level = 100000; t->side_blocks = 3;
     t->node_cap = t->ray_cap = t->shadow_cap = 0;
-    t->autotune = 1;
 }
 
 extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) { return crt_create_tuned(s, device, nullptr, out); }
@@ -440,7 +429,7 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
     ctx->height = s->height;
     ctx->tiles_x = (s->width + TILE - 1) / TILE;
     ctx->tiles_y = (s->height + TILE - 1) / TILE;
-    KernelArgs &A = ctx->args;
+    SceneArgs &A = ctx->scene;
     static_assert(sizeof(crt_node) == 32 && sizeof(crt_triangle) == 64, "record sizes");
     if (upload(ctx, (const float4 *)s->nodes, (size_t)s->n_nodes * 2, &A.nodes)) return fail(CRT_ERR_HIP);
     if (upload(ctx, s->leaf_triangles, (size_t)s->n_leaf_triangles, &A.leaf_tris)) return fail(CRT_ERR_HIP);
@@ -715,8 +704,8 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
     A.bgx = s->background[0]; A.bgy = s->background[1]; A.bgz = s->background[2];
     A.width = s->width; A.height = s->height; A.tiles_x = ctx->tiles_x;
     const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    memcpy(A.cam, ident, sizeof(ident));
-    A.cam_pos[0] = A.cam_pos[1] = A.cam_pos[2] = 0;
+    memcpy(ctx->frame.cam, ident, sizeof(ident));
+    ctx->frame.cam_pos[0] = ctx->frame.cam_pos[1] = ctx->frame.cam_pos[2] = 0;
 
     size_t frame_bytes = (size_t)s->width * s->height * 3 * sizeof(float);
     CK(hipMalloc((void **)&ctx->d_frame, frame_bytes));
@@ -741,6 +730,11 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
     CK(hipMalloc((void **)&ctx->d_counters, 3 * C_N * sizeof(unsigned long long)));  // [levels | shadow pass 0 | the rest]
     // persistent grid: 8 blocks of 256 threads per CU gives every CU its 32 waves if registers allow
     ctx->grid_blocks = (uint32_t)ctx->num_cus * 8u;
+    // the argument blocks (kernel_common.h): the scene's once, a slot per frame in flight for the frames'
+    CK(hipMalloc((void **)&ctx->d_scene, sizeof(SceneArgs)));
+    CK(hipMemcpy(ctx->d_scene, &ctx->scene, sizeof(SceneArgs), hipMemcpyHostToDevice));
+    CK(hipMalloc((void **)&ctx->d_frame_ring, (size_t)crt_ctx::EV_RING * sizeof(FrameArgs)));
+    CK(hipHostMalloc((void **)&ctx->h_frame_ring, (size_t)crt_ctx::EV_RING * sizeof(FrameArgs)));
 #undef CK
     *out = ctx;
     return CRT_OK;
@@ -764,6 +758,9 @@ extern "C" void crt_destroy(crt_ctx *ctx) {
     if (ctx->d_sheavy) (void)hipFree(ctx->d_sheavy);
     if (ctx->d_hits) (void)hipFree(ctx->d_hits);
     if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
+    if (ctx->h_frame_ring) (void)hipHostFree(ctx->h_frame_ring);
+    if (ctx->d_frame_ring) (void)hipFree(ctx->d_frame_ring);
+    if (ctx->d_scene) (void)hipFree(ctx->d_scene);
     if (ctx->d_fallback_total) (void)hipFree(ctx->d_fallback_total);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_frames) (void)hipFree(ctx->d_frames);
@@ -791,8 +788,8 @@ extern "C" const char *crt_last_error(const crt_ctx *ctx) {
 
 extern "C" int crt_set_camera(crt_ctx *ctx, const float position[3], const float matrix[9]) {
     if (!ctx || !position || !matrix) return CRT_ERR_INVALID;
-    memcpy(ctx->args.cam_pos, position, 3 * sizeof(float));
-    memcpy(ctx->args.cam, matrix, 9 * sizeof(float));
+    memcpy(ctx->frame.cam_pos, position, 3 * sizeof(float));
+    memcpy(ctx->frame.cam, matrix, 9 * sizeof(float));
     return CRT_OK;
 }
 
@@ -827,8 +824,8 @@ static int ensure_frames(crt_ctx *ctx, uint32_t max_depth, bool gi) {
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_frames, waves * per_wave * sizeof(float)));
         ctx->frames_floats = waves * per_wave;
     }
-    ctx->args.frames = ctx->d_frames;
-    ctx->args.frame_wave_stride = per_wave;
+    ctx->frame.frames = ctx->d_frames;
+    ctx->frame.frame_wave_stride = per_wave;
     return CRT_OK;
 }
 
@@ -866,7 +863,7 @@ static void adapt_queue_sizing(crt_ctx *ctx) {
         ctx->shadow_extra = std::min(3.0, ctx->shadow_extra * 2.0);
         return;
     }
-    const KernelArgs &A = ctx->args;
+    const FrameArgs &A = ctx->frame;
     if (!A.s_node_cap || !ctx->last_counts_items) return;
     const uint64_t px = (uint64_t)ctx->last_counts_items * 64;
     uint64_t rays = 0, nodes = px;
@@ -882,7 +879,7 @@ static void adapt_queue_sizing(crt_ctx *ctx) {
 }
 
 static int ensure_stream(crt_ctx *ctx, uint32_t n_items) {
-    KernelArgs &A = ctx->args;
+    FrameArgs &A = ctx->frame;
     adapt_queue_sizing(ctx);
     const uint64_t px = (uint64_t)n_items * 64;
     const uint64_t lights = ctx->n_lights ? ctx->n_lights : 1;
@@ -941,66 +938,6 @@ static void launch_lds(K kernel, uint32_t blocks, uint32_t lds_bytes, hipStream_
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK), lds_bytes, stream, args...);
 }
 
-// crt_tuning::autotune.  Two constants of the ray-stream pass have no best value across scenes -- measured on the five
-// BASELINE scenes: the step budget of level 0's per-lane kernel (256 / 192 / 128: HW14 5.87 / 5.76 / 5.85 ms, HW11 6.27 / 6.07 /
-// 6.04, HW12 20.6 / 20.7 / 21.4) and the ray count below which a deeper level goes to the wave-per-ray kernel whole (100 k / 40 k:
-// HW14 5.74 / 5.61 with the 192 budget, HW11 6.3 / 7.6) -- and no counter of the previous frame predicts it.  So the frames
-// themselves are the measurement: every frame is timed by events anyway (ev0 .. ev4); a context renders a dozen frames with the
-// defaults, a dozen with each candidate, and keeps what was faster by more than the noise.  Frames of another size or depth start
-// it over; explicit budgets in crt_tuning switch it off.  Events are only read once they have completed (hipEventQuery): no wait.
-// A third one: the workgroups per CU of the bulk shadow pass beside the levels (4 / 3: HW12 20.6 / 19.6 ms, HW11 6.06 / 6.0, HW14 and HW08 level;
-// 3 is the default, 4 the candidate).
-static constexpr uint32_t AT_KEEP = 0xFFFFFFFFu;  // "the best value so far"
-static const uint32_t AT_CAND[][3] = {{192u, 0u, 0u}, {128u, 0u, 0u}, {AT_KEEP, 40000u, 0u}, {AT_KEEP, AT_KEEP, 4u}};  // {level-0 budget, heavy_level, side workgroups}
-static constexpr int AT_N_CAND = 4, AT_SKIP = 3, AT_SAMPLES = 12;
-static void autotune_step(crt_ctx *ctx, uint32_t n_items, uint32_t depth, bool eligible) {
-    crt_ctx::AutoTune &T = ctx->at;
-    const int slot_now = (int)(ctx->launches % crt_ctx::EV_RING);
-    if (!eligible) { T.tag[slot_now] = -2; return; }
-    if (T.items != n_items || T.depth != depth) {  // another workload: start over with the defaults
-        T = crt_ctx::AutoTune();
-        T.items = n_items; T.depth = depth;
-        T.next_harvest = ctx->launches;
-        for (int i = 0; i < crt_ctx::EV_RING; i++) T.tag[i] = -2;
-    }
-    // read the frames that have completed since the last look
-    while (T.next_harvest < ctx->launches) {
-        const uint64_t j = T.next_harvest;
-        if (j + crt_ctx::EV_RING <= ctx->launches) { T.next_harvest++; continue; }  // its slot has been reused
-        const int slot = (int)(j % crt_ctx::EV_RING);
-        if (hipEventQuery(ctx->ev4[slot]) != hipSuccess) { (void)hipGetLastError(); break; }
-        T.next_harvest++;
-        float ms = 0;
-        if (T.stage < 0 || T.tag[slot] != T.stage || hipEventElapsedTime(&ms, ctx->ev0[slot], ctx->ev4[slot]) != hipSuccess) { (void)hipGetLastError(); continue; }
-        if (++T.seen <= AT_SKIP) continue;  // the first frames after a change still carry the previous setting's queues and counters
-        if (T.n < AT_SAMPLES) T.samples[T.n++] = ms;
-    }
-    // a candidate whose first frames are all clearly slower than the best so far is dropped at once (its fastest frame 4 % behind)
-    if (T.stage > 0 && T.n >= 4 && T.n < AT_SAMPLES && *std::min_element(T.samples, T.samples + T.n) > T.best_ms * 1.04) {
-        for (int i = T.n; i < AT_SAMPLES; i++) T.samples[i] = T.samples[0];
-        T.n = AT_SAMPLES;
-    }
-    if (T.stage >= 0 && T.n >= AT_SAMPLES) {
-        // the mean of the faster two thirds: a frame that was redone by the fallback, or met another process, does not count
-        std::sort(T.samples, T.samples + AT_SAMPLES);
-        double mean = 0;
-        for (int i = 0; i < AT_SAMPLES * 2 / 3; i++) mean += T.samples[i];
-        mean /= AT_SAMPLES * 2 / 3;
-        if (T.stage == 0 || mean < T.best_ms * 0.993) { T.best_ms = mean; T.best_b0 = T.b0; T.best_hl = T.hl; T.best_sb = T.sb; }
-        T.stage = T.stage + 1 <= AT_N_CAND ? T.stage + 1 : -1;
-        T.n = 0; T.seen = 0;
-        if (T.stage > 0) {
-            const uint32_t *c = AT_CAND[T.stage - 1];
-            T.b0 = c[0] == AT_KEEP ? T.best_b0 : c[0];
-            T.hl = c[1] == AT_KEEP ? T.best_hl : (c[1] ? c[1] : T.best_hl);
-            T.sb = c[2] == AT_KEEP ? T.best_sb : (c[2] ? c[2] : T.best_sb);
-        } else {
-            T.b0 = T.best_b0; T.hl = T.best_hl; T.sb = T.best_sb;  // settled
-        }
-    }
-    T.tag[slot_now] = T.stage;
-}
-
 // One frame's launches.  Ray-stream path (kernel_stream.h), per recursion level g = 0 .. MAX_DEPTH on `stream`:
 //   the per-lane kernel (plan kernels; the faithful kernel for the counting build and for scenes without a plan),
 //   heavy_trace_closest for the walks it handed over (or the whole level), stream_shade_evicted for their hits;
@@ -1010,30 +947,29 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
     const bool gi = o->use_gi != 0;  // the GI / multi-sample mode: rendered pixel by pixel by render_lanes<.., true> (kernel_lane.h)
     int rc = ensure_frames(ctx, o->max_depth, gi);
     if (rc) return rc;
-    KernelArgs &A = ctx->args;
-    A.use_gi = gi ? 1u : 0u;
-    A.gi_samples = o->gi_sample_size;
-    A.rays_per_pixel = o->rays_per_pixel;
-    A.monte_carlo_bias = o->monte_carlo_bias;
-    A.gi_seed = o->gi_seed;
+    const SceneArgs &SC = ctx->scene;
+    FrameArgs &F = ctx->frame;
+    F.use_gi = gi ? 1u : 0u;
+    F.gi_samples = o->gi_sample_size;
+    F.rays_per_pixel = o->rays_per_pixel;
+    F.monte_carlo_bias = o->monte_carlo_bias;
+    F.gi_seed = o->gi_seed;
     const bool stream_mode = ctx->mode == crt_ctx::MODE_STREAM && !gi;
     if (stream_mode && o->max_depth + 1 > (uint32_t)MAX_GENERATIONS) {
         ctx->error = "max_depth too large for the ray-stream pass";
         return CRT_ERR_INVALID;
     }
-    A.max_depth = o->max_depth;
-    A.shadow_bias = o->shadow_bias;
-    A.reflection_bias = o->reflection_bias;
-    A.refraction_bias = o->refraction_bias;
-    A.items = ctx->d_items;
-    A.n_items = n_items;
-    A.pixel_counter = ctx->d_sync + 0;
-    A.out = d_out;
-    A.packed = packed;
-    A.counters = ctx->d_counters;
-    A.s_counts = ctx->d_scounts;
-    A.only_if_overflow = 0;
-    A.fallback_total = ctx->d_fallback_total;
+    F.max_depth = o->max_depth;
+    F.shadow_bias = o->shadow_bias;
+    F.reflection_bias = o->reflection_bias;
+    F.refraction_bias = o->refraction_bias;
+    F.items = ctx->d_items;
+    F.n_items = n_items;
+    F.pixel_counter = ctx->d_sync + 0;
+    F.out = d_out;
+    F.packed = packed;
+    F.s_counts = ctx->d_scounts;
+    F.fallback_total = ctx->d_fallback_total;
     const bool count = o->collect_counters == 1;       // the counting build: every ray walked the reference's way
     const bool exec_count = o->collect_counters == 2;  // the production kernels, tallying the tests they execute
     CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_sync, 0, 4 * sizeof(uint32_t), stream));
@@ -1041,12 +977,11 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
     harvest_counts(ctx);
     const int slot = (int)(ctx->launches % crt_ctx::EV_RING);
     if (ctx->launches >= (uint64_t)crt_ctx::EV_RING) {
-        // the slot's previous frame (64 launches ago) must be complete before its events and its pinned words are reused
+        // the slot's previous frame (64 launches ago) must be complete before its events, its pinned words and its argument block are reused
         CRT_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev4[slot]));
         harvest_counts(ctx);
     }
     ctx->slot_items[slot] = 0;
-    ctx->at.tag[slot] = -2;  // (crt_tuning::autotune: not a frame it may learn from, unless autotune_step below says otherwise)
     const uint32_t lane_need = (n_items * 64u + BLOCK - 1) / BLOCK;
     const uint32_t lane_blocks = std::max(1u, lane_need < ctx->grid_blocks ? lane_need : ctx->grid_blocks);
     CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0[slot], stream));
@@ -1057,23 +992,27 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         ctx->launches++;
         return CRT_OK;
     }
+    // the wave-per-ray path needs nested boxes; the counting build walks every ray the reference's way
+    const bool heavy = stream_mode && ctx->step_budget && SC.nested_boxes && !count;
+    // the plan kernels (kernel_plan.h): a small top-level tree (its leaves as a plan), 32-bit offsets, compact leaf links
+    const bool lean = heavy && ctx->lean_ok && SC.plan_ok;
     if (stream_mode) {
         rc = ensure_stream(ctx, n_items);
         if (rc) return rc;
+        F.heavy_level_threshold = lean ? ctx->tuning.heavy_level : 0u;
+        // level 0 owns the first n_items * 64 * n_lights slots of the shadow queue; the deeper levels append
+        F.fixed0 = (uint64_t)n_items * 64u * ctx->n_lights <= F.s_shadow_cap ? 1u : 0u;
+    }
+    // this frame's argument block, into its own slot (the copy is ordered on `stream` ahead of the kernels that read it)
+    ctx->h_frame_ring[slot] = F;
+    CRT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_frame_ring + slot, ctx->h_frame_ring + slot, sizeof(FrameArgs), hipMemcpyHostToDevice, stream));
+    KernelArgs A{};
+    A.s = (scene_args_p)ctx->d_scene;
+    A.f = (frame_args_p)(ctx->d_frame_ring + slot);
+    A.counters = ctx->d_counters;
+    if (stream_mode) {
         CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_scounts, 0, SC_ALLOC_WORDS * sizeof(uint32_t), stream));
-        // the wave-per-ray path needs nested boxes; the counting build walks every ray the reference's way
-        const bool heavy = ctx->step_budget && A.nested_boxes && !count;
-        // the plan kernels (kernel_plan.h): a small top-level tree (its leaves as a plan), 32-bit offsets, compact leaf links
-        const bool lean = heavy && ctx->lean_ok && A.plan_ok;
-        A.heavy_level_threshold = lean ? ctx->tuning.heavy_level : 0u;
-        uint32_t side_per_cu = ctx->tuning.side_blocks;  // workgroups per CU of the bulk shadow pass beside the levels
-        {
-            const bool eligible = ctx->tuning.autotune && lean && !exec_count && ctx->tuning.level0_budget == 0u &&
-                                  ctx->tuning.heavy_level == 100000u && ctx->tuning.step_budget == 256u;
-            autotune_step(ctx, n_items, o->max_depth, eligible);
-            if (eligible && ctx->at.hl) A.heavy_level_threshold = ctx->at.hl;
-            if (eligible && ctx->at.sb && ctx->tuning.side_blocks == 3u) side_per_cu = ctx->at.sb;
-        }
+        const uint32_t side_per_cu = ctx->tuning.side_blocks;  // workgroups per CU of the bulk shadow pass beside the levels
         A.exec_count = exec_count ? 1u : 0u;
         A.exec_counters = ctx->d_exec;
         A.exec_plan = ctx->d_exec + 4;
@@ -1082,15 +1021,8 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         A.bundle = REFILL_BUNDLE;
         A.wave_prio = 3u;  // the levels' waves (the frame's critical path) ahead of the bulk shadow pass's, which share their SIMDs
         A.force_whole = 0u;
-        A.fixed0 = 0;
-        {   // level 0 owns the first n_items * 64 * n_lights slots of the shadow queue; the deeper levels append
-            const uint64_t n0 = (uint64_t)n_items * 64u * ctx->n_lights;
-            if (n0 <= A.s_shadow_cap) {
-                A.fixed0 = 1;
-                CRT_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->d_scounts + SC_SHADOW), (int)(uint32_t)n0, 1, stream));
-            }
-        }
-        const uint32_t plds = A.plan_list_words * BLOCK * (uint32_t)sizeof(uint32_t);  // kernel_plan.h: mesh lists
+        if (F.fixed0) CRT_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->d_scounts + SC_SHADOW), (int)((uint32_t)n_items * 64u * ctx->n_lights), 1, stream));
+        const uint32_t plds = SC.plan_list_words * BLOCK * (uint32_t)sizeof(uint32_t);  // kernel_plan.h: mesh lists
         KernelArgs S = A;  // argument block of the bulk shadow pass
         S.wave_prio = 0u;
         S.counters = ctx->d_counters + C_N;
@@ -1111,7 +1043,6 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         const uint64_t est0 = (uint64_t)n_items * 64u * 70u / ((uint64_t)lane_blocks * BLOCK);
         uint32_t budget0 = est0 >= ctx->step_budget ? ctx->step_budget : (est0 < 64u ? 64u : (uint32_t)est0);
         if (ctx->tuning.level0_budget) budget0 = ctx->tuning.level0_budget;
-        else if (ctx->at.b0 && ctx->at.tag[slot] >= -1 && ctx->at.b0 < budget0) budget0 = ctx->at.b0;  // crt_tuning::autotune
         const uint32_t *prev = ctx->last_counts_items == n_items ? ctx->last_counts.data() : nullptr;  // a completed frame of this size
         for (uint32_t g = 0; g <= o->max_depth; g++) {
             A.step_budget = heavy ? (g == 0 ? budget0 : ctx->step_budget) : 0u;
@@ -1121,7 +1052,7 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
             uint32_t level_blocks = lane_blocks;
             if (g >= 1 && lean && prev) {
                 const uint32_t was = prev[SC_COUNT + g];
-                const uint32_t want = was < A.heavy_level_threshold ? 64u : std::max<uint32_t>((uint32_t)ctx->num_cus, (was + was / 2u + BLOCK - 1) / BLOCK);
+                const uint32_t want = was < F.heavy_level_threshold ? 64u : std::max<uint32_t>((uint32_t)ctx->num_cus, (was + was / 2u + BLOCK - 1) / BLOCK);
                 level_blocks = std::min(lane_blocks, want);
             }
             if (count) launch(stream_trace_shade<true>, lane_blocks, stream, A, g);
@@ -1508,7 +1439,7 @@ extern "C" int crt_debug_stream_counts(crt_ctx *ctx, uint32_t *out, uint32_t max
 // Which kernels a production frame of this context runs (bench.py names the roofline's kernel with it).
 extern "C" int crt_describe_kernels(const crt_ctx *ctx, char *out, size_t size) {
     if (!ctx || !out || size == 0) return CRT_ERR_INVALID;
-    const KernelArgs &A = ctx->args;
+    const SceneArgs &A = ctx->scene;
     std::string d;
     if (ctx->mode == crt_ctx::MODE_LANES) d = "all=render_lanes<false>";
     else {
@@ -1517,10 +1448,6 @@ extern "C" int crt_describe_kernels(const crt_ctx *ctx, char *out, size_t size) 
         d = std::string("level0=") + (!lean ? "stream_trace_shade<false>" : "stream_trace_shade_plan");
         d += std::string(";shadow0=") + (!lean ? "stream_trace_shadow<false>" : "stream_trace_shadow_plan<0u>");
         d += std::string(";levels=") + (!heavy ? "stream_trace_shade<false>" : "heavy_trace_closest");
-        char buf[160];
-        snprintf(buf, sizeof(buf), ";autotune=%s level0_budget=%u heavy_level=%u side_blocks=%u", !ctx->tuning.autotune ? "off" : (ctx->at.stage < 0 ? "settled" : "measuring"),
-                 ctx->at.b0, ctx->at.hl ? ctx->at.hl : ctx->tuning.heavy_level, ctx->at.sb ? ctx->at.sb : ctx->tuning.side_blocks);
-        d += buf;
     }
     snprintf(out, size, "%s", d.c_str());
     return CRT_OK;

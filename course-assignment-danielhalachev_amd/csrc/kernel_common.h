@@ -42,7 +42,14 @@ struct HeavyMesh {
     uint32_t count[4];            // entries per level
 };
 
-struct KernelArgs {
+// What the kernels are given.  Three blocks, by how often they change (round 2 passed one 560 - 1000-byte struct by value:
+// every field any code path touched was loaded at kernel entry and stayed in scalar registers, 60 - 130 of them spilled):
+//   SceneArgs   written once by crt_create, resident in device memory: the flattened scene and everything derived from it
+//   FrameArgs   one per frame, in a device slot of its own (frames are enqueued without waiting): camera, options, queues
+//   KernelArgs  by value, 80 bytes: pointers to the two (constant address space: a field is one scalar load where it is used,
+//               and a load on a cold path -- refill, eviction, shading -- is not hoisted into the walk loop) + what differs
+//               between the launches of one frame
+struct SceneArgs {
     const float4 *nodes;          // 2 x float4 per crt_node
     const uint32_t *leaf_tris;
     const uint32_t *leaf_meshes;
@@ -59,6 +66,37 @@ struct KernelArgs {
     uint32_t n_lights, top_root;
     float bgx, bgy, bgz;
     uint32_t width, height, tiles_x;
+    uint32_t nested_boxes;        // every inner node's child boxes lie inside its own box (checked by crt_create)
+    // heavy-ray path (kernel_heavy.h): leaf boxes in visit order + 64-ary group boxes above them
+    const float4 *hbox;           // 2 x float4 per entry: {lo, begin|-} {hi, count|-}
+    const HeavyMesh *hmesh;       // per mesh
+    // single-leaf meshes (walls, floors: a root that is a leaf): the wave-per-ray kernels test them all in one step at the
+    // start of a ray (kernel_heavy.h: TinyResults).  tiny_at[k] = the mesh's entry in hbox, tiny_flags[k] = crt_mesh::flags;
+    // the device copy of crt_mesh::pad holds k + 1 for such a mesh, 0 for the others.
+    // the top-level tree held in registers by the wave-per-ray kernels (kernel_heavy.h: TopRegs) when it is small:
+    // its nodes are [top_first, top_first + top_count), top_count <= 64, leaf_meshes has <= 128 entries and there are <= 64 meshes
+    uint32_t top_fast, top_first, top_count, top_leaf_entries, top_meshes;
+    uint32_t top_lds;             // the top-level tree fits the wave-per-ray kernels' LDS copy (kernel_walk.h: TopLds): <= 256 nodes, 1024 entries, 256 meshes
+    const uint32_t *tiny_at, *tiny_flags;
+    uint32_t tiny_count;
+    // The top-level tree as a PLAN for the per-lane kernels (kernel_plan.h), built by crt_create when the tree is small
+    // (top_fast) and its boxes are nested: the top-level LEAVES in visit order.  A ray reaches a leaf exactly when the leaf's
+    // own box passes (nesting + monotone slab test, as for the mesh trees), so a wave tests its rays against leaf k with k
+    // uniform -- boxes in scalar registers, no gathers, no divergence -- instead of walking ~40 nodes and ~75 entries per lane.
+    uint32_t plan_ok;             // the plan kernels may be used
+    uint32_t plan_leaves;         // number of top-level leaves, <= 64
+    const float4 *plan_boxes;     // 4 x float4 per leaf: {lo, first entry in leaf_meshes} {hi, number of entries} {shadow mask lo, hi, -, -} {-}
+    const uint32_t *plan_shadow_mesh;  // shadow order: bit b = mesh plan_shadow_mesh[b] (big meshes first: likeliest occluders)
+    uint32_t plan_shadow_bits;    // number of non-refractive meshes, <= 64
+    // compact forms (crt_create): 3 x float4 per leaf entry {v0,nx} {v1,ny} {v2,nz}; the nodes again with leaf links
+    // LEAF | (entries - 1) << 24 | first entry
+    uint32_t plan_compact;
+    const float4 *ptris;
+    const float4 *pnodes;
+    uint32_t plan_list_words;     // LDS words per lane of a closest-hit ray's mesh list: ceil(meshes / 4)
+};
+
+struct FrameArgs {
     float cam_pos[3];
     float cam[9];
     uint32_t max_depth;
@@ -70,8 +108,6 @@ struct KernelArgs {
     uint32_t packed;              // 0: out is the H*W*3 frame, 1: out is packed by out_tile
     float *frames;                // [wave][level][FRAME_DWORDS][64]
     uint64_t frame_wave_stride;   // floats per wave
-    unsigned long long *counters; // C_N, counting build only
-    uint32_t nested_boxes;        // every inner node's child boxes lie inside its own box (checked by crt_create)
     // ray-stream buffers (kernel_stream.h)
     float4 *s_rayq[2];            // closest-hit ray queues of alternating recursion levels, 2 x float4 per ray
     float4 *s_shadowq;            // shadow rays of all levels: {origin, light distance}, {direction, light factor}
@@ -79,52 +115,34 @@ struct KernelArgs {
     float4 *s_nodes;              // ray-tree nodes (TNode), 2 x float4 each
     uint32_t *s_counts;           // SC_WORDS counters / cursors, zeroed before every frame
     uint32_t s_ray_cap, s_shadow_cap, s_node_cap;
-    uint32_t only_if_overflow;    // lane kernel: run only when the stream pass overflowed its queues
-    uint32_t *fallback_total;     // frames redone that way since crt_create (never reset)
-    // heavy-ray path (kernel_heavy.h): leaf boxes in visit order + 64-ary group boxes above them
-    const float4 *hbox;           // 2 x float4 per entry: {lo, begin|-} {hi, count|-}
-    const HeavyMesh *hmesh;       // per mesh
+    uint32_t *fallback_total;     // frames redone by the queue-less kernel since crt_create (never reset)
     uint32_t *s_heavy;            // evicted ray ids of the current recursion level
     uint32_t *s_sheavy;           // evicted shadow ray ids (same capacity)
     uint32_t s_heavy_cap;
     float4 *s_hits;               // closest-hit records of evicted rays: {t, triangle, mesh, have}
-    uint32_t step_budget;         // a lane's walk is evicted after this many steps (0 = never)
     uint32_t heavy_level_threshold; // a recursion level with fewer rays than this goes to heavy_trace whole
+    uint32_t fixed0;              // level 0's shadow rays go to fixed, tile-ordered slots (kernel_stream.h: level0_shadow_slot)
+    uint32_t use_gi, gi_samples, rays_per_pixel, gi_seed;  // crt_options: the GI / multi-sample mode (kernel_lane.h, gi_random.h)
+    float monte_carlo_bias;
+};
+
+typedef const __attribute__((address_space(4))) SceneArgs *scene_args_p;
+typedef const __attribute__((address_space(4))) FrameArgs *frame_args_p;
+
+struct KernelArgs {
+    scene_args_p s;
+    frame_args_p f;
+    unsigned long long *counters; // C_N, counting build only
     // crt_options::collect_counters == 2: the production kernels tally the box and triangle tests they EXECUTE (the exact
     // shortcuts make that fewer than the reference's, which the counting build tallies): {box tests, triangle tests}
     unsigned long long *exec_counters;
     unsigned long long *exec_plan;  // ... and the plan loops' box tests (wave-uniform boxes: no per-lane fetch), one word
     uint32_t exec_count;
-    uint32_t bundle;              // shadow passes: refill a wave when at most this many of its lanes are still walking (>= 64: at once)
-    // single-leaf meshes (walls, floors: a root that is a leaf): the wave-per-ray kernels test them all in one step at the
-    // start of a ray (kernel_heavy.h: TinyResults).  tiny_at[k] = the mesh's entry in hbox, tiny_flags[k] = crt_mesh::flags;
-    // the device copy of crt_mesh::pad holds k + 1 for such a mesh, 0 for the others.
-    // the top-level tree held in registers by the wave-per-ray kernels (kernel_heavy.h: TopRegs) when it is small:
-    // its nodes are [top_first, top_first + top_count), top_count <= 64, leaf_meshes has <= 128 entries and there are <= 64 meshes
-    uint32_t top_fast, top_first, top_count, top_leaf_entries, top_meshes;
-    uint32_t top_lds;             // the top-level tree fits the per-lane kernels' LDS copy (kernel_walk.h: TopLds): <= 256 nodes, 1024 entries, 256 meshes
-    const uint32_t *tiny_at, *tiny_flags;
-    uint32_t tiny_count;
-    uint32_t fixed0;              // level 0's shadow rays go to fixed, tile-ordered slots (kernel_stream.h: level0_shadow_slot)
-    // The top-level tree as a PLAN for the per-lane kernels (kernel_plan.h), built by crt_create when the tree is small
-    // (top_fast) and its boxes are nested: the top-level LEAVES in visit order.  A ray reaches a leaf exactly when the leaf's
-    // own box passes (nesting + monotone slab test, as for the mesh trees), so a wave tests its rays against leaf k with k
-    // uniform -- boxes in scalar registers, no gathers, no divergence -- instead of walking ~40 nodes and ~75 entries per lane.
-    uint32_t plan_ok;             // the plan kernels may be used
-    uint32_t plan_leaves;         // number of top-level leaves, <= 64
-    const float4 *plan_boxes;     // 2 x float4 per leaf: {lo, first entry in leaf_meshes} {hi, number of entries}
-    const uint32_t *plan_shadow_mesh;  // shadow order: bit b = mesh plan_shadow_mesh[b] (big meshes first: likeliest occluders)
-    uint32_t plan_shadow_bits;    // number of non-refractive meshes, <= 64
-    // compact forms (crt_create): 3 x float4 per leaf entry {v0,nx} {v1,ny} {v2,nz}; the nodes again with leaf links
-    // LEAF | (entries - 1) << 24 | first entry
-    uint32_t plan_compact;
-    const float4 *ptris;
-    const float4 *pnodes;
-    uint32_t plan_list_words;     // LDS words per lane of a closest-hit ray's mesh list: ceil(meshes / 4)
-    uint32_t use_gi, gi_samples, rays_per_pixel, gi_seed;  // crt_options: the GI / multi-sample mode (kernel_lane.h, gi_random.h)
-    float monte_carlo_bias;
+    uint32_t step_budget;         // a lane's walk is evicted after this many steps (0 = never)
+    uint32_t bundle;              // plan kernels: refill a wave when at most this many of its lanes are still walking (>= 64: at once)
+    uint32_t only_if_overflow;    // lane kernel: run only when the stream pass overflowed its queues
     uint32_t force_whole;         // this level's per-lane kernel was not launched: the wave-per-ray kernel takes all its rays (kernel_stream.h)
-    uint32_t wave_prio;           // s_setprio of the recursion levels' waves (crt_tuning::wave_priority)
+    uint32_t wave_prio;           // s_setprio of the recursion levels' waves over the bulk shadow pass's, which shares the SIMDs with them
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -250,17 +268,17 @@ __device__ __forceinline__ bool triangle_test(const Ray &R, bool primary, const 
 __device__ __forceinline__ void primary_ray(const KernelArgs &A, uint32_t px, uint32_t py, Ray &R) {
     float x = (float)px + 0.5f;
     float y = (float)py + 0.5f;
-    x = x / (float)A.width;
-    y = y / (float)A.height;
+    x = x / (float)A.s->width;
+    y = y / (float)A.s->height;
     x = (2.0f * x) - 1.0f;
     y = 1.0f - (2.0f * y);
-    x = x * ((float)A.width / (float)A.height);
+    x = x * ((float)A.s->width / (float)A.s->height);
     const float z = -1.0f;
-    R.dx = x * A.cam[0] + y * A.cam[3] + z * A.cam[6];   // row vector x matrix, Matrix.h:137-142
-    R.dy = x * A.cam[1] + y * A.cam[4] + z * A.cam[7];
-    R.dz = x * A.cam[2] + y * A.cam[5] + z * A.cam[8];
+    R.dx = x * A.f->cam[0] + y * A.f->cam[3] + z * A.f->cam[6];   // row vector x matrix, Matrix.h:137-142
+    R.dy = x * A.f->cam[1] + y * A.f->cam[4] + z * A.f->cam[7];
+    R.dz = x * A.f->cam[2] + y * A.f->cam[5] + z * A.f->cam[8];
     normalize3(R.dx, R.dy, R.dz);
-    R.ox = A.cam_pos[0]; R.oy = A.cam_pos[1]; R.oz = A.cam_pos[2];
+    R.ox = A.f->cam_pos[0]; R.oy = A.f->cam_pos[1]; R.oz = A.f->cam_pos[2];
     normalize3(R.dx, R.dy, R.dz);
     ray_prepare(R);
 }
@@ -290,11 +308,11 @@ __device__ __forceinline__ void texture_color(const KernelArgs &A, const DTextur
         else { r = T.ax; g = T.ay; b = T.az; }
         return;
     }
-    const uint32_t i0 = A.tri_verts[3 * (size_t)tri], i1 = A.tri_verts[3 * (size_t)tri + 1],
-                   i2 = A.tri_verts[3 * (size_t)tri + 2];
+    const uint32_t i0 = A.s->tri_verts[3 * (size_t)tri], i1 = A.s->tri_verts[3 * (size_t)tri + 1],
+                   i2 = A.s->tri_verts[3 * (size_t)tri + 2];
     // u * UV1 + v * UV2 + (w * UV0), Texture.cpp:34-36 / 63-65 (only x and y are used)
-    const float uvx = (u * A.vuvs[3 * (size_t)i1] + v * A.vuvs[3 * (size_t)i2]) + w * A.vuvs[3 * (size_t)i0];
-    const float uvy = (u * A.vuvs[3 * (size_t)i1 + 1] + v * A.vuvs[3 * (size_t)i2 + 1]) + w * A.vuvs[3 * (size_t)i0 + 1];
+    const float uvx = (u * A.s->vuvs[3 * (size_t)i1] + v * A.s->vuvs[3 * (size_t)i2]) + w * A.s->vuvs[3 * (size_t)i0];
+    const float uvy = (u * A.s->vuvs[3 * (size_t)i1 + 1] + v * A.s->vuvs[3 * (size_t)i2 + 1]) + w * A.s->vuvs[3 * (size_t)i0 + 1];
     if (T.kind == CRT_TEX_CHECKER) {
         const unsigned int x = x86_float_to_uint(uvx / T.scalar);
         const unsigned int y = x86_float_to_uint(uvy / T.scalar);
@@ -306,7 +324,7 @@ __device__ __forceinline__ void texture_color(const KernelArgs &A, const DTextur
     int y = x86_float_to_int((1.0f - uvy) * (float)(int)T.h);
     x = (x < 0) ? 0 : (((int)T.w - 1 < x) ? (int)T.w - 1 : x);  // std::clamp
     y = (y < 0) ? 0 : (((int)T.h - 1 < y) ? (int)T.h - 1 : y);
-    const uint32_t px = A.texels[T.offset + (size_t)y * T.w + (size_t)x];
+    const uint32_t px = A.s->texels[T.offset + (size_t)y * T.w + (size_t)x];
     const float coefficient = 1.0f / 255.0f;  // Texture.cpp:53-57
     r = (float)(px & 255u) * coefficient;
     g = (float)((px >> 8) & 255u) * coefficient;
@@ -321,10 +339,10 @@ struct Surface {
 };
 
 __device__ __forceinline__ void surface_at(const KernelArgs &A, const Ray &R, float t, uint32_t tri, uint32_t mesh, Surface &S) {
-    const float4 ta = A.tris[4 * (size_t)tri + 0], tb = A.tris[4 * (size_t)tri + 1], tc = A.tris[4 * (size_t)tri + 2];
+    const float4 ta = A.s->tris[4 * (size_t)tri + 0], tb = A.s->tris[4 * (size_t)tri + 1], tc = A.s->tris[4 * (size_t)tri + 2];
     S.px = R.ox + R.dx * t; S.py = R.oy + R.dy * t; S.pz = R.oz + R.dz * t;  // Ray.cpp:23
     S.nx = ta.w; S.ny = tb.w; S.nz = tc.w;
-    S.M = A.materials[A.meshes[mesh].material];
+    S.M = A.s->materials[A.s->meshes[mesh].material];
     S.u = 0; S.v = 0;
     if (S.M.smooth || S.M.texture >= 0) {
         // Triangle::getBarycentricCoordinates (Triangle.cpp:63-73)
@@ -335,12 +353,12 @@ __device__ __forceinline__ void surface_at(const KernelArgs &A, const Ray &R, fl
         S.u = len3(v0py * e2z - v0pz * e2y, v0pz * e2x - v0px * e2z, v0px * e2y - v0py * e2x) / area;
         S.v = len3(e1y * v0pz - e1z * v0py, e1z * v0px - e1x * v0pz, e1x * v0py - e1y * v0px) / area;
         if (S.M.smooth) {  // KDTree.cpp:180-185: n1*u + n2*v + n0*(1-u-v), normalised
-            const uint32_t i0 = A.tri_verts[3 * (size_t)tri], i1 = A.tri_verts[3 * (size_t)tri + 1],
-                           i2 = A.tri_verts[3 * (size_t)tri + 2];
+            const uint32_t i0 = A.s->tri_verts[3 * (size_t)tri], i1 = A.s->tri_verts[3 * (size_t)tri + 1],
+                           i2 = A.s->tri_verts[3 * (size_t)tri + 2];
             const float w = 1 - S.u - S.v;
-            S.nx = (A.vnormals[3 * (size_t)i1] * S.u + A.vnormals[3 * (size_t)i2] * S.v) + A.vnormals[3 * (size_t)i0] * w;
-            S.ny = (A.vnormals[3 * (size_t)i1 + 1] * S.u + A.vnormals[3 * (size_t)i2 + 1] * S.v) + A.vnormals[3 * (size_t)i0 + 1] * w;
-            S.nz = (A.vnormals[3 * (size_t)i1 + 2] * S.u + A.vnormals[3 * (size_t)i2 + 2] * S.v) + A.vnormals[3 * (size_t)i0 + 2] * w;
+            S.nx = (A.s->vnormals[3 * (size_t)i1] * S.u + A.s->vnormals[3 * (size_t)i2] * S.v) + A.s->vnormals[3 * (size_t)i0] * w;
+            S.ny = (A.s->vnormals[3 * (size_t)i1 + 1] * S.u + A.s->vnormals[3 * (size_t)i2 + 1] * S.v) + A.s->vnormals[3 * (size_t)i0 + 1] * w;
+            S.nz = (A.s->vnormals[3 * (size_t)i1 + 2] * S.u + A.s->vnormals[3 * (size_t)i2 + 2] * S.v) + A.s->vnormals[3 * (size_t)i0 + 2] * w;
             normalize3(S.nx, S.ny, S.nz);
         }
     }
@@ -350,14 +368,14 @@ __device__ __forceinline__ void surface_at(const KernelArgs &A, const Ray &R, fl
 // length and the factor (intensity / sphereArea * angle) the albedo is multiplied by when it is unoccluded.
 __device__ __forceinline__ void light_setup(const KernelArgs &A, uint32_t li, float hpx, float hpy, float hpz, float hnx,
                                             float hny, float hnz, Ray &R, float &dist, float &kfac) {
-    const float4 lg = A.lights[li];
+    const float4 lg = A.s->lights[li];
     float lx = lg.x - hpx, ly = lg.y - hpy, lz = lg.z - hpz;
     dist = len3(lx, ly, lz);
     const float area = 4 * dist * dist * PI_F;
     normalize3(lx, ly, lz);
     const float angle = std_max(0.0f, dot3(lx, ly, lz, hnx, hny, hnz));
     kfac = lg.w / area * angle;
-    R.ox = hpx + hnx * A.shadow_bias; R.oy = hpy + hny * A.shadow_bias; R.oz = hpz + hnz * A.shadow_bias;
+    R.ox = hpx + hnx * A.f->shadow_bias; R.oy = hpy + hny * A.f->shadow_bias; R.oz = hpz + hnz * A.f->shadow_bias;
     R.dx = lx; R.dy = ly; R.dz = lz;
     ray_prepare(R);
 }

@@ -64,7 +64,7 @@ __device__ __forceinline__ float wave_min(float v) {
 template <bool SHADOW>
 __device__ __forceinline__ void heavy_batch(const KernelArgs &A, const Ray &R, const bool primary, const bool valid,
                                             const size_t e, HeavyState &H) {
-    const float4 a = A.ltris[4 * e + 0], b = A.ltris[4 * e + 1], c = A.ltris[4 * e + 2], d = A.ltris[4 * e + 3];
+    const float4 a = A.s->ltris[4 * e + 0], b = A.s->ltris[4 * e + 1], c = A.s->ltris[4 * e + 2], d = A.s->ltris[4 * e + 3];
     float t = 0;
     if (A.exec_count) { H.ntri += (uint32_t)__popcll(__ballot(valid)); H.n_batches++; }
     const bool acc = valid && triangle_test(R, primary, a, b, c, d.x, t);
@@ -129,8 +129,8 @@ __device__ __forceinline__ ChunkBoxes heavy_chunk_load(const KernelArgs &A, cons
     const uint32_t idx = chunk * 64u + lane;
     C.valid = idx < M.count[LEVEL];
     const size_t at = (size_t)M.first[LEVEL] + (C.valid ? idx : 0u);
-    C.b0 = A.hbox[2 * at];
-    C.b1 = A.hbox[2 * at + 1];
+    C.b0 = A.s->hbox[2 * at];
+    C.b1 = A.s->hbox[2 * at + 1];
     return C;
 }
 
@@ -169,7 +169,7 @@ struct TinyResults {  // per lane k < tiny_count: the closest hit in single-leaf
 template <bool SHADOW>
 __device__ __forceinline__ void heavy_tiny_batch(const KernelArgs &A, const Ray &R, const bool primary, const bool valid, const size_t e,
                                                  const uint32_t tag, unsigned long long tags, TinyResults &T, HeavyState &H, const uint32_t lane) {
-    const float4 a = A.ltris[4 * e + 0], b = A.ltris[4 * e + 1], c = A.ltris[4 * e + 2], d = A.ltris[4 * e + 3];
+    const float4 a = A.s->ltris[4 * e + 0], b = A.s->ltris[4 * e + 1], c = A.s->ltris[4 * e + 2], d = A.s->ltris[4 * e + 3];
     float t = 0;
     if (A.exec_count) { H.ntri += (uint32_t)__popcll(__ballot(valid)); H.n_batches++; }
     const bool acc = valid && triangle_test(R, primary, a, b, c, d.x, t);
@@ -205,12 +205,12 @@ template <bool SHADOW>
 __device__ __forceinline__ void heavy_tiny_meshes(const KernelArgs &A, const Ray &R, const bool primary, TinyResults &T, HeavyState &H,
                                                   const uint32_t lane) {
     T.have = false; T.mmin = INFINITY; T.mt = 0; T.mtri = 0;
-    if (A.tiny_count == 0) return;
-    const bool valid = lane < A.tiny_count;
-    const size_t at = valid ? A.tiny_at[lane] : A.tiny_at[0];
-    const uint32_t flags = valid ? A.tiny_flags[lane] : 0u;
-    const float4 b0 = A.hbox[2 * at], b1 = A.hbox[2 * at + 1];
-    if (A.exec_count) H.nbox += A.tiny_count;
+    if (A.s->tiny_count == 0) return;
+    const bool valid = lane < A.s->tiny_count;
+    const size_t at = valid ? A.s->tiny_at[lane] : A.s->tiny_at[0];
+    const uint32_t flags = valid ? A.s->tiny_flags[lane] : 0u;
+    const float4 b0 = A.s->hbox[2 * at], b1 = A.s->hbox[2 * at + 1];
+    if (A.exec_count) H.nbox += A.s->tiny_count;
     const bool hit = valid && !(SHADOW && (flags & 1u)) && slab_test(R, b0.x, b0.y, b0.z, b1.x, b1.y, b1.z);
     unsigned long long m = __ballot(hit);
     if (!m) return;
@@ -242,7 +242,7 @@ __device__ __forceinline__ void heavy_tiny_meshes(const KernelArgs &A, const Ray
 template <bool SHADOW>
 __device__ __forceinline__ void heavy_mesh(const KernelArgs &A, const Ray &R, const bool primary, const uint32_t mesh,
                                            HeavyState &H, const uint32_t lane) {
-    const HeavyMesh M = A.hmesh[mesh];
+    const HeavyMesh M = A.s->hmesh[mesh];
     const uint32_t guard = H.guard;
     H.guard = guard;
     H.mhave = false;
@@ -271,11 +271,11 @@ struct TopRegs {
 __device__ __forceinline__ TopRegs heavy_top_load(const KernelArgs &A, const uint32_t lane) {
     TopRegs TR;
     TR.q0 = make_float4(0, 0, 0, 0); TR.q1 = TR.q0; TR.entry = 0; TR.entry2 = 0; TR.mflags = 0; TR.mpad = 0;
-    if (A.top_fast) {
-        if (lane < A.top_count) { TR.q0 = A.nodes[2 * (size_t)(A.top_first + lane)]; TR.q1 = A.nodes[2 * (size_t)(A.top_first + lane) + 1]; }
-        if (lane < A.top_leaf_entries) TR.entry = A.leaf_meshes[lane];
-        if (64u + lane < A.top_leaf_entries) TR.entry2 = A.leaf_meshes[64u + lane];
-        if (lane < A.top_meshes) { const crt_mesh m = A.meshes[lane]; TR.mflags = m.flags; TR.mpad = m.pad; }
+    if (A.s->top_fast) {
+        if (lane < A.s->top_count) { TR.q0 = A.s->nodes[2 * (size_t)(A.s->top_first + lane)]; TR.q1 = A.s->nodes[2 * (size_t)(A.s->top_first + lane) + 1]; }
+        if (lane < A.s->top_leaf_entries) TR.entry = A.s->leaf_meshes[lane];
+        if (64u + lane < A.s->top_leaf_entries) TR.entry2 = A.s->leaf_meshes[64u + lane];
+        if (lane < A.s->top_meshes) { const crt_mesh m = A.s->meshes[lane]; TR.mflags = m.flags; TR.mpad = m.pad; }
     }
     return TR;
 }
@@ -289,7 +289,7 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const TopRegs &T
     have = false;
     occluded = false;
     float tmin = INFINITY;
-    uint32_t ti = A.top_root;
+    uint32_t ti = A.s->top_root;
     SeenMeshes seen;
     seen_clear(seen);
     HeavyState H;
@@ -299,15 +299,15 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const TopRegs &T
     H.nbox = 0; H.ntri = 0; H.n_chunks = 0; H.n_batches = 0; H.n_meshes = 0;
     TinyResults T;
     heavy_tiny_meshes<SHADOW>(A, R, primary, T, H, lane);
-    const bool fast = A.top_fast != 0;
+    const bool fast = A.s->top_fast != 0;
     // all top-level boxes against this ray at once (the same test, node by node, as the loop below would make)
-    const unsigned long long top_hits = fast ? __ballot(lane < A.top_count && slab_test(R, TR.q0.x, TR.q0.y, TR.q0.z, TR.q1.x, TR.q1.y, TR.q1.z)) : 0ull;
+    const unsigned long long top_hits = fast ? __ballot(lane < A.s->top_count && slab_test(R, TR.q0.x, TR.q0.y, TR.q0.z, TR.q1.x, TR.q1.y, TR.q1.z)) : 0ull;
     while (ti != END && H.go()) {  // the top-level tree is tiny: walked node by node, uniformly
         H.guard--;
         uint32_t miss, link;
         bool hit;
         if (fast) {
-            const int i = (int)(ti - A.top_first);
+            const int i = (int)(ti - A.s->top_first);
             miss = lane_value(__float_as_uint(TR.q0.w), i);
             link = lane_value(__float_as_uint(TR.q1.w), i);
             hit = ((top_hits >> i) & 1ull) != 0;
@@ -316,7 +316,7 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const TopRegs &T
             miss = __builtin_amdgcn_readfirstlane(__float_as_uint(a[3])); link = __builtin_amdgcn_readfirstlane(__float_as_uint(b[3]));
             hit = __builtin_amdgcn_readfirstlane(slab_test(R, a[0], a[1], a[2], b[0], b[1], b[2]) ? 1 : 0) != 0;
         } else {
-            const float4 q0 = A.nodes[2 * (size_t)ti], q1 = A.nodes[2 * (size_t)ti + 1];
+            const float4 q0 = A.s->nodes[2 * (size_t)ti], q1 = A.s->nodes[2 * (size_t)ti + 1];
             miss = __float_as_uint(q0.w); link = __float_as_uint(q1.w);
             hit = slab_test(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
         }
@@ -326,7 +326,7 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const TopRegs &T
         uint32_t e = link & ~LEAF;
         for (;;) {
             const uint32_t ent = fast ? (e < 64u ? lane_value(TR.entry, (int)e) : lane_value(TR.entry2, (int)(e - 64u)))
-                                      : ((TL && TL->fast) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)TL->entries[e]) : A.leaf_meshes[e]);
+                                      : ((TL && TL->fast) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)TL->entries[e]) : A.s->leaf_meshes[e]);
             e++;
             const uint32_t mi = ent & ~LAST;
             crt_mesh m;
@@ -336,7 +336,7 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const TopRegs &T
                 m.flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[0]); m.pad = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[3]);
                 m.root = 0; m.material = 0;
             }
-            else m = A.meshes[mi];
+            else m = A.s->meshes[mi];
             if (!(SHADOW && (m.flags & 1u)) && !mesh_walk_is_repeat(seen, mi)) {  // (kernel_common.h: every mesh once per ray)
                 if (m.pad) {  // a single-leaf mesh: its result has been waiting in lane pad - 1 since the start of the ray
                     const int k = (int)m.pad - 1;
@@ -364,10 +364,10 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const TopRegs &T
         }
         ti = miss;
     }
-    if (!H.guard && lane == 0) { A.s_counts[SC_GUARD] = 1; A.s_counts[SC_OVERFLOW] = 1; }  // bound hit: let the fallback redo the frame
+    if (!H.guard && lane == 0) { A.f->s_counts[SC_GUARD] = 1; A.f->s_counts[SC_OVERFLOW] = 1; }  // bound hit: let the fallback redo the frame
     if (A.exec_count && lane == 0) {
         atomicAdd(&A.exec_counters[0], (unsigned long long)H.nbox); atomicAdd(&A.exec_counters[1], (unsigned long long)H.ntri);
-        uint32_t *diag = A.s_counts + SC_HEAVY_DIAG + (SHADOW ? 8 : 0);  // tools/stream_stats.py: what a wave-per-ray walk consists of
+        uint32_t *diag = A.f->s_counts + SC_HEAVY_DIAG + (SHADOW ? 8 : 0);  // tools/stream_stats.py: what a wave-per-ray walk consists of
         atomicAdd(diag + 0, 1u); atomicAdd(diag + 1, H.n_chunks); atomicAdd(diag + 2, H.n_batches); atomicAdd(diag + 3, H.n_meshes);
         atomicAdd(diag + 4, (1u << 18) - H.guard);
     }
@@ -381,30 +381,30 @@ __global__ __launch_bounds__(BLOCK, 5) void heavy_trace_closest(const KernelArgs
     __shared__ TopLdsStorage top_storage;  // used when the top-level tree is too large for the registers and small enough for this
     TopLds TL;
     TL.fast = false;
-    if (!A.top_fast && A.top_lds) TL = top_lds_load(A, top_storage);  // (a barrier inside: before any return; the condition is uniform)
+    if (!A.s->top_fast && A.s->top_lds) TL = top_lds_load(A, top_storage);  // (a barrier inside: before any return; the condition is uniform)
     const uint32_t lane = threadIdx.x & 63u;
-    if (A.s_counts[SC_OVERFLOW]) return;
+    if (A.f->s_counts[SC_OVERFLOW]) return;
     const uint32_t count = stream_level_count(A, gen);
     const bool whole = stream_level_is_whole_heavy(A, gen, count);  // every ray of the level: entry k is ray k
     if (A.force_whole && !whole && gen > 0) {  // no per-lane launch and more rays than s_hits holds: the fallback redoes the frame
-        if (threadIdx.x == 0 && blockIdx.x == 0) A.s_counts[SC_OVERFLOW] = 1;
+        if (threadIdx.x == 0 && blockIdx.x == 0) A.f->s_counts[SC_OVERFLOW] = 1;
         return;
     }
-    uint32_t total = whole ? count : A.s_counts[SC_HEAVY + gen];
-    if (total > A.s_heavy_cap) total = A.s_heavy_cap;
-    const float4 *in_q = A.s_rayq[gen & 1u];
+    uint32_t total = whole ? count : A.f->s_counts[SC_HEAVY + gen];
+    if (total > A.f->s_heavy_cap) total = A.f->s_heavy_cap;
+    const float4 *in_q = A.f->s_rayq[gen & 1u];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
     const uint32_t n_waves = gridDim.x * (BLOCK / 64);
     if (wave >= total) return;
     const TopRegs TR = heavy_top_load(A, lane);
     for (uint32_t k = wave; k < total; k += n_waves) {  // one evicted ray per wave and trip
-        const uint32_t r = whole ? k : A.s_heavy[k];
+        const uint32_t r = whole ? k : A.f->s_heavy[k];
         Ray R;
         bool primary = false;
         if (gen == 0) {
-            const WorkItem wi = A.items[r >> 6];
+            const WorkItem wi = A.f->items[r >> 6];
             const uint32_t sub = r & 63u;
-            primary_ray(A, (wi.tile % A.tiles_x) * TILE + (sub & 7u), (wi.tile / A.tiles_x) * TILE + (sub >> 3), R);
+            primary_ray(A, (wi.tile % A.s->tiles_x) * TILE + (sub & 7u), (wi.tile / A.s->tiles_x) * TILE + (sub >> 3), R);
             primary = true;
         } else {
             const float4 q0 = in_q[2 * (size_t)r], q1 = in_q[2 * (size_t)r + 1];
@@ -413,15 +413,14 @@ __global__ __launch_bounds__(BLOCK, 5) void heavy_trace_closest(const KernelArgs
             normalize3(R.dx, R.dy, R.dz);
             ray_prepare(R);
         }
-        R.ox = uniform_f(R.ox); R.oy = uniform_f(R.oy); R.oz = uniform_f(R.oz);
-        R.dx = uniform_f(R.dx); R.dy = uniform_f(R.dy); R.dz = uniform_f(R.dz);
-        R.ix = uniform_f(R.ix); R.iy = uniform_f(R.iy); R.iz = uniform_f(R.iz);
+        // (the ray stays in vector registers, the same value in every lane: a vector instruction takes one scalar operand at most,
+        //  and the scalar file is what this kernel runs out of)
         R.parmask = __builtin_amdgcn_readfirstlane(R.parmask);
         bool have = false, occluded = false;
         float bt = 0;
         uint32_t btri = 0, bmesh = 0;
         heavy_walk<false>(A, TR, R, primary, 0.0f, have, bt, btri, bmesh, occluded, lane, &TL);
-        if (lane == 0) A.s_hits[k] = make_float4(bt, __uint_as_float(btri), __uint_as_float(bmesh), __uint_as_float(have ? 1u : 0u));
+        if (lane == 0) A.f->s_hits[k] = make_float4(bt, __uint_as_float(btri), __uint_as_float(bmesh), __uint_as_float(have ? 1u : 0u));
     }
 }
 
@@ -431,11 +430,11 @@ __global__ __launch_bounds__(BLOCK) void heavy_trace_shadow(const KernelArgs A, 
     __shared__ TopLdsStorage top_storage;
     TopLds TL;
     TL.fast = false;
-    if (!A.top_fast && A.top_lds) TL = top_lds_load(A, top_storage);
+    if (!A.s->top_fast && A.s->top_lds) TL = top_lds_load(A, top_storage);
     const uint32_t lane = threadIdx.x & 63u;
-    if (A.s_counts[SC_OVERFLOW]) return;
-    uint32_t total = A.s_counts[SC_SHEAVY], split = A.s_counts[SC_SHEAVY_SPLIT];
-    if (total > A.s_heavy_cap) total = A.s_heavy_cap;
+    if (A.f->s_counts[SC_OVERFLOW]) return;
+    uint32_t total = A.f->s_counts[SC_SHEAVY], split = A.f->s_counts[SC_SHEAVY_SPLIT];
+    if (total > A.f->s_heavy_cap) total = A.f->s_heavy_cap;
     if (split > total) split = total;
     const uint32_t first = part == 0 ? 0u : split;
     if (part == 0) total = split;
@@ -444,18 +443,17 @@ __global__ __launch_bounds__(BLOCK) void heavy_trace_shadow(const KernelArgs A, 
     if (first + wave >= total) return;
     const TopRegs TR = heavy_top_load(A, lane);
     for (uint32_t k = first + wave; k < total; k += n_waves) {
-        const uint32_t r = A.s_sheavy[k];
-        const float4 q0 = A.s_shadowq[2 * (size_t)r], q1 = A.s_shadowq[2 * (size_t)r + 1];
+        const uint32_t r = A.f->s_sheavy[k];
+        const float4 q0 = A.f->s_shadowq[2 * (size_t)r], q1 = A.f->s_shadowq[2 * (size_t)r + 1];
         Ray R;
-        R.ox = uniform_f(q0.x); R.oy = uniform_f(q0.y); R.oz = uniform_f(q0.z);
-        R.dx = uniform_f(q1.x); R.dy = uniform_f(q1.y); R.dz = uniform_f(q1.z);
+        R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
+        R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;
         ray_prepare(R);
-        R.ix = uniform_f(R.ix); R.iy = uniform_f(R.iy); R.iz = uniform_f(R.iz);
         R.parmask = __builtin_amdgcn_readfirstlane(R.parmask);
         bool have, occluded;
         float bt = 0;
         uint32_t btri = 0, bmesh = 0;
         heavy_walk<true>(A, TR, R, false, uniform_f(q0.w), have, bt, btri, bmesh, occluded, lane, &TL);
-        if (lane == 0) A.s_occluded[r] = occluded ? 1 : 0;
+        if (lane == 0) A.f->s_occluded[r] = occluded ? 1 : 0;
     }
 }

@@ -21,17 +21,17 @@ enum : int { FR_DIFFUSE_GI = 4 };
 __device__ __forceinline__ void primary_ray_offset(const KernelArgs &A, uint32_t px, uint32_t py, float offx, float offy, Ray &R) {
     float x = (float)px + offx;
     float y = (float)py + offy;
-    x = x / (float)A.width;
-    y = y / (float)A.height;
+    x = x / (float)A.s->width;
+    y = y / (float)A.s->height;
     x = (2.0f * x) - 1.0f;
     y = 1.0f - (2.0f * y);
-    x = x * ((float)A.width / (float)A.height);
+    x = x * ((float)A.s->width / (float)A.s->height);
     const float z = -1.0f;
-    R.dx = x * A.cam[0] + y * A.cam[3] + z * A.cam[6];
-    R.dy = x * A.cam[1] + y * A.cam[4] + z * A.cam[7];
-    R.dz = x * A.cam[2] + y * A.cam[5] + z * A.cam[8];
+    R.dx = x * A.f->cam[0] + y * A.f->cam[3] + z * A.f->cam[6];
+    R.dy = x * A.f->cam[1] + y * A.f->cam[4] + z * A.f->cam[7];
+    R.dz = x * A.f->cam[2] + y * A.f->cam[5] + z * A.f->cam[8];
     normalize3(R.dx, R.dy, R.dz);
-    R.ox = A.cam_pos[0]; R.oy = A.cam_pos[1]; R.oz = A.cam_pos[2];
+    R.ox = A.f->cam_pos[0]; R.oy = A.f->cam_pos[1]; R.oz = A.f->cam_pos[2];
     normalize3(R.dx, R.dy, R.dz);
     ray_prepare(R);
 }
@@ -90,10 +90,10 @@ __device__ __forceinline__ bool traversal_step(LaneWalk &L, const Ray &R, const 
     if (L.mleaf != NONE) {
         // ---- inside a mesh-tree leaf: test one triangle (KDTree.cpp:57-65)
         // the leaf's triangles are stored in list order, one 64-byte record each: no index indirection
-        const float4 a = A.ltris[4 * (size_t)L.mleaf + 0];
-        const float4 b = A.ltris[4 * (size_t)L.mleaf + 1];
-        const float4 c = A.ltris[4 * (size_t)L.mleaf + 2];
-        const float4 d = A.ltris[4 * (size_t)L.mleaf + 3];
+        const float4 a = A.s->ltris[4 * (size_t)L.mleaf + 0];
+        const float4 b = A.s->ltris[4 * (size_t)L.mleaf + 1];
+        const float4 c = A.s->ltris[4 * (size_t)L.mleaf + 2];
+        const float4 d = A.s->ltris[4 * (size_t)L.mleaf + 3];
         const float plane = d.x;
         const uint32_t tri = __float_as_uint(d.y);
         L.mleaf = __float_as_uint(d.z) ? NONE : L.mleaf + 1;
@@ -116,7 +116,7 @@ __device__ __forceinline__ bool traversal_step(LaneWalk &L, const Ray &R, const 
     if (L.cur_mesh != NONE) {
         if (L.mnode != END) {
             // ---- visit one mesh-tree node (KDTree.cpp:53-74)
-            const float4 q0 = A.nodes[2 * (size_t)L.mnode], q1 = A.nodes[2 * (size_t)L.mnode + 1];
+            const float4 q0 = A.s->nodes[2 * (size_t)L.mnode], q1 = A.s->nodes[2 * (size_t)L.mnode + 1];
             const uint32_t miss = __float_as_uint(q0.w), link = __float_as_uint(q1.w);
             if (COUNT) cnt[C_BOX]++;
             const bool hit = slab_test(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
@@ -144,12 +144,12 @@ __device__ __forceinline__ bool traversal_step(LaneWalk &L, const Ray &R, const 
     }
     if (L.tleaf != NONE) {
         // ---- inside a top-level leaf: start the next mesh (KDTree.cpp:138-144, AccelerationStructure.cpp:66-72)
-        const uint32_t ent = A.leaf_meshes[L.tleaf];
+        const uint32_t ent = A.s->leaf_meshes[L.tleaf];
         const uint32_t mi = ent & ~LAST;
         L.tleaf = (ent & LAST) ? NONE : L.tleaf + 1;
         if (COUNT) cnt[C_LEAFIDX]++;
-        const crt_mesh m = A.meshes[mi];
-        if (L.rtype == RAY_SHADOW && (m.flags & 1u) && !A.use_gi) return true;  // AccelerationStructure.cpp:67-71
+        const crt_mesh m = A.s->meshes[mi];
+        if (L.rtype == RAY_SHADOW && (m.flags & 1u) && !A.f->use_gi) return true;  // AccelerationStructure.cpp:67-71
         if (!COUNT && mesh_walk_is_repeat(L.seen, mi)) return true;  // production build: every mesh once per ray (kernel_common.h, exact)
         L.cur_mesh = mi;
         L.mnode = m.root;
@@ -159,7 +159,7 @@ __device__ __forceinline__ bool traversal_step(LaneWalk &L, const Ray &R, const 
     }
     if (L.tnode != END) {
         // ---- visit one top-level node (KDTree.cpp:132-155)
-        const float4 q0 = A.nodes[2 * (size_t)L.tnode], q1 = A.nodes[2 * (size_t)L.tnode + 1];
+        const float4 q0 = A.s->nodes[2 * (size_t)L.tnode], q1 = A.s->nodes[2 * (size_t)L.tnode + 1];
         const uint32_t miss = __float_as_uint(q0.w), link = __float_as_uint(q1.w);
         if (COUNT) cnt[C_BOX]++;
         const bool hit = slab_test(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
@@ -179,7 +179,7 @@ template <bool COUNT, bool GI = false>
 __global__ __launch_bounds__(BLOCK) void render_lanes(const KernelArgs A) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
-    float *frames = A.frames + (size_t)wave * A.frame_wave_stride + lane;
+    float *frames = A.f->frames + (size_t)wave * A.f->frame_wave_stride + lane;
     constexpr int FDW = GI ? FRAME_DWORDS_GI : FRAME_DWORDS;
     auto FR = [&](uint32_t level, int field) -> float & { return frames[((size_t)level * FDW + field) * 64]; };
     auto FRK = [&](uint32_t level) -> int & { return *reinterpret_cast<int *>(&frames[(size_t)level * FDW * 64]); };
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(BLOCK) void render_lanes(const KernelArgs A) {
     uint32_t key = 0, pixel_key = 0, sample = 0, cur_px = 0, cur_py = 0;
     float sumx = 0, sumy = 0, sumz = 0;          // std::accumulate over the pixel's samples (RayTracer.cpp:102-104)
     float inx = 0, iny = 0, inz = 0;             // the ray direction that reached the diffuse hit being lit
-    const uint32_t n_samples = A.rays_per_pixel ? A.rays_per_pixel : 1u;  // colorVector always holds the centre sample
+    const uint32_t n_samples = A.f->rays_per_pixel ? A.f->rays_per_pixel : 1u;  // colorVector always holds the centre sample
 
     uint32_t cnt[C_N];
     if (COUNT) for (int k = 0; k < C_N; k++) cnt[k] = 0;
@@ -204,10 +204,10 @@ __global__ __launch_bounds__(BLOCK) void render_lanes(const KernelArgs A) {
     uint32_t li = 0;
     bool base_is_bitmap = false;
     if (A.only_if_overflow) {  // fallback of the stream pass: usually nothing to do
-        if (!A.s_counts[SC_OVERFLOW_WORD]) return;
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(A.fallback_total, 1u);  // reported as crt_stats::fallback_frames
+        if (!A.f->s_counts[SC_OVERFLOW_WORD]) return;
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(A.f->fallback_total, 1u);  // reported as crt_stats::fallback_frames
     }
-    const uint32_t total_px = A.n_items * 64u;
+    const uint32_t total_px = A.f->n_items * 64u;
 
     for (;;) {
         // ------------------------------------------------------------------ fetch new pixels
@@ -217,20 +217,20 @@ __global__ __launch_bounds__(BLOCK) void render_lanes(const KernelArgs A) {
                 const int n = __popcll(need);
                 const int rank = __popcll(need & ((1ull << lane) - 1ull));
                 uint32_t base = 0;
-                if (rank == 0) base = atomicAdd(A.pixel_counter, (uint32_t)n);
+                if (rank == 0) base = atomicAdd(A.f->pixel_counter, (uint32_t)n);
                 base = __shfl(base, __ffsll((long long)need) - 1);
                 uint32_t q = base + (uint32_t)rank;
                 if (q >= total_px) { state = ST_DONE; break; }
-                const WorkItem wi = A.items[q >> 6];
+                const WorkItem wi = A.f->items[q >> 6];
                 const uint32_t sub = q & 63u;
-                const uint32_t px = (wi.tile % A.tiles_x) * TILE + (sub & 7u);
-                const uint32_t py = (wi.tile / A.tiles_x) * TILE + (sub >> 3);
-                if (!((wi.mask >> sub) & 1ull) || px >= A.width || py >= A.height) continue;  // not covered: take another
-                out_off = A.packed ? ((size_t)wi.out_tile * 64 + sub) * 3 : ((size_t)py * A.width + px) * 3;
+                const uint32_t px = (wi.tile % A.s->tiles_x) * TILE + (sub & 7u);
+                const uint32_t py = (wi.tile / A.s->tiles_x) * TILE + (sub >> 3);
+                if (!((wi.mask >> sub) & 1ull) || px >= A.s->width || py >= A.s->height) continue;  // not covered: take another
+                out_off = A.f->packed ? ((size_t)wi.out_tile * 64 + sub) * 3 : ((size_t)py * A.s->width + px) * 3;
                 primary_ray(A, px, py, R);  // depth 0 <= MAX_DEPTH always (RayTracer.cpp:427)
                 if (GI) {
                     cur_px = px; cur_py = py;
-                    pixel_key = crt_gi_mix(A.gi_seed, py * A.width + px);
+                    pixel_key = crt_gi_mix(A.f->gi_seed, py * A.s->width + px);
                     sample = 0;
                     key = crt_gi_mix(pixel_key, 0u);
                     sumx = sumy = sumz = 0;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(BLOCK) void render_lanes(const KernelArgs A) {
                 L.rtype = RAY_PRIMARY;
                 sp = 0;
                 if (COUNT) cnt[C_PRIMARY]++;
-                traversal_begin(L, A.top_root);
+                traversal_begin(L, A.s->top_root);
                 state = ST_TRAVERSE;
             }
         }
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(BLOCK) void render_lanes(const KernelArgs A) {
                 li++;
                 next_light = true;
             } else if (!L.have) {
-                cx = A.bgx; cy = A.bgy; cz = A.bgz; returning = true;  // RayTracer.cpp:449-450
+                cx = A.s->bgx; cy = A.s->bgy; cz = A.s->bgz; returning = true;  // RayTracer.cpp:449-450
             } else {
                 Surface S;
                 surface_at(A, R, L.bt, L.btri, L.bmesh, S);
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(BLOCK) void render_lanes(const KernelArgs A) {
                     if (GI) { inx = R.dx; iny = R.dy; inz = R.dz; }
                     base_is_bitmap = false;
                     if (S.M.texture >= 0) {
-                        texture_color<COUNT>(A, A.textures[S.M.texture], L.btri, S.u, S.v, 1.0f - S.u - S.v, basex, basey,
+                        texture_color<COUNT>(A, A.s->textures[S.M.texture], L.btri, S.u, S.v, 1.0f - S.u - S.v, basex, basey,
                                              basez, base_is_bitmap);
                     } else { basex = S.M.ax; basey = S.M.ay; basez = S.M.az; }
                     accx = accy = accz = 0;
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(BLOCK) void render_lanes(const KernelArgs A) {
                     if (GI) { FRU(sp, 8) = key; key = crt_gi_child_key(key, 0u); }
                     const float k = 2 * dot3(R.dx, R.dy, R.dz, S.nx, S.ny, S.nz);  // Vector::reflect, Vector.cpp:119-122
                     const float rx = R.dx - k * S.nx, ry = R.dy - k * S.ny, rz = R.dz - k * S.nz;
-                    R.ox = S.px + S.nx * A.reflection_bias; R.oy = S.py + S.ny * A.reflection_bias; R.oz = S.pz + S.nz * A.reflection_bias;
+                    R.ox = S.px + S.nx * A.f->reflection_bias; R.oy = S.py + S.ny * A.f->reflection_bias; R.oz = S.pz + S.nz * A.f->reflection_bias;
                     R.dx = rx; R.dy = ry; R.dz = rz;
                     normalize3(R.dx, R.dy, R.dz);
                     L.rtype = RAY_REFLECTION;
@@ -323,14 +323,14 @@ __global__ __launch_bounds__(BLOCK) void render_lanes(const KernelArgs A) {
                         float tz = eta_ratio * (R.dz + cos_a * nz) - cos_b * nz;
                         normalize3(tx, ty, tz);
                         FRK(sp) = FR_REFRACT_WAIT_REFLECTION;
-                        FR(sp, 1) = S.px - nx * A.refraction_bias; FR(sp, 2) = S.py - ny * A.refraction_bias;
-                        FR(sp, 3) = S.pz - nz * A.refraction_bias;
+                        FR(sp, 1) = S.px - nx * A.f->refraction_bias; FR(sp, 2) = S.py - ny * A.f->refraction_bias;
+                        FR(sp, 3) = S.pz - nz * A.f->refraction_bias;
                         FR(sp, 4) = tx; FR(sp, 5) = ty; FR(sp, 6) = tz;
                         FR(sp, 7) = fresnel;
                     } else {
                         FRK(sp) = FR_REFRACT_NO_TRANSMISSION;
                     }
-                    R.ox = S.px + nx * A.reflection_bias; R.oy = S.py + ny * A.reflection_bias; R.oz = S.pz + nz * A.reflection_bias;
+                    R.ox = S.px + nx * A.f->reflection_bias; R.oy = S.py + ny * A.f->reflection_bias; R.oz = S.pz + nz * A.f->reflection_bias;
                     R.dx = rx; R.dy = ry; R.dz = rz;
                     normalize3(R.dx, R.dy, R.dz);
                     L.rtype = RAY_REFLECTION;
@@ -338,21 +338,21 @@ __global__ __launch_bounds__(BLOCK) void render_lanes(const KernelArgs A) {
                     sp++;
                     new_ray = true;
                 } else {
-                    cx = A.bgx; cy = A.bgy; cz = A.bgz; returning = true;  // RayTracer.cpp:443-446
+                    cx = A.s->bgx; cy = A.s->bgy; cz = A.s->bgz; returning = true;  // RayTracer.cpp:443-446
                 }
             }
 
             // ---- diffuse light loop: set up the next shadow ray or return the accumulated colour
             if (next_light) {
-                if (li < A.n_lights) {
+                if (li < A.s->n_lights) {
                     if (COUNT) { cnt[C_LIGHT]++; cnt[C_SHADOW]++; }
                     light_setup(A, li, hpx, hpy, hpz, hnx, hny, hnz, R, L.light_dist, kfac);
                     L.rtype = RAY_SHADOW;
-                    traversal_begin(L, A.top_root);
-                } else if (GI && A.use_gi) {
+                    traversal_begin(L, A.s->top_root);
+                } else if (GI && A.f->use_gi) {
                     // RayTracer.cpp:331-354: GI_SAMPLE_SIZE diffuse reflection rays, one after the other, each a shootRay(depth + 1)
-                    if (A.gi_samples == 0) {
-                        const float inv = 1.0f / (float)(A.gi_samples + 1u);
+                    if (A.f->gi_samples == 0) {
+                        const float inv = 1.0f / (float)(A.f->gi_samples + 1u);
                         cx = (accx + 0.0f) * inv; cy = (accy + 0.0f) * inv; cz = (accz + 0.0f) * inv;
                         returning = true;
                     } else {
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(BLOCK) void render_lanes(const KernelArgs A) {
                         FR(sp, 12) = hnx; FR(sp, 13) = hny; FR(sp, 14) = hnz;
                         FR(sp, 15) = inx; FR(sp, 16) = iny; FR(sp, 17) = inz;
                         gi_sample_direction(inx, iny, inz, hnx, hny, hnz, crt_gi_uniform(key, 2u), crt_gi_uniform(key, 3u), R.dx, R.dy, R.dz);
-                        R.ox = hpx + hnx * A.monte_carlo_bias; R.oy = hpy + hny * A.monte_carlo_bias; R.oz = hpz + hnz * A.monte_carlo_bias;
+                        R.ox = hpx + hnx * A.f->monte_carlo_bias; R.oy = hpy + hny * A.f->monte_carlo_bias; R.oz = hpz + hnz * A.f->monte_carlo_bias;
                         L.rtype = RAY_REFLECTION;
                         key = crt_gi_child_key(key, 2u);
                         sp++;
@@ -382,14 +382,14 @@ __global__ __launch_bounds__(BLOCK) void render_lanes(const KernelArgs A) {
                     // shootRay entry (RayTracer.cpp:419-429)
                     normalize3(R.dx, R.dy, R.dz);
                     new_ray = false;
-                    if (sp > A.max_depth) { cx = A.bgx; cy = A.bgy; cz = A.bgz; returning = true; continue; }
+                    if (sp > A.f->max_depth) { cx = A.s->bgx; cy = A.s->bgy; cz = A.s->bgz; returning = true; continue; }
                     if (COUNT) cnt[C_SECONDARY]++;
                     ray_prepare(R);
-                    traversal_begin(L, A.top_root);
+                    traversal_begin(L, A.s->top_root);
                     break;
                 }
                 if (sp == 0) {
-                    if (GI && A.use_gi) {  // RayTracer.cpp:90-104: the centre sample, then RAYS_PER_PIXEL - 1 jittered ones, then the mean
+                    if (GI && A.f->use_gi) {  // RayTracer.cpp:90-104: the centre sample, then RAYS_PER_PIXEL - 1 jittered ones, then the mean
                         sumx = sumx + cx; sumy = sumy + cy; sumz = sumz + cz;
                         sample++;
                         if (sample < n_samples) {
@@ -397,14 +397,14 @@ __global__ __launch_bounds__(BLOCK) void render_lanes(const KernelArgs A) {
                             primary_ray_offset(A, cur_px, cur_py, crt_gi_uniform(key, 0u), crt_gi_uniform(key, 1u), R);
                             L.rtype = RAY_PRIMARY;
                             if (COUNT) cnt[C_PRIMARY]++;
-                            traversal_begin(L, A.top_root);
+                            traversal_begin(L, A.s->top_root);
                             returning = false;
                             break;
                         }
                         const float inv = 1.0f / (float)n_samples;
                         cx = sumx * inv; cy = sumy * inv; cz = sumz * inv;
                     }
-                    A.out[out_off] = cx; A.out[out_off + 1] = cy; A.out[out_off + 2] = cz;  // RayTracer.cpp:106
+                    A.f->out[out_off] = cx; A.f->out[out_off + 1] = cy; A.f->out[out_off + 2] = cz;  // RayTracer.cpp:106
                     state = ST_FETCH;
                     break;
                 }
@@ -414,19 +414,19 @@ __global__ __launch_bounds__(BLOCK) void render_lanes(const KernelArgs A) {
                 if (GI && kind == FR_DIFFUSE_GI) {
                     const float ix = FR(f, 4) + cx, iy = FR(f, 5) + cy, iz = FR(f, 6) + cz;  // indirectLightContribution += shootRay(...)
                     const uint32_t i = FRU(f, 7) + 1u;
-                    if (i < A.gi_samples) {
+                    if (i < A.f->gi_samples) {
                         FR(f, 4) = ix; FR(f, 5) = iy; FR(f, 6) = iz;
                         FRU(f, 7) = i;
                         const float px = FR(f, 9), py = FR(f, 10), pz = FR(f, 11), nx = FR(f, 12), ny = FR(f, 13), nz = FR(f, 14);
                         gi_sample_direction(FR(f, 15), FR(f, 16), FR(f, 17), nx, ny, nz, crt_gi_uniform(key, 2u + 2u * i),
                                             crt_gi_uniform(key, 3u + 2u * i), R.dx, R.dy, R.dz);
-                        R.ox = px + nx * A.monte_carlo_bias; R.oy = py + ny * A.monte_carlo_bias; R.oz = pz + nz * A.monte_carlo_bias;
+                        R.ox = px + nx * A.f->monte_carlo_bias; R.oy = py + ny * A.f->monte_carlo_bias; R.oz = pz + nz * A.f->monte_carlo_bias;
                         L.rtype = RAY_REFLECTION;
                         key = crt_gi_child_key(key, 2u + i);
                         returning = false;
                         new_ray = true;   // enters shootRay at level sp (== f + 1)
                     } else {
-                        const float inv = 1.0f / (float)(A.gi_samples + 1u);  // RayTracer.cpp:352-353
+                        const float inv = 1.0f / (float)(A.f->gi_samples + 1u);  // RayTracer.cpp:352-353
                         cx = (FR(f, 1) + ix) * inv; cy = (FR(f, 2) + iy) * inv; cz = (FR(f, 3) + iz) * inv;
                         sp = f;
                     }

@@ -33,7 +33,7 @@
 constexpr int PLAN_LEAF_DWORDS = 16;
 
 __device__ __forceinline__ v16f plan_leaf(const KernelArgs &A, uint32_t k) {
-    return *(kv16p)((kfp)(const float *)A.plan_boxes + PLAN_LEAF_DWORDS * (size_t)k);
+    return *(kv16p)((kfp)(const float *)A.s->plan_boxes + PLAN_LEAF_DWORDS * (size_t)k);
 }
 
 // Leaf cursor of the plan kernels: bits 0..23 = the next entry of the leaf, bits 24..30 = entries that follow it (compact
@@ -46,12 +46,12 @@ __device__ __forceinline__ uint32_t leaf_cursor_next(uint32_t c) { return (c >> 
 constexpr uint32_t SHADOW_NODE_REPEAT = 2;  // node steps per loop trip (measured: 2 beats 1, 3 and 4)
 __device__ __forceinline__ void shadow_plan_walks(const KernelArgs &A, const uint32_t first, const uint32_t total, uint32_t *cursor) {
     __shared__ uint32_t root_of_bit[64];  // shadow order -> root node of the mesh's tree
-    if (threadIdx.x < 64u) root_of_bit[threadIdx.x] = threadIdx.x < A.plan_shadow_bits ? A.meshes[A.plan_shadow_mesh[threadIdx.x]].root : END;
+    if (threadIdx.x < 64u) root_of_bit[threadIdx.x] = threadIdx.x < A.s->plan_shadow_bits ? A.s->meshes[A.s->plan_shadow_mesh[threadIdx.x]].root : END;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
-    if (A.s_counts[SC_OVERFLOW]) return;
-    const char *nodes_b = reinterpret_cast<const char *>(A.pnodes);
-    const char *ptris_b = reinterpret_cast<const char *>(A.ptris);
+    if (A.f->s_counts[SC_OVERFLOW]) return;
+    const char *nodes_b = reinterpret_cast<const char *>(A.s->pnodes);
+    const char *ptris_b = reinterpret_cast<const char *>(A.s->ptris);
 
     Ray R;
     uint32_t wn = END, we = NONE;   // next mesh-tree node, leaf cursor
@@ -70,19 +70,19 @@ __device__ __forceinline__ void shadow_plan_walks(const KernelArgs &A, const uin
                 r = wave_fetch(cursor, lane);
                 if (r >= total) { state = ST_DONE; break; }
                 r += first;
-                const float4 q0 = A.s_shadowq[2 * (size_t)r], q1 = A.s_shadowq[2 * (size_t)r + 1];
+                const float4 q0 = A.f->s_shadowq[2 * (size_t)r], q1 = A.f->s_shadowq[2 * (size_t)r + 1];
                 if (__float_as_uint(q0.w) == SHADOW_SLOT_UNUSED) continue;  // a level-0 pixel without a diffuse hit
                 // The light is behind the surface (angle = max(0, l . n) = 0, RayTracer.cpp:312): its contribution is
                 // intensity / area * 0 = +-0 times the albedo, and adding +-0 to the light sum -- which starts at +0 and can
                 // therefore never be -0 -- changes no bit of it (RayTracer.cpp:319-328).  Occluded or not, the pixel is the same:
                 // no walk.  (A NaN factor -- the light AT the surface -- is not zero and is walked.)
-                if (q1.w == 0.0f) { A.s_occluded[r] = 0; continue; }
+                if (q1.w == 0.0f) { A.f->s_occluded[r] = 0; continue; }
                 R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
                 R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;  // already normalised once; shadow rays skip shootRay (RayTracer.cpp:313-317)
                 ray_prepare(R);
                 if (R.parmask != 0) {  // BoundingBox.h:90-93 needs the general test: the wave-per-ray kernel has it
-                    if (evict_ray(A.s_sheavy, A.s_heavy_cap, A.s_counts + SC_SHEAVY, r, lane)) continue;
-                    A.s_counts[SC_OVERFLOW] = 1;
+                    if (evict_ray(A.f->s_sheavy, A.f->s_heavy_cap, A.f->s_counts + SC_SHEAVY, r, lane)) continue;
+                    A.f->s_counts[SC_OVERFLOW] = 1;
                     continue;
                 }
                 light_dist = q0.w;
@@ -93,13 +93,13 @@ __device__ __forceinline__ void shadow_plan_walks(const KernelArgs &A, const uin
             if (fresh) {
                 // the plan: which meshes does this ray have to walk?  (k is wave-uniform: scalar loads, no gathers)
                 uint32_t lo = 0, hi = 0;
-                for (uint32_t k = 0; k < A.plan_leaves; k++) {
+                for (uint32_t k = 0; k < A.s->plan_leaves; k++) {
                     const v16f L = plan_leaf(A, k);
                     const bool hit = slab_test_no_parallel(R, L[0], L[1], L[2], L[4], L[5], L[6]);
                     lo |= hit ? __float_as_uint(L[8]) : 0u;
                     hi |= hit ? __float_as_uint(L[9]) : 0u;
                 }
-                if (A.exec_count) nplan += A.plan_leaves;
+                if (A.exec_count) nplan += A.s->plan_leaves;
                 mlo = lo; mhi = hi; wn = END; we = NONE;
             }
         }
@@ -170,11 +170,11 @@ __device__ __forceinline__ void shadow_plan_walks(const KernelArgs &A, const uin
                 if (done) break;
             }
             if (done) {
-                A.s_occluded[r] = occluded ? 1 : 0;
+                A.f->s_occluded[r] = occluded ? 1 : 0;
                 state = ST_FETCH;
             } else if (steps >= A.step_budget) {
                 // a long walk goes to the wave-per-ray kernel, which restarts it (the list full: keep walking here)
-                if (evict_ray(A.s_sheavy, A.s_heavy_cap, A.s_counts + SC_SHEAVY, r, lane)) state = ST_FETCH;
+                if (evict_ray(A.f->s_sheavy, A.f->s_heavy_cap, A.f->s_counts + SC_SHEAVY, r, lane)) state = ST_FETCH;
                 steps = 0;
             }
         }
@@ -184,10 +184,10 @@ __device__ __forceinline__ void shadow_plan_walks(const KernelArgs &A, const uin
 
 // pass 0: the level-0 shadow rays (queue slots below the split mark); pass 1: all the deeper levels' at once
 template <uint32_t pass>  // (a template parameter so that the passes are separate kernels in a profile)
-__global__ __launch_bounds__(BLOCK, 8) void stream_trace_shadow_plan(const KernelArgs A) {
-    const uint32_t split = A.s_counts[SC_SHADOW_SPLIT];
-    shadow_plan_walks(A, pass == 0 ? 0u : split, pass == 0 ? split : A.s_counts[SC_SHADOW] - split,
-                      A.s_counts + (pass == 0 ? SC_SHADOW_FETCH : SC_SHADOW_FETCH2));
+__global__ __launch_bounds__(BLOCK) void stream_trace_shadow_plan(const KernelArgs A) {
+    const uint32_t split = A.f->s_counts[SC_SHADOW_SPLIT];
+    shadow_plan_walks(A, pass == 0 ? 0u : split, pass == 0 ? split : A.f->s_counts[SC_SHADOW] - split,
+                      A.f->s_counts + (pass == 0 ? SC_SHADOW_FETCH : SC_SHADOW_FETCH2));
 }
 
 // ---------------------------------------------------------------------------------------------------------- closest hit
@@ -203,9 +203,9 @@ struct PlanList {
 // order and list order, i.e. in the order the reference collects their hits (KDTree.cpp:132-155).  Wave-uniform loops:
 // leaf boxes and entries come through scalar loads.
 __device__ __forceinline__ void plan_closest_meshes(const KernelArgs &A, const Ray &R, PlanList &PL, uint32_t &nplan) {
-    const ku32p entries = (ku32p)A.leaf_meshes;
+    const ku32p entries = (ku32p)A.s->leaf_meshes;
     uint32_t seen_lo = 0, seen_hi = 0, acc = 0, cnt = 0;
-    for (uint32_t k = 0; k < A.plan_leaves; k++) {
+    for (uint32_t k = 0; k < A.s->plan_leaves; k++) {
         const v16f L = plan_leaf(A, k);
         const bool hit = slab_test_no_parallel(R, L[0], L[1], L[2], L[4], L[5], L[6]);
         // (no `continue` on the wave-uniform ballot: DESIGN.md "compiler notes")
@@ -225,7 +225,7 @@ __device__ __forceinline__ void plan_closest_meshes(const KernelArgs &A, const R
         }
     }
     if (cnt & 3u) PL.words[(cnt >> 2) * BLOCK] = acc;
-    if (A.exec_count) nplan += A.plan_leaves;
+    if (A.exec_count) nplan += A.s->plan_leaves;
     PL.count = cnt;
     PL.next = 0;
 }
@@ -241,23 +241,23 @@ __device__ __forceinline__ uint32_t plan_list_pop(PlanList &PL) {
 // first with exact distance pruning on loose boxes -- grazing rays, the long walks, have nothing to prune before they hit.)
 __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArgs A, const uint32_t gen) {
     if (A.wave_prio) __builtin_amdgcn_s_setprio(3);  // ahead of the bulk shadow pass's waves on this SIMD
-    extern __shared__ uint32_t plan_lds[];  // mesh lists: A.plan_list_words x BLOCK
+    extern __shared__ uint32_t plan_lds[];  // mesh lists: A.s->plan_list_words x BLOCK
     __shared__ uint32_t s_tree_root[64];    // per mesh (plan kernels: at most 64 meshes)
-    if (threadIdx.x < 64u) s_tree_root[threadIdx.x] = threadIdx.x < A.top_meshes ? A.meshes[threadIdx.x].root : END;
+    if (threadIdx.x < 64u) s_tree_root[threadIdx.x] = threadIdx.x < A.s->top_meshes ? A.s->meshes[threadIdx.x].root : END;
     __syncthreads();
     PlanList PL;
     PL.words = plan_lds + threadIdx.x;
     PL.count = 0; PL.next = 0;
     const uint32_t lane = threadIdx.x & 63u;
-    if (A.s_counts[SC_OVERFLOW]) return;
+    if (A.f->s_counts[SC_OVERFLOW]) return;
     const uint32_t count = stream_level_count(A, gen);
     const uint32_t node_base = stream_level_base(A, gen);
     const uint32_t child_base = node_base + count;
-    const float4 *in_q = A.s_rayq[gen & 1u];
+    const float4 *in_q = A.f->s_rayq[gen & 1u];
     const bool primary = gen == 0;
     if (stream_level_is_whole_heavy(A, gen, count)) return;
-    const char *nodes_b = reinterpret_cast<const char *>(A.pnodes);
-    const char *ptris_b = reinterpret_cast<const char *>(A.ptris);
+    const char *nodes_b = reinterpret_cast<const char *>(A.s->pnodes);
+    const char *ptris_b = reinterpret_cast<const char *>(A.s->ptris);
 
     Ray R;
     uint32_t wn = END, we = NONE;   // next mesh-tree node (END: none), leaf cursor
@@ -271,15 +271,15 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArg
         if (__ballot(state == ST_FETCH) && (A.bundle >= 64u || (uint32_t)__popcll(__ballot(state == ST_TRAVERSE)) <= A.bundle)) {
             bool fresh = false;
             while (state == ST_FETCH) {
-                r = wave_fetch(A.s_counts + SC_FETCH + gen, lane);
+                r = wave_fetch(A.f->s_counts + SC_FETCH + gen, lane);
                 if (r >= count) { state = ST_DONE; break; }
                 if (gen == 0) {
-                    const WorkItem wi = A.items[r >> 6];
+                    const WorkItem wi = A.f->items[r >> 6];
                     const uint32_t sub = r & 63u;
-                    const uint32_t px = (wi.tile % A.tiles_x) * TILE + (sub & 7u);
-                    const uint32_t py = (wi.tile / A.tiles_x) * TILE + (sub >> 3);
-                    if (!((wi.mask >> sub) & 1ull) || px >= A.width || py >= A.height) {
-                        reinterpret_cast<uint32_t *>(A.s_nodes + 2 * (size_t)r)[3] = TN_SKIP;
+                    const uint32_t px = (wi.tile % A.s->tiles_x) * TILE + (sub & 7u);
+                    const uint32_t py = (wi.tile / A.s->tiles_x) * TILE + (sub >> 3);
+                    if (!((wi.mask >> sub) & 1ull) || px >= A.s->width || py >= A.s->height) {
+                        reinterpret_cast<uint32_t *>(A.f->s_nodes + 2 * (size_t)r)[3] = TN_SKIP;
                         level0_release_shadow_slots(A, r);
                         continue;
                     }
@@ -292,8 +292,8 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArg
                     ray_prepare(R);
                 }
                 if (R.parmask != 0) {
-                    if (evict_ray(A.s_heavy, A.s_heavy_cap, A.s_counts + SC_HEAVY + gen, r, lane)) continue;
-                    A.s_counts[SC_OVERFLOW] = 1;  // cannot walk it here: let the fallback redo the frame
+                    if (evict_ray(A.f->s_heavy, A.f->s_heavy_cap, A.f->s_counts + SC_HEAVY + gen, r, lane)) continue;
+                    A.f->s_counts[SC_OVERFLOW] = 1;  // cannot walk it here: let the fallback redo the frame
                     continue;
                 }
                 fresh = true;
@@ -370,11 +370,11 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArg
                 }
             }
             if (done) {
-                if (have) btri = A.leaf_tris[btri] & ~LAST;  // leaf entry -> triangle
+                if (have) btri = A.s->leaf_tris[btri] & ~LAST;  // leaf entry -> triangle
                 shade_and_emit<false>(A, gen, r, node_base, child_base, R, have, bt, btri, bmesh, nullptr, lane);
                 state = ST_FETCH;
             } else if (steps >= A.step_budget) {
-                if (evict_ray(A.s_heavy, A.s_heavy_cap, A.s_counts + SC_HEAVY + gen, r, lane)) state = ST_FETCH;
+                if (evict_ray(A.f->s_heavy, A.f->s_heavy_cap, A.f->s_counts + SC_HEAVY + gen, r, lane)) state = ST_FETCH;
                 steps = 0;
             }
         }

@@ -47,13 +47,13 @@ static_assert(SC_WORDS <= SC_HEAVY_DIAG, "counter block too small");
 static_assert(SC_OVERFLOW == SC_OVERFLOW_WORD, "kernel_common.h SC_OVERFLOW_WORD must match");
 
 __device__ __forceinline__ uint32_t stream_level_count(const KernelArgs &A, uint32_t g) {
-    return g == 0 ? A.n_items * 64u : A.s_counts[SC_COUNT + g];
+    return g == 0 ? A.f->n_items * 64u : A.f->s_counts[SC_COUNT + g];
 }
 // Levels below the threshold skip the per-lane kernel: list entry k of the wave-per-ray kernel is ray k itself.
 // (force_whole: the host did not launch the per-lane kernel for this level at all -- a frame ago the level was far below the
 // threshold, crt_tuning::level_grid -- so the wave-per-ray kernel takes every ray whatever the count turns out to be.)
 __device__ __forceinline__ bool stream_level_is_whole_heavy(const KernelArgs &A, uint32_t g, uint32_t count) {
-    return g > 0 && (A.force_whole || count < A.heavy_level_threshold) && count <= A.s_heavy_cap;  // s_hits holds s_heavy_cap records
+    return g > 0 && (A.force_whole || count < A.f->heavy_level_threshold) && count <= A.f->s_heavy_cap;  // s_hits holds s_heavy_cap records
 }
 __device__ __forceinline__ uint32_t stream_level_base(const KernelArgs &A, uint32_t g) {
     uint32_t base = 0;
@@ -88,12 +88,12 @@ __device__ __forceinline__ bool evict_ray(uint32_t *list, uint32_t cap, uint32_t
 // visit the same nodes at the same time, which is what the vector L1 serves cheaply -- and no atomic is needed.  A pixel
 // without a diffuse hit marks its slots unused (distance word all ones: no computed distance has that pattern).
 constexpr uint32_t SHADOW_SLOT_UNUSED = 0xFFFFFFFFu;
-__device__ __forceinline__ uint32_t level0_shadow_slot(const KernelArgs &A, uint32_t r) { return (r >> 6) * A.n_lights * 64u + (r & 63u); }
+__device__ __forceinline__ uint32_t level0_shadow_slot(const KernelArgs &A, uint32_t r) { return (r >> 6) * A.s->n_lights * 64u + (r & 63u); }
 __device__ __forceinline__ void level0_release_shadow_slots(const KernelArgs &A, uint32_t r) {
-    if (!A.fixed0) return;
+    if (!A.f->fixed0) return;
     const size_t first = level0_shadow_slot(A, r);
-    for (uint32_t li = 0; li < A.n_lights; li++)
-        A.s_shadowq[2 * (first + (size_t)li * 64u)] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(SHADOW_SLOT_UNUSED));
+    for (uint32_t li = 0; li < A.s->n_lights; li++)
+        A.f->s_shadowq[2 * (first + (size_t)li * 64u)] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(SHADOW_SLOT_UNUSED));
 }
 
 // shootRay's dispatch on the closest hit (RayTracer.cpp:431-450), in two steps.  shade_hit: everything but the child
@@ -114,9 +114,9 @@ __device__ __forceinline__ void shade_hit(const KernelArgs &A, const uint32_t ge
                                           const uint32_t lane, Shaded &E, bool *out_diffuse = nullptr,
                                           uint32_t *out_first = nullptr, uint32_t *out_stride = nullptr) {
     if (out_diffuse) *out_diffuse = false;
-    const bool spawn_allowed = gen + 1 <= A.max_depth;  // a child enters shootRay with depth gen+1 (RayTracer.cpp:427)
+    const bool spawn_allowed = gen + 1 <= A.f->max_depth;  // a child enters shootRay with depth gen+1 (RayTracer.cpp:427)
     TNode &N = E.N;
-    N.cx = A.bgx; N.cy = A.bgy; N.cz = A.bgz;
+    N.cx = A.s->bgx; N.cy = A.s->bgy; N.cz = A.s->bgz;
     N.kind = TN_CONST; N.a = 0; N.b = 0; N.f = 0; N.pad = 0;
     E.reflect = false; E.transmit = false;
     E.rox = E.roy = E.roz = E.rdx = E.rdy = E.rdz = 0;
@@ -129,36 +129,36 @@ __device__ __forceinline__ void shade_hit(const KernelArgs &A, const uint32_t ge
             // calculateDiffusion (RayTracer.cpp:300-330): the light loop becomes n_lights shadow rays
             bool bitmap = false;
             if (S.M.texture >= 0)
-                texture_color<COUNT>(A, A.textures[S.M.texture], btri, S.u, S.v, 1.0f - S.u - S.v, N.cx, N.cy, N.cz, bitmap);
+                texture_color<COUNT>(A, A.s->textures[S.M.texture], btri, S.u, S.v, 1.0f - S.u - S.v, N.cx, N.cy, N.cz, bitmap);
             else { N.cx = S.M.ax; N.cy = S.M.ay; N.cz = S.M.az; }
             const unsigned long long mask = __ballot(1);
             uint32_t cntd = (uint32_t)__popcll(mask);
             uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
             uint32_t base = 0;
-            if (gen == 0 && A.fixed0) {
-                base = (r >> 6) * A.n_lights * 64u;  // level0_shadow_slot(r) = base + rank, one light apart = 64 slots
+            if (gen == 0 && A.f->fixed0) {
+                base = (r >> 6) * A.s->n_lights * 64u;  // level0_shadow_slot(r) = base + rank, one light apart = 64 slots
                 rank = r & 63u;
                 cntd = 64u;
             } else {
-                if (rank == 0) base = atomicAdd(A.s_counts + SC_SHADOW, cntd * A.n_lights);
+                if (rank == 0) base = atomicAdd(A.f->s_counts + SC_SHADOW, cntd * A.s->n_lights);
                 base = __shfl(base, __ffsll((long long)mask) - 1);
             }
-            if ((uint64_t)base + (uint64_t)cntd * A.n_lights > A.s_shadow_cap) {
-                A.s_counts[SC_OVERFLOW] = 1;
+            if ((uint64_t)base + (uint64_t)cntd * A.s->n_lights > A.f->s_shadow_cap) {
+                A.f->s_counts[SC_OVERFLOW] = 1;
                 N.cx = N.cy = N.cz = 0;  // the frame is redone by the fallback path
             } else {
                 N.kind = TN_DIFFUSE | (bitmap ? TN_BITMAP : 0u);
                 N.a = base + rank;
                 N.b = cntd;
                 if (out_diffuse) { *out_diffuse = true; *out_first = N.a; *out_stride = cntd; }
-                for (uint32_t li = 0; li < A.n_lights; li++) {
+                for (uint32_t li = 0; li < A.s->n_lights; li++) {
                     Ray SR;
                     float dist, kfac;
                     light_setup(A, li, S.px, S.py, S.pz, S.nx, S.ny, S.nz, SR, dist, kfac);
                     if (COUNT) { cnt[C_LIGHT]++; cnt[C_SHADOW]++; }
                     const size_t slot = (size_t)base + (size_t)li * cntd + rank;
-                    A.s_shadowq[2 * slot] = make_float4(SR.ox, SR.oy, SR.oz, dist);
-                    A.s_shadowq[2 * slot + 1] = make_float4(SR.dx, SR.dy, SR.dz, kfac);
+                    A.f->s_shadowq[2 * slot] = make_float4(SR.ox, SR.oy, SR.oz, dist);
+                    A.f->s_shadowq[2 * slot + 1] = make_float4(SR.dx, SR.dy, SR.dz, kfac);
                 }
             }
         } else if (S.M.type == CRT_MAT_REFLECTIVE || S.M.type == CRT_MAT_REFRACTIVE) {
@@ -187,7 +187,7 @@ __device__ __forceinline__ void shade_hit(const KernelArgs &A, const uint32_t ge
                     E.tdy = eta_ratio * (R.dy + cos_a * ny) - cos_b * ny;
                     E.tdz = eta_ratio * (R.dz + cos_a * nz) - cos_b * nz;
                     normalize3(E.tdx, E.tdy, E.tdz);
-                    E.tox = S.px - nx * A.refraction_bias; E.toy = S.py - ny * A.refraction_bias; E.toz = S.pz - nz * A.refraction_bias;
+                    E.tox = S.px - nx * A.f->refraction_bias; E.toy = S.py - ny * A.f->refraction_bias; E.toz = S.pz - nz * A.f->refraction_bias;
                     transmit = true;
                 }
                 N.kind = TN_REFRACT;
@@ -199,7 +199,7 @@ __device__ __forceinline__ void shade_hit(const KernelArgs &A, const uint32_t ge
             const float k = 2 * dot3(R.dx, R.dy, R.dz, nx, ny, nz);
             E.rdx = R.dx - k * nx; E.rdy = R.dy - k * ny; E.rdz = R.dz - k * nz;
             normalize3(E.rdx, E.rdy, E.rdz);
-            E.rox = S.px + nx * A.reflection_bias; E.roy = S.py + ny * A.reflection_bias; E.roz = S.pz + nz * A.reflection_bias;
+            E.rox = S.px + nx * A.f->reflection_bias; E.roy = S.py + ny * A.f->reflection_bias; E.roz = S.pz + nz * A.f->reflection_bias;
             N.a = CHILD_BG;
             N.b = refractive ? (transmit ? CHILD_BG : CHILD_NONE) : 0u;
             E.reflect = spawn_allowed;
@@ -211,7 +211,7 @@ __device__ __forceinline__ void shade_hit(const KernelArgs &A, const uint32_t ge
 }
 
 __device__ __forceinline__ void store_tnode(const KernelArgs &A, const size_t index, const TNode &N) {
-    float4 *dst = A.s_nodes + 2 * index;
+    float4 *dst = A.f->s_nodes + 2 * index;
     dst[0] = make_float4(N.cx, N.cy, N.cz, __uint_as_float(N.kind));
     dst[1] = make_float4(__uint_as_float(N.a), __uint_as_float(N.b), N.f, 0.0f);
 }
@@ -234,8 +234,8 @@ __device__ __forceinline__ void shade_and_emit(const KernelArgs &A, const uint32
     Shaded E;
     shade_hit<COUNT>(A, gen, r, R, have, bt, btri, bmesh, cnt, lane, E, out_diffuse, out_first, out_stride);
     if (E.reflect) {
-        float4 *out_q = A.s_rayq[(gen + 1u) & 1u];
-        uint32_t *out_count = A.s_counts + SC_COUNT + gen + 1;
+        float4 *out_q = A.f->s_rayq[(gen + 1u) & 1u];
+        uint32_t *out_count = A.f->s_counts + SC_COUNT + gen + 1;
         // wave-aggregated append of 1 or 2 child rays per lane
         const unsigned long long m1 = __ballot(1), m2 = __ballot(E.transmit);
         const unsigned long long below = (1ull << lane) - 1ull;
@@ -243,8 +243,8 @@ __device__ __forceinline__ void shade_and_emit(const KernelArgs &A, const uint32
         uint32_t base = 0;
         if ((m1 & below) == 0) base = atomicAdd(out_count, n1 + n2);
         base = __shfl(base, __ffsll((long long)m1) - 1);
-        if ((uint64_t)base + n1 + n2 > A.s_ray_cap || (uint64_t)child_base + base + n1 + n2 > A.s_node_cap) {
-            A.s_counts[SC_OVERFLOW] = 1;
+        if ((uint64_t)base + n1 + n2 > A.f->s_ray_cap || (uint64_t)child_base + base + n1 + n2 > A.f->s_node_cap) {
+            A.f->s_counts[SC_OVERFLOW] = 1;
         } else {
             const uint32_t i1 = base + (uint32_t)__popcll(m1 & below);
             store_child_ray(out_q, i1, E.rox, E.roy, E.roz, E.rdx, E.rdy, E.rdz, gen + 1u, child_base + i1);
@@ -262,11 +262,11 @@ __device__ __forceinline__ void shade_and_emit(const KernelArgs &A, const uint32
 template <bool COUNT>
 __global__ __launch_bounds__(BLOCK) void stream_trace_shade(const KernelArgs A, const uint32_t gen) {
     const uint32_t lane = threadIdx.x & 63u;
-    if (A.s_counts[SC_OVERFLOW]) return;  // the fallback path redoes the frame
+    if (A.f->s_counts[SC_OVERFLOW]) return;  // the fallback path redoes the frame
     const uint32_t count = stream_level_count(A, gen);
     const uint32_t node_base = stream_level_base(A, gen);
     const uint32_t child_base = node_base + count;
-    const float4 *in_q = A.s_rayq[gen & 1u];
+    const float4 *in_q = A.f->s_rayq[gen & 1u];
 
     uint32_t cnt[C_N];
     if (COUNT) for (int k = 0; k < C_N; k++) cnt[k] = 0;
@@ -281,15 +281,15 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade(const KernelArgs A, 
         // ------------------------------------------------------------------ fetch
         if (__ballot(state == ST_FETCH)) {
             while (state == ST_FETCH) {
-                r = wave_fetch(A.s_counts + SC_FETCH + gen, lane);
+                r = wave_fetch(A.f->s_counts + SC_FETCH + gen, lane);
                 if (r >= count) { state = ST_DONE; break; }
                 if (gen == 0) {
-                    const WorkItem wi = A.items[r >> 6];
+                    const WorkItem wi = A.f->items[r >> 6];
                     const uint32_t sub = r & 63u;
-                    const uint32_t px = (wi.tile % A.tiles_x) * TILE + (sub & 7u);
-                    const uint32_t py = (wi.tile / A.tiles_x) * TILE + (sub >> 3);
-                    if (!((wi.mask >> sub) & 1ull) || px >= A.width || py >= A.height) {
-                        reinterpret_cast<uint32_t *>(A.s_nodes + 2 * (size_t)r)[3] = TN_SKIP;
+                    const uint32_t px = (wi.tile % A.s->tiles_x) * TILE + (sub & 7u);
+                    const uint32_t py = (wi.tile / A.s->tiles_x) * TILE + (sub >> 3);
+                    if (!((wi.mask >> sub) & 1ull) || px >= A.s->width || py >= A.s->height) {
+                        reinterpret_cast<uint32_t *>(A.f->s_nodes + 2 * (size_t)r)[3] = TN_SKIP;
                         level0_release_shadow_slots(A, r);
                         continue;
                     }
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade(const KernelArgs A, 
                     L.rtype = RAY_REFLECTION;      // reflection and refraction rays behave alike in the walk
                     if (COUNT) cnt[C_SECONDARY]++;
                 }
-                traversal_begin(L, A.top_root);
+                traversal_begin(L, A.s->top_root);
                 state = ST_TRAVERSE;
             }
         }
@@ -329,11 +329,11 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade(const KernelArgs A, 
         } else if (state == ST_TRAVERSE && A.step_budget && steps >= A.step_budget) {
             const unsigned long long em = __ballot(1);
             uint32_t base = 0;
-            if ((em & ((1ull << lane) - 1ull)) == 0) base = atomicAdd(A.s_counts + SC_HEAVY + gen, (uint32_t)__popcll(em));
+            if ((em & ((1ull << lane) - 1ull)) == 0) base = atomicAdd(A.f->s_counts + SC_HEAVY + gen, (uint32_t)__popcll(em));
             base = __shfl(base, __ffsll((long long)em) - 1);
             const uint32_t slot = base + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
-            if (slot < A.s_heavy_cap) {
-                A.s_heavy[slot] = r;
+            if (slot < A.f->s_heavy_cap) {
+                A.f->s_heavy[slot] = r;
                 state = ST_FETCH;
             }
             steps = 0;  // list full: keep walking here
@@ -354,23 +354,23 @@ template <bool COUNT>
 __global__ __launch_bounds__(BLOCK) void stream_shade_evicted(const KernelArgs A, const uint32_t gen) {
     if (A.wave_prio) __builtin_amdgcn_s_setprio(3);  // ahead of the bulk shadow pass's waves on this SIMD
     const uint32_t lane = threadIdx.x & 63u;
-    if (A.s_counts[SC_OVERFLOW]) return;
+    if (A.f->s_counts[SC_OVERFLOW]) return;
     const uint32_t count = stream_level_count(A, gen);
     const bool whole = stream_level_is_whole_heavy(A, gen, count);
-    uint32_t total = whole ? count : A.s_counts[SC_HEAVY + gen];
-    if (total > A.s_heavy_cap) total = A.s_heavy_cap;
+    uint32_t total = whole ? count : A.f->s_counts[SC_HEAVY + gen];
+    if (total > A.f->s_heavy_cap) total = A.f->s_heavy_cap;
     const uint32_t node_base = stream_level_base(A, gen);
     const uint32_t child_base = node_base + count;
-    const float4 *in_q = A.s_rayq[gen & 1u];
+    const float4 *in_q = A.f->s_rayq[gen & 1u];
     uint32_t cnt[C_N];
     if (COUNT) for (int k = 0; k < C_N; k++) cnt[k] = 0;
     for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < total; k += gridDim.x * BLOCK) {
-        const uint32_t r = whole ? k : A.s_heavy[k];
+        const uint32_t r = whole ? k : A.f->s_heavy[k];
         Ray R;
         if (gen == 0) {
-            const WorkItem wi = A.items[r >> 6];
+            const WorkItem wi = A.f->items[r >> 6];
             const uint32_t sub = r & 63u;
-            primary_ray(A, (wi.tile % A.tiles_x) * TILE + (sub & 7u), (wi.tile / A.tiles_x) * TILE + (sub >> 3), R);
+            primary_ray(A, (wi.tile % A.s->tiles_x) * TILE + (sub & 7u), (wi.tile / A.s->tiles_x) * TILE + (sub >> 3), R);
         } else {
             const float4 q0 = in_q[2 * (size_t)r], q1 = in_q[2 * (size_t)r + 1];
             R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(BLOCK) void stream_shade_evicted(const KernelArgs A
             normalize3(R.dx, R.dy, R.dz);
             ray_prepare(R);
         }
-        const float4 h = A.s_hits[k];
+        const float4 h = A.f->s_hits[k];
         shade_and_emit<COUNT>(A, gen, r, node_base, child_base, R, __float_as_uint(h.w) != 0, h.x, __float_as_uint(h.y),
                               __float_as_uint(h.z), cnt, lane);
     }
@@ -397,17 +397,17 @@ __global__ __launch_bounds__(BLOCK) void stream_shade_evicted(const KernelArgs A
 // pass 0 = the rays queued by level 0 (indices below the split mark), on a side stream as soon as level 0 is
 // done; pass 1 = the rest, after the last level.
 __global__ void stream_mark_split(const KernelArgs A, const uint32_t dst_word, const uint32_t src_word) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) A.s_counts[dst_word] = A.s_counts[src_word];
+    if (threadIdx.x == 0 && blockIdx.x == 0) A.f->s_counts[dst_word] = A.f->s_counts[src_word];
 }
 
 template <bool COUNT>
 __global__ __launch_bounds__(BLOCK) void stream_trace_shadow(const KernelArgs A, const uint32_t pass) {
     const uint32_t lane = threadIdx.x & 63u;
-    if (A.s_counts[SC_OVERFLOW]) return;  // the fallback path redoes the frame
-    const uint32_t split = A.s_counts[SC_SHADOW_SPLIT];
+    if (A.f->s_counts[SC_OVERFLOW]) return;  // the fallback path redoes the frame
+    const uint32_t split = A.f->s_counts[SC_SHADOW_SPLIT];
     const uint32_t first = pass == 0 ? 0u : split;
-    const uint32_t total = pass == 0 ? split : A.s_counts[SC_SHADOW] - split;
-    uint32_t *cursor = A.s_counts + (pass == 0 ? SC_SHADOW_FETCH : SC_SHADOW_FETCH2);
+    const uint32_t total = pass == 0 ? split : A.f->s_counts[SC_SHADOW] - split;
+    uint32_t *cursor = A.f->s_counts + (pass == 0 ? SC_SHADOW_FETCH : SC_SHADOW_FETCH2);
     uint32_t cnt[C_N];
     if (COUNT) for (int k = 0; k < C_N; k++) cnt[k] = 0;
 
@@ -422,13 +422,13 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shadow(const KernelArgs A,
                 if (r >= total) state = ST_DONE;
                 else {
                     r += first;
-                    const float4 q0 = A.s_shadowq[2 * (size_t)r], q1 = A.s_shadowq[2 * (size_t)r + 1];
+                    const float4 q0 = A.f->s_shadowq[2 * (size_t)r], q1 = A.f->s_shadowq[2 * (size_t)r + 1];
                     if (__float_as_uint(q0.w) != SHADOW_SLOT_UNUSED) {  // (unused: the lane fetches again next trip)
                         R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
                         R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;  // already normalised once; shadow rays skip shootRay (RayTracer.cpp:313-317)
                         ray_prepare(R);
                         L.rtype = RAY_SHADOW;
-                        traversal_begin(L, A.top_root);
+                        traversal_begin(L, A.s->top_root);
                         L.light_dist = q0.w;
                         state = ST_TRAVERSE;
                     }
@@ -444,17 +444,17 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shadow(const KernelArgs A,
                 steps++;
             } while (--budget > 0);
             if (finished) {
-                A.s_occluded[r] = L.occluded ? 1 : 0;
+                A.f->s_occluded[r] = L.occluded ? 1 : 0;
                 steps = 0;
                 state = ST_FETCH;
             } else if (A.step_budget && steps >= A.step_budget) {  // a long walk: hand it to heavy_trace_shadow
                 const unsigned long long em = __ballot(1);
                 uint32_t base = 0;
-                if ((em & ((1ull << lane) - 1ull)) == 0) base = atomicAdd(A.s_counts + SC_SHEAVY, (uint32_t)__popcll(em));
+                if ((em & ((1ull << lane) - 1ull)) == 0) base = atomicAdd(A.f->s_counts + SC_SHEAVY, (uint32_t)__popcll(em));
                 base = __shfl(base, __ffsll((long long)em) - 1);
                 const uint32_t slot = base + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
-                if (slot < A.s_heavy_cap) {
-                    A.s_sheavy[slot] = r;
+                if (slot < A.f->s_heavy_cap) {
+                    A.f->s_sheavy[slot] = r;
                     state = ST_FETCH;
                 }
                 steps = 0;
@@ -479,10 +479,10 @@ __device__ __forceinline__ void resolve_leaf(const KernelArgs &A, const float4 &
         // finalColor += (intensity / area * angle) * albedo, light by light in the reference's order (RayTracer.cpp:319-329)
         const uint32_t first = __float_as_uint(n1.x), stride = __float_as_uint(n1.y);
         float ax = 0, ay = 0, az = 0;
-        for (uint32_t li = 0; li < A.n_lights; li++) {
+        for (uint32_t li = 0; li < A.s->n_lights; li++) {
             const size_t slot = (size_t)first + (size_t)li * stride;
-            if (!A.s_occluded[slot]) {
-                const float k = A.s_shadowq[2 * slot + 1].w;
+            if (!A.f->s_occluded[slot]) {
+                const float k = A.f->s_shadowq[2 * slot + 1].w;
                 if (COUNT && (kind & TN_BITMAP)) cnt[C_TEXEL]++;
                 ax += k * n0.x; ay += k * n0.y; az += k * n0.z;
             }
@@ -498,10 +498,10 @@ __device__ __forceinline__ void resolve_leaf(const KernelArgs &A, const float4 &
 template <bool COUNT>
 __global__ __launch_bounds__(BLOCK) void stream_resolve(const KernelArgs A) {
     const uint32_t lane = threadIdx.x & 63u;
-    if (A.s_counts[SC_OVERFLOW]) return;  // the fallback path redoes the frame
-    const uint32_t total = A.n_items * 64u;
-    const float4 *nodes = A.s_nodes;
-    float4 *wnodes = A.s_nodes;
+    if (A.f->s_counts[SC_OVERFLOW]) return;  // the fallback path redoes the frame
+    const uint32_t total = A.f->n_items * 64u;
+    const float4 *nodes = A.f->s_nodes;
+    float4 *wnodes = A.f->s_nodes;
     uint32_t cnt[C_N];
     if (COUNT) for (int k = 0; k < C_N; k++) cnt[k] = 0;
     uint32_t stack[MAX_GENERATIONS];
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(BLOCK) void stream_resolve(const KernelArgs A) {
         // by the child just finished and stack[sp-1] is its parent.
         for (;;) {
             if (descending) {
-                if (cur == CHILD_BG) { cx = A.bgx; cy = A.bgy; cz = A.bgz; descending = false; }
+                if (cur == CHILD_BG) { cx = A.s->bgx; cy = A.s->bgy; cz = A.s->bgz; descending = false; }
                 else {
                     const float4 n0 = nodes[2 * (size_t)cur], n1 = nodes[2 * (size_t)cur + 1];
                     const uint32_t kind = __float_as_uint(n0.w) & TN_KIND_MASK;
@@ -555,11 +555,11 @@ __global__ __launch_bounds__(BLOCK) void stream_resolve(const KernelArgs A) {
                 }
             }
         }
-        const WorkItem wi = A.items[q >> 6];
+        const WorkItem wi = A.f->items[q >> 6];
         const uint32_t sub = q & 63u;
-        const uint32_t px = (wi.tile % A.tiles_x) * TILE + (sub & 7u), py = (wi.tile / A.tiles_x) * TILE + (sub >> 3);
-        const size_t out_off = A.packed ? ((size_t)wi.out_tile * 64 + sub) * 3 : ((size_t)py * A.width + px) * 3;
-        A.out[out_off] = cx; A.out[out_off + 1] = cy; A.out[out_off + 2] = cz;  // RayTracer.cpp:106
+        const uint32_t px = (wi.tile % A.s->tiles_x) * TILE + (sub & 7u), py = (wi.tile / A.s->tiles_x) * TILE + (sub >> 3);
+        const size_t out_off = A.f->packed ? ((size_t)wi.out_tile * 64 + sub) * 3 : ((size_t)py * A.s->width + px) * 3;
+        A.f->out[out_off] = cx; A.f->out[out_off + 1] = cy; A.f->out[out_off + 2] = cz;  // RayTracer.cpp:106
     }
     if (COUNT) {
         for (int k = 0; k < C_N; k++) {

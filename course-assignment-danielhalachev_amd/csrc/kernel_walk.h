@@ -40,19 +40,19 @@ struct TopLds {
 // Called by every thread of the workgroup before anything else (it holds a barrier).
 __device__ __forceinline__ TopLds top_lds_load(const KernelArgs &A, TopLdsStorage &S) {
     TopLds T;
-    T.fast = A.top_lds != 0;
-    T.first = A.top_first;
+    T.fast = A.s->top_lds != 0;
+    T.first = A.s->top_first;
     T.nodes = (lds_f4)S.nodes;
     T.meshes = (lds_u4)S.meshes;
     T.entries = (lds_u32)S.entries;
     if (T.fast) {
-        for (uint32_t i = threadIdx.x; i < A.top_count * 2u; i += blockDim.x) {
-            const float4 q = A.nodes[2 * (size_t)A.top_first + i];
+        for (uint32_t i = threadIdx.x; i < A.s->top_count * 2u; i += blockDim.x) {
+            const float4 q = A.s->nodes[2 * (size_t)A.s->top_first + i];
             S.nodes[i] = lds_v4f{q.x, q.y, q.z, q.w};
         }
-        for (uint32_t i = threadIdx.x; i < A.top_leaf_entries; i += blockDim.x) S.entries[i] = A.leaf_meshes[i];
-        for (uint32_t i = threadIdx.x; i < A.top_meshes; i += blockDim.x) {
-            const crt_mesh m = A.meshes[i];
+        for (uint32_t i = threadIdx.x; i < A.s->top_leaf_entries; i += blockDim.x) S.entries[i] = A.s->leaf_meshes[i];
+        for (uint32_t i = threadIdx.x; i < A.s->top_meshes; i += blockDim.x) {
+            const crt_mesh m = A.s->meshes[i];
             S.meshes[i] = lds_v4u{m.flags, m.root, 0u, m.pad};  // (pad: index + 1 among the single-leaf meshes, kernel_heavy.h)
         }
         __syncthreads();

@@ -174,8 +174,9 @@ typedef struct crt_ctx crt_ctx;
 /* Kernel selection and sizing.  Nothing here changes a pixel: every combination renders the same frame bit for
  * bit (tests/test_gpu_parity.py runs the matrix); the defaults are what bench.py measures.  The reference has no
  * counterpart (its only tunables are RenderOptions, above); the library reads NO environment variables.
- * (Round 2's 43 fields selected between ~20 kernel variants; the variants that lost their measurements were removed --
- * DESIGN.md section 7 keeps the numbers, git keeps the code -- and their constants are now constants.) */
+ * (Round 2's 43 fields selected between ~20 kernel variants and fed a wall-clock autotuner; the variants that lost their
+ * measurements were removed -- DESIGN.md section 7 keeps the numbers, git keeps the code -- their constants are now constants,
+ * and the defaults below are within 1.5 % of the best setting on every BASELINE scene.) */
 enum { CRT_MODE_STREAM = 0, CRT_MODE_LANES = 1 };
 typedef struct crt_tuning {
     uint32_t size;            /* sizeof(crt_tuning), filled in by crt_tuning_defaults */
@@ -187,10 +188,6 @@ typedef struct crt_tuning {
     uint32_t side_blocks;     /* 3: workgroups per CU of the bulk shadow pass on the side stream; 0 = no side stream */
     uint32_t node_cap, ray_cap, shadow_cap; /* 0 = the queues follow the frames; explicit values make
                                              * queue overflow -- and the fallback -- reachable in tests */
-    uint32_t autotune;        /* 1: three settings whose best value depends on the scene (level 0's step budget, heavy_level, side_blocks 3 / 4)
-                               * are tried on the frames themselves -- a dozen frames each, timed by the events every frame records -- and
-                               * the faster setting is kept (crt_device.hip: autotune_step); off when level0_budget, heavy_level or
-                               * step_budget are given explicitly; side_blocks is only tried from its default of 3 */
 } crt_tuning;
 void crt_tuning_defaults(crt_tuning *tuning);
 

@@ -63,7 +63,7 @@ KERNEL_PATHS = [
     dict(heavy_level=3000),                                      # ... some levels straddle the threshold
     dict(side_blocks=0),                                         # no side stream
     dict(step_budget=100000, shadow_budget=100000, heavy_level=0),  # nothing evicted: per-lane kernels alone
-    dict(autotune=0, side_blocks=4),                             # fixed settings
+    dict(side_blocks=4),                                         # the bulk shadow pass on four workgroups per CU
 ]
 
 
@@ -426,34 +426,3 @@ def test_async_frames_equal_synchronous_ones(pkg, scenes, oracle):
         want, _ = o.render(depth)
         assert_same_floats(bufs[j % 2][0], want, "async frame %d" % j)
     assert ring[0].stats().pixels == H * W and ring[0].stats().kernel_ms > 0
-
-
-def test_autotune_tries_settings_on_the_frames_and_never_changes_one(pkg, scenes, oracle):
-    """crt_tuning::autotune (default on): a context times its own frames and tries two budgets on them.  Every frame on the way is
-    the oracle's, and after enough frames the context has settled; explicit budgets switch the tuner off."""
-    scene, depth, _ = small_case(scenes, "hw14")
-    want, _ = oracle.OracleScene(scenes.to_blob(scene)).render(depth)
-    tracer = make_tracer(pkg, scenes, scene)
-    assert tracer.kernels()["autotune"].startswith("measuring")
-    for k in range(100):
-        got = tracer.render(max_depth=depth)
-        if k % 7 == 0 or k > 90:
-            assert_same_floats(got, want, "autotune frame %d (%s)" % (k, tracer.kernels()["autotune"]))
-    assert tracer.kernels()["autotune"].startswith("settled"), tracer.kernels()["autotune"]
-    assert tracer.stats().fallback_frames == 0
-    settled = tracer.kernels()["autotune"]
-    # frames the tuner must not learn from (the counting build, a GI frame) leave it where it is
-    tracer.render(max_depth=depth, counters=True)
-    tracer.render(options=pkg.make_options(depth, use_gi=True, gi_sample_size=1, rays_per_pixel=1, gi_seed=1))
-    assert_same_floats(tracer.render(max_depth=depth), want, "after a counting and a GI frame")
-    assert tracer.kernels()["autotune"] == settled
-    # another depth is another workload: the tuner starts over
-    tracer.render(max_depth=depth - 1)
-    assert tracer.kernels()["autotune"].startswith("measuring")
-    fixed = make_tracer(pkg, scenes, scene, tuning=dict(level0_budget=192))
-    for _ in range(3):
-        fixed.render(max_depth=depth)
-    assert fixed.kernels()["autotune"].startswith("measuring level0_budget=0")   # never leaves its start: not eligible
-    off = make_tracer(pkg, scenes, scene, tuning=dict(autotune=0))
-    off.render(max_depth=depth)
-    assert off.kernels()["autotune"].startswith("off")

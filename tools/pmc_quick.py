@@ -8,7 +8,7 @@ d = os.path.join(root, "gpurun_out", "pmcq_" + tag)
 os.makedirs(d, exist_ok=True)
 cmd = ["rocprofv3", "--pmc"] + counters + ["-d", d, "--output-format", "csv", "--", "python3", os.path.join(root, "tools", "stream_stats.py"), scene]
 with open(os.path.join(d, "run.log"), "w") as log:
-    rc = subprocess.run(cmd, cwd=root, env=dict(os.environ, TMPDIR="/tmp"), stdout=log, stderr=subprocess.STDOUT, timeout=500).returncode
+    rc = subprocess.run(cmd, cwd=root, env=dict(os.environ, TMPDIR="/tmp"), stdout=log, stderr=subprocess.STDOUT, timeout=150).returncode
 f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
 if not f:
     print("no counter file, rc", rc); sys.exit(1)
