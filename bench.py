@@ -10,8 +10,10 @@ HBM before the timed region.  With N > 1 the frame's 8x8 tiles are dealt round-r
 process per GPU, scene replicated), each rank renders its tiles into a packed device buffer and one RCCL
 all_gather collects them; rank 0 scatters them into the row-major frame.  The timed region
 is bracketed by barrier + torch.cuda.synchronize() on both sides, the MAX over ranks is taken, and rank 0
-prints ONE JSON line.  `value` is the whole job's Mpixels/s with the finished frame left in HBM on rank 0;
-the device->host-inclusive rate is reported beside it as `value_incl_d2h` (never as `value`).
+prints ONE JSON line.  `value` is the whole job's Mpixels/s as SURVEY.md section 8(d) defines the metric -- the
+reference's timing window ends with the float frame in HOST memory (RayTracer.cpp:207,289-293) -- so every timed
+frame is copied to pinned host memory inside the timed region, on a copy stream, frame k's copy beside frame
+k + 1's kernels.  `value_device_resident` is the same loop without the copies.
 
 PyTorch is plumbing here (device buffers, streams, torch.distributed); the renderer is libcrt_hip.so.
 """
@@ -28,6 +30,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+HBM_MEASURED_GBS = 6290.0  # ... and the streaming rate measured there (float4 copy, 79 %)
+N_CUS, N_SIMDS = 256, 1024
 WORKLOAD = "hw14"
 
 
@@ -89,19 +93,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--settle", type=int, default=100,
-                    help="untimed frames rendered one at a time BEFORE the warm-up steps, on which the context's crt_tuning::autotune tries "
-                         "its candidate settings and settles (part of preparing the context, like building the tree; 0: none)")
     ap.add_argument("--scene", default=WORKLOAD)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=None,
-                    help="frames in flight of the extra `pipelined` measurement (default: 3 on one GPU, 0 = skipped on several, where only "
-                         "the gloo rehearsal of the gather has run so far); `value` is always one frame at a time")
+                    help="frames in flight of the extra `pipelined` measurement (default 3, 0 = skipped); `value` is always one frame at a time")
     ap.add_argument("--no-alone", action="store_true", help="skip roofline.alone (keeps a rocprofv3 --stats run of this command to the in-frame launches)")
     ap.add_argument("--tuning", default="", help="development: crt_tuning fields as 'name=value ...' (default: the library's defaults)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the collective path (process group, all_gather_into_tensor) even with one rank: exercises the RCCL "
+                         "branch on a one-GPU box (tests/test_gpu_cli.py)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="development only: N processes share GPU 0 and gather through gloo on host buffers "
                          "(exercises the multi-rank code path on a one-GPU box; its numbers mean nothing)")
@@ -125,8 +128,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist   # the gather is a collective (with one rank: a copy, through the same RCCL call)
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.rehearse_gloo:
             dist.init_process_group(backend="gloo")
         else:
@@ -149,27 +156,45 @@ def main():
     per_rank = (n_tiles + world - 1) // world            # tiles per rank, padded to the same count
     part_floats = per_rank * 64 * 3
     packed = torch.zeros(part_floats, dtype=torch.float32, device=dev)
-    gathered = torch.zeros(part_floats * world, dtype=torch.float32, device=dev) if world > 1 else packed
-    frame = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
+    gathered = torch.zeros(part_floats * world, dtype=torch.float32, device=dev) if dist_on else packed
+    # rank 0 assembles the frame; two buffers, so that frame k's copy to the host can run beside frame k + 1's kernels
+    frames2 = [torch.zeros(H * W * 3, dtype=torch.float32, device=dev) for _ in range(2)]
+    frame = frames2[0]
+    hosts2 = [torch.empty(H * W * 3, dtype=torch.float32).pin_memory() for _ in range(2)] if rank == 0 else None
     stream = torch.cuda.current_stream(dev)
     sptr = stream.cuda_stream
+    copy_stream = torch.cuda.Stream(dev)
+    ev_done = [torch.cuda.Event() for _ in range(2)]
+    ev_copied = [torch.cuda.Event() for _ in range(2)]
     opts = pkg.make_options(depth)
 
     failed = False
+    step_no = [0]
 
-    def step():
+    def step(to_host=False):
+        k = step_no[0] % 2
+        step_no[0] += 1
         tracer.render_tiles_device(opts, rank, world, packed.data_ptr(), sptr)
-        if world > 1 and args.rehearse_gloo:
+        if dist_on and args.rehearse_gloo:
             parts = [torch.empty(part_floats) for _ in range(world)]
             dist.all_gather(parts, packed.cpu())
             gathered.copy_(torch.cat(parts))
-        elif world > 1:
+        elif dist_on:
             dist.all_gather_into_tensor(gathered, packed)
         if rank == 0:
-            tracer.unpack_tiles_device(gathered.data_ptr(), world, part_floats, frame.data_ptr(), sptr)
+            if to_host:
+                stream.wait_event(ev_copied[k])       # (the copy of the frame that used this buffer two steps ago)
+            tracer.unpack_tiles_device(gathered.data_ptr(), world, part_floats, frames2[k].data_ptr(), sptr)
+            if to_host:
+                # the reference's window ends with the frame in host memory (RayTracer.cpp:289-293): copied on a stream of its own
+                ev_done[k].record(stream)
+                copy_stream.wait_event(ev_done[k])
+                with torch.cuda.stream(copy_stream):
+                    hosts2[k].copy_(frames2[k], non_blocking=True)
+                    ev_copied[k].record(copy_stream)
 
     def fence():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -192,61 +217,52 @@ def main():
     frame_ok = bool(torch.equal(packed.view(torch.int32), counted_pixels.view(torch.int32)))
     del counted_pixels
 
-    # Preparing the context: crt_tuning::autotune times the context's own frames and tries three settings on
-    # them; like the tree build and the queue sizing this happens once per workload, before the steady state the bench measures.
-    # One frame at a time, so that the context sees each frame's duration before it launches the next.  (The same number of
-    # frames on every rank: the gather inside step() is a collective.)
-    for _ in range(max(0, args.settle)):
-        step()
-        tracer.synchronize()
+    def timed(n, to_host):
+        fence()
+        t_ = time.perf_counter()
+        for _ in range(n):
+            step(to_host)
+        fence()
+        e = time.perf_counter() - t_
+        if world > 1:
+            tt = torch.tensor([e], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            e = float(tt.item())
+        return e
+
+    cdev = torch.device("cpu") if args.rehearse_gloo else dev
     for _ in range(args.warmup):
-        step()
+        step(True)
     fence()
     # queue capacities follow the frames: a context's FIRST frames may outgrow them and be redone by the
     # queue-less kernel.  Such a frame inside the timed region would not be a measurement of the path; before it, it is start-up.
     tracer.synchronize()
     fallback_before = int(tracer.stats().fallback_frames)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    # THE timed region: K frames, each one ending in pinned host memory on rank 0 (frame k's copy beside frame k + 1's kernels)
+    elapsed = timed(args.steps, True)
     kernel_ms = tracer.kernel_times_ms(min(args.steps, 64))
-    cdev = torch.device("cpu") if args.rehearse_gloo else dev
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # device->host inclusive rate (reported beside `value`, never as it)
-    d2h_elapsed = None
+    host_ok = None
     if rank == 0:
-        host = torch.empty(H * W * 3, dtype=torch.float32).pin_memory()
-    fence()
-    t1 = time.perf_counter()
-    for _ in range(min(args.steps, 5)):
-        step()
-        if rank == 0:
-            host.copy_(frame, non_blocking=True)
-    fence()
-    d2h_elapsed = (time.perf_counter() - t1) / min(args.steps, 5)
-    if world > 1:
-        t = torch.tensor([d2h_elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        d2h_elapsed = float(t.item())
+        last = (step_no[0] - 1) % 2
+        host_ok = bool(torch.equal(hosts2[last].view(torch.int32), frames2[last].cpu().view(torch.int32)))
+    # the same loop with the frame left in HBM (reported beside `value`)
+    resident_elapsed = timed(args.steps, False)
 
     # The same K steps once more with several frames in flight (reported beside `value`, never as it): frame k on context k % F
     # and stream k % F, each context with the scene resident and queues of its own, so that one frame's latency-bound head and
     # tail (level 0's longest walks; the deeper levels' shadow rays, resolve) overlap its neighbours' busy middle -- what the
     # animation driver does (crt_animation --in-flight).  Every frame is complete inside the timed region and is compared with
     # the one-at-a-time frame afterwards.
+    if rank == 0:   # `frame` = the last timed step's tiles (whichever of the two buffers that step used)
+        tracer.unpack_tiles_device(gathered.data_ptr(), world, part_floats, frame.data_ptr(), sptr)
+        torch.cuda.synchronize(dev)
     pipelined = None
-    F = 0 if args.rehearse_gloo else max(0, args.in_flight if args.in_flight is not None else (3 if world == 1 else 0))
+    F = max(0, args.in_flight if args.in_flight is not None else 3)
     if F >= 2:
         trs = [tracer] + [pkg.Tracer(hs, device=local_rank, tuning=pkg.tuning_from_string(args.tuning)) for _ in range(F - 1)]
         strs = [torch.cuda.Stream(dev) for _ in range(F)]
         packs = [packed] + [torch.zeros_like(packed) for _ in range(F - 1)]
-        gaths = [gathered] + [(torch.zeros_like(gathered) if world > 1 else packs[i + 1]) for i in range(F - 1)]
+        gaths = [gathered] + [(torch.zeros_like(gathered) if dist_on else packs[i + 1]) for i in range(F - 1)]
         frames_f = [frame] + [torch.zeros_like(frame) for _ in range(F - 1)] if rank == 0 else [frame] * F
         reference_frame = frame.clone() if rank == 0 else None
 
@@ -254,7 +270,12 @@ def main():
             i = k % F
             with torch.cuda.stream(strs[i]):
                 trs[i].render_tiles_device(opts, rank, world, packs[i].data_ptr(), strs[i].cuda_stream)
-                if world > 1:
+                if dist_on and args.rehearse_gloo:
+                    strs[i].synchronize()
+                    parts = [torch.empty(part_floats) for _ in range(world)]
+                    dist.all_gather(parts, packs[i].cpu())
+                    gaths[i].copy_(torch.cat(parts))
+                elif dist_on:
                     dist.all_gather_into_tensor(gaths[i], packs[i])
                 if rank == 0:
                     trs[i].unpack_tiles_device(gaths[i].data_ptr(), world, part_floats, frames_f[i].data_ptr(), strs[i].cuda_stream)
@@ -293,7 +314,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         frame_ok = bool(t.item() > 0.5)
     gathered_ok = None
-    if world > 1 and rank == 0:
+    if dist_on and rank == 0:
         single = torch.zeros(n_tiles * 192, dtype=torch.float32, device=dev)
         whole = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
         tracer.render_tiles_device(opts, 0, 1, single.data_ptr(), sptr)
@@ -364,6 +385,38 @@ def main():
                          "note": "the same launch with the chip to itself (crt_tuning side_blocks=0: after the recursion levels, on their stream)"}
         except Exception as e:
             alone = {"kernel_ms": None, "note": "not measured: %r" % (e,)}
+        # The roofs nearer to this kernel than HBM, from the counters of the committed PMC passes (profiles/r03_pmc.json: per-launch
+        # counts, which do not depend on timing) over the launch duration measured LIVE above: vector-instruction issue (2 cycles
+        # per wave64 instruction on a SIMD-32), lanes per vector instruction, vector-L1 line rate; and the cycle-counter ratios of
+        # the counted launch itself (texture-address unit busy, waves waiting).
+        binding = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r03_pmc.json")) as f:
+                pj = json.load(f).get("%s_%dx%d_d%d_n%d" % (args.scene, W, H, depth, world))
+            if pj and pj["kernel"].startswith(dom.split("<")[0]):
+                c, clk = pj["per_launch"], float(pj["clock_ghz"]) * 1e9
+
+                def roofs(ms):
+                    t = ms * 1e-3
+                    return {"kernel_ms": round(ms, 4),
+                            "valu": round(c["SQ_INSTS_VALU"] * 2.0 / (N_SIMDS * clk * t), 4),
+                            "l1": round(c["TCP_TOTAL_CACHE_ACCESSES_sum"] * 64.0 / t / (N_CUS * 64.0 * clk), 4)}
+                t_pmc = float(pj["kernel_ms_in_the_clock_pass"]) * 1e-3   # rocprofv3 serialises launches while it counts: the kernel has the chip
+                binding = {"source": "profiles/r03_pmc.json (%s)" % pj["kernel"], "clock_ghz": pj["clock_ghz"],
+                           "lanes": round(c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"] / 64.0, 4),
+                           "in_frame": roofs(dom_ms), "alone": roofs(alone["kernel_ms"]) if alone and alone.get("kernel_ms") else None,
+                           "in_the_counting_pass": {"kernel_ms": round(t_pmc * 1e3, 4), "waiting": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4),
+                                                    "ta_busy": round(c["TA_TA_BUSY_sum"] / (N_CUS * clk * t_pmc), 4),
+                                                    "l1_pending_stall": round(c["TCP_PENDING_STALL_CYCLES_sum"] / (N_CUS * clk * t_pmc), 4)},
+                           "note": "valu = wave-level vector instructions x 2 cycles over 1024 SIMDs and l1 = vector-L1 cache-line accesses over "
+                                   "256 CUs x 1 line/clk: per-launch COUNTS from the committed passes over the duration measured live here.  "
+                                   "lanes = active lanes per vector instruction / 64.  in_the_counting_pass: ratios of cycle counters, valid only "
+                                   "for the launch they were counted in (serialised by the profiler, three workgroups per CU): waiting = "
+                                   "SQ_WAIT_ANY / SQ_WAVE_CYCLES, ta_busy = texture-address busy cycles over 256 CUs, l1_pending_stall = "
+                                   "TCP_PENDING_STALL_CYCLES over 256 CUs.  No unit is saturated: the kernel waits on dependent loads "
+                                   "(a walk is a chain of node -> child gathers that hit in L2 / Infinity Cache)"}
+        except Exception as e:
+            binding = {"note": "profiles/r03_pmc.json not usable: %r" % (e,)}
         out = {
             "metric": "Mpixels/s at 1920x1080 depth 8; HBM GB/s vs roofline",
             "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -374,25 +427,25 @@ def main():
                        "scene": args.scene, "width": W, "height": H, "max_depth": depth,
                        "parallelism": "tiles8x8-roundrobin-%d" % world, "tuning": args.tuning or "defaults"},
             "frame_matches_counting_build": frame_ok,
-            "autotune": tracer.kernels().get("autotune"),   # crt_tuning::autotune: what the context settled on while it rendered
-            "settle_frames": max(0, args.settle),           # untimed frames before the warm-up on which it did so
             "pipelined": pipelined,
-            "value_incl_d2h": round(W * H / d2h_elapsed / 1e6, 3),
+            "value_device_resident": round(W * H * args.steps / resident_elapsed / 1e6, 3),   # the same K steps without the copy to the host
+            "host_frame_matches_device": host_ok,
             "kernel_ms": {"first_to_last": round(avg_kernel_ms, 4), "recursion_levels": round(pk_ms, 4),
                           "shadow_pass0_overlapped": round(ln_ms, 4), "shadow_pass1_heavy_resolve": round(rs_ms, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": dom, "kernel_ms": round(dom_ms, 4), "alone": alone,
+                         "peak_measured": HBM_MEASURED_GBS, "frac_of_measured": round(achieved / HBM_MEASURED_GBS, 4),
+                         "kernel": dom, "kernel_ms": round(dom_ms, 4), "alone": alone, "binding": binding,
                          "executed_bytes_per_launch": int(b_exec_dom),
                          "executed": {"box_tests": executed["shadow_pass0_box_tests"], "tri_tests": executed["shadow_pass0_tri_tests"],
                                       "plan_tests": executed["shadow_pass0_plan_tests"]},
                          "bound_note": "nominal: SURVEY.md section 8(d) prices this path against HBM bandwidth, and `achieved` is the "
                                        "bytes of the box / triangle tests the kernel executes (32 B / 52 B each; the tests of the plan "
                                        "loop against wave-uniform top-level leaf boxes 1 B each) over its duration IN THE FRAME, where it "
-                                       "runs at the lowest priority beside the recursion levels (`alone`: with the chip to itself).  The "
-                                       "kernel's real limiter is vector-instruction issue and the vector L1's handling of divergent 16-byte "
-                                       "gathers, not HBM: the scene (a few MB) lives in L2 / Infinity Cache and `traffic` (PMC, fabric side) "
-                                       "is a small fraction of the executed bytes -- see profiles/ and DESIGN.md section 4",
+                                       "runs at the lowest priority beside the recursion levels (`alone`: with the chip to itself).  HBM does "
+                                       "not bound this kernel: the scene (a few MB) lives in L2 / Infinity Cache and `traffic` (PMC, fabric side) "
+                                       "is a small fraction of the executed bytes.  `binding` holds the roofs nearer to it (vector issue, "
+                                       "lanes, vector-L1 rate, texture-address busy, waiting) -- see profiles/ and DESIGN.md section 4",
                          "reference_work": {
                              "note": "what the REFERENCE does for the same rays (counting build == the oracle's counters).  The production "
                                      "kernel skips work that cannot change the result (one walk per mesh and ray, exact shadow early exit), "
@@ -410,6 +463,7 @@ def main():
         }
         if gathered_ok is not None:
             out["gathered_frame_matches_single_rank"] = gathered_ok
+        out["collective"] = ("gloo (rehearsal)" if args.rehearse_gloo else "rccl all_gather_into_tensor") if dist_on else None
         tracer.synchronize()
         fallback = int(tracer.stats().fallback_frames) - fallback_before
         out["fallback_frames"] = fallback                       # in the timed region (and the copy-inclusive one after it)
@@ -429,7 +483,7 @@ def main():
             print("bench.py: FAILED self-check: frame_matches_counting_build=%r gathered_frame_matches_single_rank=%r "
                   "fallback_frames=%d" % (frame_ok, gathered_ok, fallback), file=sys.stderr, flush=True)
             failed = True
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     if failed:
