@@ -89,7 +89,8 @@ class Stats(C.Structure):
                 ("tri_tests", C.c_uint64), ("leaf_index_reads", C.c_uint64), ("shaded_hits", C.c_uint64),
                 ("light_evals", C.c_uint64), ("texel_fetches", C.c_uint64), ("primary_rays", C.c_uint64),
                 ("secondary_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("pixels", C.c_uint64),
-                ("counters_valid", C.c_uint32), ("fallback_frames", C.c_uint32), ("queue_bytes", C.c_uint64)]
+                ("counters_valid", C.c_uint32), ("fallback_frames", C.c_uint32), ("queue_bytes", C.c_uint64),
+                ("queue_regrows", C.c_uint64)]
 
     def counters(self):
         return {k: int(getattr(self, k)) for k in ("box_tests", "tri_tests", "leaf_index_reads", "shaded_hits",

@@ -144,9 +144,10 @@ struct crt_ctx {
     uint32_t last_counts_items = 0;                  // ... and the work items it rendered (0: none yet)
     uint32_t fallbacks_seen = 0;                     // fallback total of that frame
     // queue sizing (ensure_stream): capacities as multiples of the frame's pixels, adapted from frame to frame
-    double node_mult = 1.3, ray_mult = 0.5, shadow_extra = 0.125;
+    double node_mult = 4.0, ray_mult = 2.0, shadow_extra = 1.0;  // (a GB at 1920x1080 with four lights: memory is not what this device lacks)
     uint32_t sizing_seen_fallbacks = 0;
     uint64_t queue_bytes = 0;         // bytes of the per-frame buffers as allocated now
+    uint64_t regrows = 0;             // attempts repeated with larger queues (launch_render)
     hipEvent_t ev_call0 = nullptr, ev_call1 = nullptr;  // around the last crt_render / crt_render_async call's device work
     bool pending = false;             // a frame enqueued by crt_render_async has not been waited for
     crt_options pending_options{};
@@ -850,17 +851,18 @@ static void harvest_counts(crt_ctx *ctx) {
 
 // Queues of the ray-stream pass.  What a frame needs depends on the scene and the camera -- a frame of diffuse surfaces
 // has no child rays at all, nested glass can reach 2^(MAX_DEPTH+1)-1 rays per pixel -- so the capacities FOLLOW the frames:
-// they start at px * {1.3 ray-tree nodes, 0.5 rays per level, n_lights * 1.125 shadow rays} (px = 64 pixels per work item),
-// grow by half when the last completed frame used more than 70 % of one of them, and double (up to px * {4, 3, n_lights * 4})
-// after a frame that overflowed.  Such a frame is not lost: its queues raise the overflow word and render_lanes, which
-// needs no queues, redoes it in the same call (crt_stats::fallback_frames counts them).
+// they start at px * {4 ray-tree nodes, 2 rays per level, n_lights * 2 shadow rays} (px = 64 pixels per work item),
+// grow by half when the last completed frame used more than 70 % of one of them, and are regrown inside the call when an attempt
+// overflows them (launch_render).  A frame that overflows queues an earlier frame had fitted is not lost either: its queues raise
+// the overflow word and render_lanes, which needs no queues, redoes it in the same call (crt_stats::fallback_frames counts
+// those; the factors double for the next frame).
 static void adapt_queue_sizing(crt_ctx *ctx) {
     const uint32_t *c = ctx->last_counts.data();
     if (ctx->fallbacks_seen != ctx->sizing_seen_fallbacks) {
         ctx->sizing_seen_fallbacks = ctx->fallbacks_seen;
-        ctx->node_mult = std::min(4.0, ctx->node_mult * 2.0);
-        ctx->ray_mult = std::min(3.0, ctx->ray_mult * 2.0);
-        ctx->shadow_extra = std::min(3.0, ctx->shadow_extra * 2.0);
+        ctx->node_mult = std::min(64.0, ctx->node_mult * 2.0);
+        ctx->ray_mult = std::min(32.0, ctx->ray_mult * 2.0);
+        ctx->shadow_extra = std::min(32.0, ctx->shadow_extra * 2.0);
         return;
     }
     const FrameArgs &A = ctx->frame;
@@ -872,10 +874,27 @@ static void adapt_queue_sizing(crt_ctx *ctx) {
     // level 0 owns one node per pixel and n_lights fixed shadow slots per pixel: what can run out is the part beyond that
     const uint64_t base_shadow = px * (ctx->n_lights ? ctx->n_lights : 1);
     const uint64_t extra_nodes = nodes > px ? nodes - px : 0, extra_shadow = shadow > base_shadow ? shadow - base_shadow : 0;
-    if (A.s_node_cap > px && extra_nodes * 10 > ((uint64_t)A.s_node_cap - px) * 7) ctx->node_mult = std::min(4.0, ctx->node_mult * 1.5);
-    if (rays * 10 > (uint64_t)A.s_ray_cap * 7) ctx->ray_mult = std::min(3.0, ctx->ray_mult * 1.5);
+    if (A.s_node_cap > px && extra_nodes * 10 > ((uint64_t)A.s_node_cap - px) * 7) ctx->node_mult = std::min(64.0, ctx->node_mult * 1.5);
+    if (rays * 10 > (uint64_t)A.s_ray_cap * 7) ctx->ray_mult = std::min(32.0, ctx->ray_mult * 1.5);
     if (A.s_shadow_cap > base_shadow && extra_shadow * 10 > ((uint64_t)A.s_shadow_cap - base_shadow) * 7)
-        ctx->shadow_extra = std::min(3.0, ctx->shadow_extra * 1.5);
+        ctx->shadow_extra = std::min(32.0, ctx->shadow_extra * 1.5);
+}
+
+static uint64_t queue_bytes_for(const crt_ctx *ctx, uint64_t px, double node_mult, double ray_mult, double shadow_extra) {
+    const uint64_t lights = ctx->n_lights ? ctx->n_lights : 1;
+    return (uint64_t)(px * ray_mult) * (64 + 24) + (uint64_t)(px * lights * (1.0 + shadow_extra)) * 33 + (uint64_t)(px * node_mult) * 32;
+}
+
+// after an attempt that overflowed (launch_render): larger factors, as long as the device has room for them
+static bool grow_queue_sizing(crt_ctx *ctx, uint32_t n_items, double by) {
+    const double node_mult = ctx->node_mult * by, ray_mult = ctx->ray_mult * by, shadow_extra = std::max(0.5, ctx->shadow_extra * by);
+    const uint64_t px = (uint64_t)n_items * 64;
+    if (px * node_mult > 2.0e9 || px * ray_mult > 2.0e9 || px * (ctx->n_lights ? ctx->n_lights : 1) * (1.0 + shadow_extra) > 2.0e9) return false;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (queue_bytes_for(ctx, px, node_mult, ray_mult, shadow_extra) > (free_b + ctx->queue_bytes) / 2) return false;
+    ctx->node_mult = node_mult; ctx->ray_mult = ray_mult; ctx->shadow_extra = shadow_extra;
+    return true;
 }
 
 static int ensure_stream(crt_ctx *ctx, uint32_t n_items) {
@@ -943,7 +962,7 @@ static void launch_lds(K kernel, uint32_t blocks, uint32_t lds_bytes, hipStream_
 //   heavy_trace_closest for the walks it handed over (or the whole level), stream_shade_evicted for their hits;
 // the bulk shadow pass (level 0's shadow rays) on the side stream as soon as level 0 is done, then the deeper levels'
 // shadow rays, the wave-per-ray shadow walks, stream_resolve, and render_lanes, which only runs after a queue overflow.
-static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, float *d_out, uint32_t packed, hipStream_t stream) {
+static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, float *d_out, uint32_t packed, hipStream_t stream, bool last_resort) {
     const bool gi = o->use_gi != 0;  // the GI / multi-sample mode: rendered pixel by pixel by render_lanes<.., true> (kernel_lane.h)
     int rc = ensure_frames(ctx, o->max_depth, gi);
     if (rc) return rc;
@@ -1043,7 +1062,8 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         const uint64_t est0 = (uint64_t)n_items * 64u * 70u / ((uint64_t)lane_blocks * BLOCK);
         uint32_t budget0 = est0 >= ctx->step_budget ? ctx->step_budget : (est0 < 64u ? 64u : (uint32_t)est0);
         if (ctx->tuning.level0_budget) budget0 = ctx->tuning.level0_budget;
-        const uint32_t *prev = ctx->last_counts_items == n_items ? ctx->last_counts.data() : nullptr;  // a completed frame of this size
+        // a completed frame of this size (one that overflowed stopped early: its levels' counts say nothing)
+        const uint32_t *prev = ctx->last_counts_items == n_items && !ctx->last_counts[SC_OVERFLOW] ? ctx->last_counts.data() : nullptr;
         for (uint32_t g = 0; g <= o->max_depth; g++) {
             A.step_budget = heavy ? (g == 0 ? budget0 : ctx->step_budget) : 0u;
             // The per-lane kernel of a deeper level fetches its rays through a cursor, so any grid does the whole level; beside
@@ -1109,7 +1129,8 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         if (count) launch(stream_resolve<true>, lane_blocks, stream, A);
         else launch(stream_resolve<false>, lane_blocks, stream, A);
         A.only_if_overflow = 1;
-        if (count) launch(render_lanes<true>, lane_blocks, stream, A);
+        if (!last_resort) {}  // a probing attempt (launch_render): the host looks at the overflow word itself
+        else if (count) launch(render_lanes<true>, lane_blocks, stream, A);
         else launch(render_lanes<false>, lane_blocks, stream, A);
         CRT_HIP_CHECK(ctx, hipGetLastError());
     } else {
@@ -1133,12 +1154,40 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
     return CRT_OK;
 }
 
+// A frame whose queues are not yet known to fit -- the first of its size on this context, or the one after a frame that
+// overflowed -- is PROBED: the stream pass is enqueued without the queue-less fallback behind it, the call waits for it and
+// reads its overflow word, and an attempt that did not fit is repeated with four times the queues until it
+// does; every attempt ends early at the first overflow, so a failed one costs less than a frame.  Once a frame of this size has
+// completed without overflow the call is asynchronous again, with render_lanes behind the stream pass as the last resort for a
+// frame that outgrows its queues all the same (and for explicit capacities, crt_tuning, which are never regrown).
+static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, float *d_out, uint32_t packed, hipStream_t stream) {
+    const bool stream_mode = ctx->mode == crt_ctx::MODE_STREAM && !o->use_gi;
+    const bool fixed_caps = ctx->tuning.node_cap || ctx->tuning.ray_cap || ctx->tuning.shadow_cap;
+    harvest_counts(ctx);
+    const bool proven = ctx->last_counts_items == n_items && ctx->last_counts[SC_OVERFLOW] == 0;
+    if (!stream_mode || fixed_caps || proven || n_items == 0) return launch_frame(ctx, o, n_items, d_out, packed, stream, true);
+    for (int attempt = 0;; attempt++) {
+        const bool last = attempt == 5;
+        const int slot = (int)(ctx->launches % crt_ctx::EV_RING);
+        const int rc = launch_frame(ctx, o, n_items, d_out, packed, stream, last);
+        if (rc || last) return rc;
+        CRT_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev4[slot]));
+        harvest_counts(ctx);
+        if (ctx->last_counts_items != n_items) { ctx->error = "internal: a probing frame left no counters"; return CRT_ERR_HIP; }
+        if (!ctx->last_counts[SC_OVERFLOW]) return CRT_OK;
+        ctx->regrows++;
+        const bool can_grow = !ctx->last_counts[SC_GUARD] && grow_queue_sizing(ctx, n_items, 4.0);
+        if (!can_grow) return launch_frame(ctx, o, n_items, d_out, packed, stream, true);  // (a walk beyond its bound, or no memory to grow into)
+    }
+}
+
 // Called after a synchronisation: the last frame's slot tells whether the frame was redone by the queue-less kernel.
 static void note_overflow(crt_ctx *ctx) {
     harvest_counts(ctx);
     ctx->overflows = ctx->fallbacks_seen;
     ctx->stats.fallback_frames = (uint32_t)ctx->overflows;
     ctx->stats.queue_bytes = ctx->queue_bytes;
+    ctx->stats.queue_regrows = ctx->regrows;
 }
 
 static int fetch_counters(crt_ctx *ctx, const crt_options *o, uint64_t pixels) {
@@ -1723,6 +1772,7 @@ extern "C" int crt_multi_render(crt_multi *M, const crt_options *o, const crt_re
         total.primary_rays += c->stats.primary_rays; total.secondary_rays += c->stats.secondary_rays; total.shadow_rays += c->stats.shadow_rays;
         total.fallback_frames += c->stats.fallback_frames;
         total.queue_bytes += c->stats.queue_bytes;
+        total.queue_regrows += c->stats.queue_regrows;
     }
     total.pixels = M->pixels;
     total.total_ms = wall_ms;

@@ -163,10 +163,13 @@ typedef struct crt_stats {
     uint64_t pixels;           /* pixels rendered by the last call */
     uint32_t counters_valid;   /* 1 when the last render ran with collect_counters */
     uint32_t fallback_frames;  /* frames since crt_create whose ray queues overflowed and that were redone by the
-                                * queue-less kernel (same pixels, much slower): raise crt_tuning's *_cap if this grows.
+                                * queue-less kernel (same pixels, much slower): the last resort, for a frame that outgrows
+                                * queues an earlier frame of its size had fitted, and for explicit crt_tuning capacities.
                                 * Updated by the synchronous calls (crt_render, crt_kernel_times_ms, crt_synchronize). */
     uint64_t queue_bytes;      /* device memory of the per-frame ray queues as allocated now (they follow the frames: they
-                                * grow when a frame came close to a capacity, and double after one that overflowed) */
+                                * grow when a frame came close to a capacity, and after an attempt that overflowed) */
+    uint64_t queue_regrows;    /* attempts since crt_create that overflowed their queues and were repeated, inside the same
+                                * call, with larger ones (a context's first frame of a size is probed this way) */
 } crt_stats;
 
 typedef struct crt_ctx crt_ctx;
