@@ -516,7 +516,6 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
         for (uint32_t i = 0; i < s->n_nodes; i++)
             if (is_top[i]) { lo = i < lo ? i : lo; hi = i > hi ? i : hi; cnt++; }
         A.top_fast = (cnt > 0 && hi - lo + 1 == cnt && cnt <= 64u && s->n_leaf_meshes <= 128u && s->n_meshes <= 64u) ? 1u : 0u;
-        A.top_lds = (cnt > 0 && hi - lo + 1 == cnt && cnt <= 256u && s->n_leaf_meshes <= 1024u && s->n_meshes <= 256u) ? 1u : 0u;
         A.top_first = cnt ? lo : 0u;
         A.top_count = cnt;
         A.top_leaf_entries = s->n_leaf_meshes;
@@ -665,40 +664,55 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
         for (uint32_t m = 0; m < s->n_meshes; m++)
             if (!(s->meshes[m].flags & 1u)) order.push_back(m);
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hmesh_host[a].count[0] > hmesh_host[b].count[0]; });
-        std::vector<uint32_t> bit_of(s->n_meshes, 64u);
-        for (size_t b = 0; b < order.size() && b < 64; b++) bit_of[order[b]] = (uint32_t)b;
+        constexpr uint32_t MAX_BITS = 256;  // shadow mask bits of the wide plan (kernel_plan.h: 8 words); the plan proper uses the first 64
+        std::vector<uint32_t> bit_of(s->n_meshes, MAX_BITS);
+        for (size_t b = 0; b < order.size() && b < MAX_BITS; b++) bit_of[order[b]] = (uint32_t)b;
         const bool contiguous = A.top_count > 0 && A.nested_boxes;  // (top_first / top_count: the top-level nodes are one index range)
         uint32_t n_leaves = 0;
+        std::vector<float4> groups;
         for (uint32_t i = A.top_first; contiguous && i < A.top_first + A.top_count; i++) {
             const crt_node &n = s->nodes[i];
             if (!is_leaf_link(n.link)) continue;
             const uint32_t begin = n.link & ~CRT_LINK_LEAF;
             uint32_t count = 0;
-            unsigned long long mask = 0;
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (uint32_t e = begin; e < s->n_leaf_meshes; e++) {
                 const uint32_t mi = s->leaf_meshes[e] & ~CRT_ENTRY_LAST;
-                if (bit_of[mi] < 64u) mask |= 1ull << bit_of[mi];
+                if (bit_of[mi] < MAX_BITS) mask[bit_of[mi] >> 5] |= 1u << (bit_of[mi] & 31u);
                 count++;
                 if (s->leaf_meshes[e] & CRT_ENTRY_LAST) break;
             }
-            float bb, cb;
+            float bb, cb, mf[8];
             memcpy(&bb, &begin, 4);
             memcpy(&cb, &count, 4);
-            float ml, mh;
-            const uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
-            memcpy(&ml, &mlo, 4);
-            memcpy(&mh, &mhi, 4);
+            memcpy(mf, mask, sizeof(mf));
             boxes.push_back(make_float4(n.lo[0], n.lo[1], n.lo[2], bb));  // PLAN_LEAF_DWORDS = 16 per leaf (kernel_plan.h)
             boxes.push_back(make_float4(n.hi[0], n.hi[1], n.hi[2], cb));
-            boxes.push_back(make_float4(ml, mh, 0.0f, 0.0f));
-            boxes.push_back(make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+            boxes.push_back(make_float4(mf[0], mf[1], mf[2], mf[3]));
+            boxes.push_back(make_float4(mf[4], mf[5], mf[6], mf[7]));
+            // the wide plan's groups: PLAN_GROUP_LEAVES consecutive leaves under their union box
+            if (n_leaves % PLAN_GROUP_LEAVES == 0) {
+                float first_leaf, zero = 0.0f;
+                memcpy(&first_leaf, &n_leaves, 4);
+                groups.push_back(make_float4(n.lo[0], n.lo[1], n.lo[2], first_leaf));
+                groups.push_back(make_float4(n.hi[0], n.hi[1], n.hi[2], zero));
+            }
+            float4 &glo = groups[groups.size() - 2], &ghi = groups[groups.size() - 1];
+            glo.x = std::min(glo.x, n.lo[0]); glo.y = std::min(glo.y, n.lo[1]); glo.z = std::min(glo.z, n.lo[2]);
+            ghi.x = std::max(ghi.x, n.hi[0]); ghi.y = std::max(ghi.y, n.hi[1]); ghi.z = std::max(ghi.z, n.hi[2]);
+            const uint32_t in_group = n_leaves % PLAN_GROUP_LEAVES + 1u;
+            memcpy(&ghi.w, &in_group, 4);
             n_leaves++;
         }
-        // the per-lane plan kernels keep a ray's leaves and meshes in two 64-bit words
+        // the per-lane plan kernels keep a ray's meshes in two 32-bit words (the plan proper) or eight (the wide plan)
         A.plan_ok = (contiguous && A.top_fast && n_leaves <= 64u && s->n_meshes <= 64u && A.plan_compact) ? 1u : 0u;
+        A.plan_wide = (!A.plan_ok && contiguous && n_leaves > 0 && s->n_meshes <= MAX_BITS && A.plan_compact) ? 1u : 0u;
         A.plan_leaves = n_leaves;
-        A.plan_shadow_bits = (uint32_t)std::min<size_t>(order.size(), 64);
-        A.plan_list_words = (s->n_meshes + 3u) / 4u;
+        A.plan_seq = (contiguous && n_leaves > 0) ? 1u : 0u;  // the wave-per-ray kernels walk the leaf sequence (kernel_heavy.h)
+        A.plan_group_count = (uint32_t)(groups.size() / 2);
+        A.plan_shadow_bits = (uint32_t)std::min<size_t>(order.size(), A.plan_ok ? 64u : MAX_BITS);
+        A.plan_list_words = std::min((s->n_meshes + 3u) / 4u, 32u);
+        if (upload(ctx, groups.data(), groups.size(), &A.plan_groups)) return fail(CRT_ERR_HIP);
         if (upload(ctx, boxes.data(), boxes.size(), &A.plan_boxes)) return fail(CRT_ERR_HIP);
         if (upload(ctx, order.data(), order.size(), &A.plan_shadow_mesh)) return fail(CRT_ERR_HIP);
     }
@@ -1012,9 +1026,10 @@ static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, fl
         return CRT_OK;
     }
     // the wave-per-ray path needs nested boxes; the counting build walks every ray the reference's way
-    const bool heavy = stream_mode && ctx->step_budget && SC.nested_boxes && !count;
+    const bool heavy = stream_mode && ctx->step_budget && SC.nested_boxes && (SC.top_fast || SC.plan_seq) && !count;
     // the plan kernels (kernel_plan.h): a small top-level tree (its leaves as a plan), 32-bit offsets, compact leaf links
-    const bool lean = heavy && ctx->lean_ok && SC.plan_ok;
+    const bool lean = heavy && ctx->lean_ok && (SC.plan_ok || SC.plan_wide);
+    const bool wide = lean && !SC.plan_ok;  // the wide plan (kernel_plan.h): more than 64 top-level leaves or meshes
     if (stream_mode) {
         rc = ensure_stream(ctx, n_items);
         if (rc) return rc;
@@ -1058,14 +1073,17 @@ static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, fl
             if (budget < ctx->step_budget) budget = std::min(ctx->step_budget, ctx->tuning.shadow_budget);
             S.step_budget = heavy ? budget : 0u;
         }
-        // the same reasoning for level 0 (one launch over all primary rays, ~70 steps per ray)
-        const uint64_t est0 = (uint64_t)n_items * 64u * 70u / ((uint64_t)lane_blocks * BLOCK);
-        uint32_t budget0 = est0 >= ctx->step_budget ? ctx->step_budget : (est0 < 64u ? 64u : (uint32_t)est0);
-        if (ctx->tuning.level0_budget) budget0 = ctx->tuning.level0_budget;
         // a completed frame of this size (one that overflowed stopped early: its levels' counts say nothing)
         const uint32_t *prev = ctx->last_counts_items == n_items && !ctx->last_counts[SC_OVERFLOW] ? ctx->last_counts.data() : nullptr;
+        // (under the wide plan a ray crosses dozens of small mesh trees: a walk of a thousand steps is the rule there, not the outlier the
+        //  wave-per-ray kernel is for -- measured on tools/many_meshes.py 200: 32.7 ms per frame with the plain budget, 25.4 with four times it)
+        const uint32_t level_budget = wide ? std::min<uint32_t>(ctx->step_budget * 4u, 1u << 20) : ctx->step_budget;
+        // the same reasoning for level 0 (one launch over all primary rays, ~70 steps per ray)
+        const uint64_t est0 = (uint64_t)n_items * 64u * 70u / ((uint64_t)lane_blocks * BLOCK);
+        uint32_t budget0 = est0 >= level_budget ? level_budget : (est0 < 64u ? 64u : (uint32_t)est0);
+        if (ctx->tuning.level0_budget) budget0 = ctx->tuning.level0_budget;
         for (uint32_t g = 0; g <= o->max_depth; g++) {
-            A.step_budget = heavy ? (g == 0 ? budget0 : ctx->step_budget) : 0u;
+            A.step_budget = heavy ? (g == 0 ? budget0 : level_budget) : 0u;
             // The per-lane kernel of a deeper level fetches its rays through a cursor, so any grid does the whole level; beside
             // the bulk shadow pass every workgroup of it waits for a free slot, and a level below heavy_level_threshold has
             // nothing for it to do (measured: 0.15 ms for an empty full-size grid).  Sized by what the level held a frame ago.
@@ -1076,6 +1094,7 @@ static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, fl
                 level_blocks = std::min(lane_blocks, want);
             }
             if (count) launch(stream_trace_shade<true>, lane_blocks, stream, A, g);
+            else if (wide) launch_lds(stream_trace_shade_plan_wide, level_blocks, plds, stream, A, g);
             else if (lean) launch_lds(stream_trace_shade_plan, level_blocks, plds, stream, A, g);
             else launch(stream_trace_shade<false>, lane_blocks, stream, A, g);
             if (heavy) {
@@ -1094,6 +1113,7 @@ static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, fl
                 // (beside the levels its persistent waves must leave wave slots on every CU for the level kernels)
                 const uint32_t blocks0 = side_per_cu ? (uint32_t)ctx->num_cus * side_per_cu : ctx->grid_blocks;
                 if (count) launch(stream_trace_shadow<true>, blocks0, where, S, 0u);
+                else if (wide) launch(stream_trace_shadow_plan_wide<0>, blocks0, where, S);
                 else if (lean) launch(stream_trace_shadow_plan<0>, blocks0, where, S);
                 else launch(stream_trace_shadow<false>, blocks0, where, S, 0u);
                 // ... and behind it the walks it gave up, still beside the levels; the mark comes before the event the
@@ -1114,10 +1134,12 @@ static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, fl
         {
             // few rays, all tail: the short budget of the levels, or less when this launch is small (the deeper levels
             // queue about a quarter of a shadow ray per pixel on the benchmark scenes)
-            const uint64_t est1 = (uint64_t)n_items * 16u * 130u / ((uint64_t)lane_blocks * BLOCK);
-            S1.step_budget = heavy ? (est1 >= ctx->step_budget ? ctx->step_budget : (est1 < 64u ? 64u : (uint32_t)est1)) : 0u;
+            const uint64_t rays1 = prev && prev[SC_SHADOW] >= prev[SC_SHADOW_SPLIT] ? prev[SC_SHADOW] - prev[SC_SHADOW_SPLIT] : (uint64_t)n_items * 16u;
+            const uint64_t est1 = rays1 * 130u / ((uint64_t)lane_blocks * BLOCK);
+            S1.step_budget = heavy ? (est1 >= level_budget ? level_budget : (est1 < 64u ? 64u : (uint32_t)est1)) : 0u;
         }
         if (count) launch(stream_trace_shadow<true>, lane_blocks, stream, S1, 1u);
+        else if (wide) launch(stream_trace_shadow_plan_wide<1>, lane_blocks, stream, S1);
         else if (lean) launch(stream_trace_shadow_plan<1>, lane_blocks, stream, S1);
         else launch(stream_trace_shadow<false>, lane_blocks, stream, S1, 1u);
         if (side_per_cu) CRT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_s2[slot], 0));
@@ -1492,10 +1514,11 @@ extern "C" int crt_describe_kernels(const crt_ctx *ctx, char *out, size_t size) 
     std::string d;
     if (ctx->mode == crt_ctx::MODE_LANES) d = "all=render_lanes<false>";
     else {
-        const bool heavy = ctx->step_budget && A.nested_boxes;
-        const bool lean = heavy && ctx->lean_ok && A.plan_ok;
-        d = std::string("level0=") + (!lean ? "stream_trace_shade<false>" : "stream_trace_shade_plan");
-        d += std::string(";shadow0=") + (!lean ? "stream_trace_shadow<false>" : "stream_trace_shadow_plan<0u>");
+        const bool heavy = ctx->step_budget && A.nested_boxes && (A.top_fast || A.plan_seq);
+        const bool lean = heavy && ctx->lean_ok && (A.plan_ok || A.plan_wide);
+        const bool wide = lean && !A.plan_ok;
+        d = std::string("level0=") + (!lean ? "stream_trace_shade<false>" : wide ? "stream_trace_shade_plan_wide" : "stream_trace_shade_plan");
+        d += std::string(";shadow0=") + (!lean ? "stream_trace_shadow<false>" : wide ? "stream_trace_shadow_plan_wide<0u>" : "stream_trace_shadow_plan<0u>");
         d += std::string(";levels=") + (!heavy ? "stream_trace_shade<false>" : "heavy_trace_closest");
     }
     snprintf(out, size, "%s", d.c_str());

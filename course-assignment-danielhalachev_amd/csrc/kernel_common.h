@@ -76,7 +76,7 @@ struct SceneArgs {
     // the top-level tree held in registers by the wave-per-ray kernels (kernel_heavy.h: TopRegs) when it is small:
     // its nodes are [top_first, top_first + top_count), top_count <= 64, leaf_meshes has <= 128 entries and there are <= 64 meshes
     uint32_t top_fast, top_first, top_count, top_leaf_entries, top_meshes;
-    uint32_t top_lds;             // the top-level tree fits the wave-per-ray kernels' LDS copy (kernel_walk.h: TopLds): <= 256 nodes, 1024 entries, 256 meshes
+    uint32_t plan_seq;            // plan_boxes holds the top-level tree's leaf sequence (any number of leaves): kernel_heavy.h walks it 64 leaves per instruction
     const uint32_t *tiny_at, *tiny_flags;
     uint32_t tiny_count;
     // The top-level tree as a PLAN for the per-lane kernels (kernel_plan.h), built by crt_create when the tree is small
@@ -84,16 +84,19 @@ struct SceneArgs {
     // own box passes (nesting + monotone slab test, as for the mesh trees), so a wave tests its rays against leaf k with k
     // uniform -- boxes in scalar registers, no gathers, no divergence -- instead of walking ~40 nodes and ~75 entries per lane.
     uint32_t plan_ok;             // the plan kernels may be used
-    uint32_t plan_leaves;         // number of top-level leaves, <= 64
-    const float4 *plan_boxes;     // 4 x float4 per leaf: {lo, first entry in leaf_meshes} {hi, number of entries} {shadow mask lo, hi, -, -} {-}
+    uint32_t plan_leaves;         // number of top-level leaves (plan_ok: <= 64)
+    const float4 *plan_boxes;     // 4 x float4 per leaf: {lo, first entry in leaf_meshes} {hi, number of entries} {shadow mask words 0..3} {words 4..7}
+    const float4 *plan_groups;    // the wide plan: 2 x float4 per group of 16 consecutive leaves: {union lo, first leaf} {union hi, leaves}
+    uint32_t plan_group_count;
+    uint32_t plan_wide;           // the wide plan kernels may be used (more than 64 leaves or meshes, at most 256 meshes); plan_ok is then 0
     const uint32_t *plan_shadow_mesh;  // shadow order: bit b = mesh plan_shadow_mesh[b] (big meshes first: likeliest occluders)
-    uint32_t plan_shadow_bits;    // number of non-refractive meshes, <= 64
+    uint32_t plan_shadow_bits;    // number of non-refractive meshes with a bit in the shadow masks (<= 64; wide plan <= 256)
     // compact forms (crt_create): 3 x float4 per leaf entry {v0,nx} {v1,ny} {v2,nz}; the nodes again with leaf links
     // LEAF | (entries - 1) << 24 | first entry
     uint32_t plan_compact;
     const float4 *ptris;
     const float4 *pnodes;
-    uint32_t plan_list_words;     // LDS words per lane of a closest-hit ray's mesh list: ceil(meshes / 4)
+    uint32_t plan_list_words;     // LDS words per lane of a closest-hit ray's mesh list: ceil(meshes / 4), at most 32 (wide plan: a longer list sends the ray to heavy_trace_closest)
 };
 
 struct FrameArgs {

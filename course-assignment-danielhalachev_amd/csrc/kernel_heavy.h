@@ -281,15 +281,16 @@ __device__ __forceinline__ TopRegs heavy_top_load(const KernelArgs &A, const uin
 }
 
 // The two-level walk for one ray per wave.  SHADOW: AccelerationStructure.cpp:56-94, else KDTree.cpp:127-167.
-// `TL`: the workgroup's LDS copy of a top-level tree that is too large for the registers (kernel_walk.h: TopLds), or null.
+// The top-level tree comes in one of two forms: in registers (TopRegs, <= 64 nodes), or as its LEAF SEQUENCE (SceneArgs::plan_boxes,
+// any size: the leaves in visit order, 64 boxes per instruction -- the argument at the top of this file holds for the top-level
+// tree as it does for a mesh's).  (A tree with neither form -- its nodes not one index range -- keeps its rays in the per-lane kernels.)
 template <bool SHADOW>
-__device__ __forceinline__ void heavy_walk(const KernelArgs &A, const TopRegs &TR, const Ray &R, const bool primary, const float light_dist,
+__device__ __forceinline__ void heavy_walk(const KernelArgs &A, TopRegs &TR, const Ray &R, const bool primary, const float light_dist,
                                            bool &have, float &bt, uint32_t &btri, uint32_t &bmesh, bool &occluded,
-                                           const uint32_t lane, const TopLds *TL = nullptr) {
+                                           const uint32_t lane) {
     have = false;
     occluded = false;
     float tmin = INFINITY;
-    uint32_t ti = A.s->top_root;
     SeenMeshes seen;
     seen_clear(seen);
     HeavyState H;
@@ -300,69 +301,95 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, const TopRegs &T
     TinyResults T;
     heavy_tiny_meshes<SHADOW>(A, R, primary, T, H, lane);
     const bool fast = A.s->top_fast != 0;
-    // all top-level boxes against this ray at once (the same test, node by node, as the loop below would make)
-    const unsigned long long top_hits = fast ? __ballot(lane < A.s->top_count && slab_test(R, TR.q0.x, TR.q0.y, TR.q0.z, TR.q1.x, TR.q1.y, TR.q1.z)) : 0ull;
-    while (ti != END && H.go()) {  // the top-level tree is tiny: walked node by node, uniformly
-        H.guard--;
-        uint32_t miss, link;
-        bool hit;
-        if (fast) {
-            const int i = (int)(ti - A.s->top_first);
-            miss = lane_value(__float_as_uint(TR.q0.w), i);
-            link = lane_value(__float_as_uint(TR.q1.w), i);
-            hit = ((top_hits >> i) & 1ull) != 0;
-        } else if (TL && TL->fast) {  // (every lane reads the same words: a broadcast, no bank conflicts)
-            const lds_v4f a = TL->nodes[2 * (ti - TL->first)], b = TL->nodes[2 * (ti - TL->first) + 1];
-            miss = __builtin_amdgcn_readfirstlane(__float_as_uint(a[3])); link = __builtin_amdgcn_readfirstlane(__float_as_uint(b[3]));
-            hit = __builtin_amdgcn_readfirstlane(slab_test(R, a[0], a[1], a[2], b[0], b[1], b[2]) ? 1 : 0) != 0;
+    // one mesh of a top-level leaf's list, in list order; false: the walk is over (a shadow ray found its occluder)
+    auto visit_mesh = [&](const uint32_t mi, const uint32_t mflags, const uint32_t mpad) -> bool {
+        if ((SHADOW && (mflags & 1u)) || mesh_walk_is_repeat(seen, mi)) return true;  // (kernel_common.h: every mesh once per ray)
+        if (mpad) {  // a single-leaf mesh: its result has been waiting in lane pad - 1 since the start of the ray
+            const int k = (int)mpad - 1;
+            H.mhave = __builtin_amdgcn_readlane((int)T.have, k) != 0;
+            H.mt = lane_value(T.mt, k);
+            H.mtri = lane_value(T.mtri, k);
+            H.mmin = lane_value(T.mmin, k);
         } else {
-            const float4 q0 = A.s->nodes[2 * (size_t)ti], q1 = A.s->nodes[2 * (size_t)ti + 1];
-            miss = __float_as_uint(q0.w); link = __float_as_uint(q1.w);
-            hit = slab_test(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
+            if (A.exec_count) H.n_meshes++;
+            heavy_mesh<SHADOW>(A, R, primary, mi, H, lane);
         }
-        H.nbox++;
-        if (!hit) { ti = miss; continue; }
-        if (!is_leaf_link(link)) { ti = link; continue; }
-        uint32_t e = link & ~LEAF;
-        for (;;) {
-            const uint32_t ent = fast ? (e < 64u ? lane_value(TR.entry, (int)e) : lane_value(TR.entry2, (int)(e - 64u)))
-                                      : ((TL && TL->fast) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)TL->entries[e]) : A.s->leaf_meshes[e]);
+        if (SHADOW && H.stop) { occluded = true; return false; }
+        if (H.mhave) {
+            if (SHADOW) {
+                const float px = R.ox + R.dx * H.mt, py = R.oy + R.dy * H.mt, pz = R.oz + R.dz * H.mt;
+                if (len3(px - R.ox, py - R.oy, pz - R.oz) <= light_dist) occluded = true;
+            } else {
+                if (!have) { have = true; bt = H.mt; btri = H.mtri; bmesh = mi; }
+                if (H.mt < tmin) { tmin = H.mt; bt = H.mt; btri = H.mtri; bmesh = mi; }
+            }
+        }
+        return true;
+    };
+    // The meshes of the top-level leaves the ray reaches, one per call, in the reference's order (all state wave-uniform but the
+    // registers of TR, which in the leaf-sequence form hold the current 64 leaves and the current 64 list entries).
+    uint32_t ti = A.s->top_root, next_ti = END;          // registers form: node, and the node after the current leaf
+    uint32_t e = NONE;                                    // both forms: next entry of the current leaf's list (NONE: not in a leaf)
+    uint32_t chunk = 0, left = 0, bi = 0, bn = 0;         // leaf-sequence form: next chunk, entries left in the list, batch cursor / size
+    unsigned long long leaves = 0;                        // ... leaves of the current chunk that pass and are still to visit
+    const unsigned long long top_hits = fast ? __ballot(lane < A.s->top_count && slab_test(R, TR.q0.x, TR.q0.y, TR.q0.z, TR.q1.x, TR.q1.y, TR.q1.z)) : 0ull;
+    auto next_mesh = [&](uint32_t &mi, uint32_t &mflags, uint32_t &mpad) -> bool {
+        if (fast) {
+            if (e == NONE) {
+                while (ti != END && H.go()) {  // node by node, uniformly; every box was tested above, in one instruction
+                    H.guard--;
+                    const int i = (int)(ti - A.s->top_first);
+                    const uint32_t miss = lane_value(__float_as_uint(TR.q0.w), i), link = lane_value(__float_as_uint(TR.q1.w), i);
+                    H.nbox++;
+                    if (!((top_hits >> i) & 1ull)) { ti = miss; continue; }
+                    if (!is_leaf_link(link)) { ti = link; continue; }
+                    e = link & ~LEAF; next_ti = miss;
+                    break;
+                }
+                if (e == NONE) return false;
+            }
+            const uint32_t ent = e < 64u ? lane_value(TR.entry, (int)e) : lane_value(TR.entry2, (int)(e - 64u));
             e++;
-            const uint32_t mi = ent & ~LAST;
-            crt_mesh m;
-            if (fast) { m.flags = lane_value(TR.mflags, (int)mi); m.pad = lane_value(TR.mpad, (int)mi); m.root = 0; m.material = 0; }
-            else if (TL && TL->fast) {
-                const lds_v4u v = TL->meshes[mi];  // {flags, tree root, -, pad}
-                m.flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[0]); m.pad = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[3]);
-                m.root = 0; m.material = 0;
-            }
-            else m = A.s->meshes[mi];
-            if (!(SHADOW && (m.flags & 1u)) && !mesh_walk_is_repeat(seen, mi)) {  // (kernel_common.h: every mesh once per ray)
-                if (m.pad) {  // a single-leaf mesh: its result has been waiting in lane pad - 1 since the start of the ray
-                    const int k = (int)m.pad - 1;
-                    H.mhave = __builtin_amdgcn_readlane((int)T.have, k) != 0;
-                    H.mt = lane_value(T.mt, k);
-                    H.mtri = lane_value(T.mtri, k);
-                    H.mmin = lane_value(T.mmin, k);
-                } else {
-                    if (A.exec_count) H.n_meshes++;
-                    heavy_mesh<SHADOW>(A, R, primary, mi, H, lane);
-                }
-                if (SHADOW && H.stop) { occluded = true; break; }
-                if (H.mhave) {
-                    if (SHADOW) {
-                        const float px = R.ox + R.dx * H.mt, py = R.oy + R.dy * H.mt, pz = R.oz + R.dz * H.mt;
-                        if (len3(px - R.ox, py - R.oy, pz - R.oz) <= light_dist) occluded = true;
-                    } else {
-                        if (!have) { have = true; bt = H.mt; btri = H.mtri; bmesh = mi; }
-                        if (H.mt < tmin) { tmin = H.mt; bt = H.mt; btri = H.mtri; bmesh = mi; }
-                    }
-                }
-            }
-            if ((ent & LAST) || !H.go()) break;
-            H.guard--;
+            if (ent & LAST) { e = NONE; ti = next_ti; }
+            mi = ent & ~LAST;
+            mflags = lane_value(TR.mflags, (int)mi); mpad = lane_value(TR.mpad, (int)mi);
+            return true;
         }
-        ti = miss;
+        for (;;) {
+            if (!H.go()) return false;
+            H.guard--;
+            if (bi < bn) {
+                mi = lane_value(TR.entry, (int)bi); mflags = lane_value(TR.mflags, (int)bi); mpad = lane_value(TR.mpad, (int)bi);
+                bi++;
+                return true;
+            }
+            if (left) {  // the next (up to) 64 entries of the list: lane j reads entry j and its mesh record
+                bn = left < 64u ? left : 64u;
+                TR.entry = lane < bn ? A.s->leaf_meshes[e + lane] & ~LAST : 0u;
+                const crt_mesh mm = A.s->meshes[TR.entry];  // (lanes >= bn: mesh 0, not used)
+                TR.mflags = mm.flags; TR.mpad = mm.pad;
+                bi = 0; e += bn; left -= bn;
+                continue;
+            }
+            if (leaves) {
+                const int j = __ffsll((long long)leaves) - 1;
+                leaves &= leaves - 1;
+                e = lane_value(__float_as_uint(TR.q0.w), j); left = lane_value(__float_as_uint(TR.q1.w), j);
+                continue;
+            }
+            if (chunk * 64u >= A.s->plan_leaves) return false;
+            const uint32_t k = chunk * 64u + lane;  // lane j tests leaf 64 c + j: {lo, first entry} {hi, entries}
+            const bool valid = k < A.s->plan_leaves;
+            const float4 *L = reinterpret_cast<const float4 *>(A.s->plan_boxes) + 4 * (size_t)(valid ? k : 0u);
+            TR.q0 = L[0]; TR.q1 = L[1];
+            H.nbox += (uint32_t)__popcll(__ballot(valid));
+            leaves = __ballot(valid && slab_test(R, TR.q0.x, TR.q0.y, TR.q0.z, TR.q1.x, TR.q1.y, TR.q1.z));
+            chunk++;
+        }
+    };
+    for (;;) {
+        uint32_t mi, mflags, mpad;
+        if (!next_mesh(mi, mflags, mpad) || !visit_mesh(mi, mflags, mpad) || !H.go()) break;
     }
     if (!H.guard && lane == 0) { A.f->s_counts[SC_GUARD] = 1; A.f->s_counts[SC_OVERFLOW] = 1; }  // bound hit: let the fallback redo the frame
     if (A.exec_count && lane == 0) {
@@ -378,10 +405,6 @@ __device__ __forceinline__ float uniform_f(float v) { return __uint_as_float(__b
 // closest hits of the rays evicted from stream_trace_shade(gen); results go to s_hits[k] for list entry k
 __global__ __launch_bounds__(BLOCK, 5) void heavy_trace_closest(const KernelArgs A, const uint32_t gen) {
     if (A.wave_prio) __builtin_amdgcn_s_setprio(3);  // ahead of the bulk shadow pass's waves on this SIMD
-    __shared__ TopLdsStorage top_storage;  // used when the top-level tree is too large for the registers and small enough for this
-    TopLds TL;
-    TL.fast = false;
-    if (!A.s->top_fast && A.s->top_lds) TL = top_lds_load(A, top_storage);  // (a barrier inside: before any return; the condition is uniform)
     const uint32_t lane = threadIdx.x & 63u;
     if (A.f->s_counts[SC_OVERFLOW]) return;
     const uint32_t count = stream_level_count(A, gen);
@@ -396,7 +419,7 @@ __global__ __launch_bounds__(BLOCK, 5) void heavy_trace_closest(const KernelArgs
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
     const uint32_t n_waves = gridDim.x * (BLOCK / 64);
     if (wave >= total) return;
-    const TopRegs TR = heavy_top_load(A, lane);
+    TopRegs TR = heavy_top_load(A, lane);
     for (uint32_t k = wave; k < total; k += n_waves) {  // one evicted ray per wave and trip
         const uint32_t r = whole ? k : A.f->s_heavy[k];
         Ray R;
@@ -419,7 +442,7 @@ __global__ __launch_bounds__(BLOCK, 5) void heavy_trace_closest(const KernelArgs
         bool have = false, occluded = false;
         float bt = 0;
         uint32_t btri = 0, bmesh = 0;
-        heavy_walk<false>(A, TR, R, primary, 0.0f, have, bt, btri, bmesh, occluded, lane, &TL);
+        heavy_walk<false>(A, TR, R, primary, 0.0f, have, bt, btri, bmesh, occluded, lane);
         if (lane == 0) A.f->s_hits[k] = make_float4(bt, __uint_as_float(btri), __uint_as_float(bmesh), __uint_as_float(have ? 1u : 0u));
     }
 }
@@ -427,10 +450,6 @@ __global__ __launch_bounds__(BLOCK, 5) void heavy_trace_closest(const KernelArgs
 // part 0: the walks shadow pass 0 gave up (list entries below the SC_SHEAVY_SPLIT mark), on the side stream right
 // after that pass; part 1: the rest, after the last pass.
 __global__ __launch_bounds__(BLOCK) void heavy_trace_shadow(const KernelArgs A, const uint32_t part) {
-    __shared__ TopLdsStorage top_storage;
-    TopLds TL;
-    TL.fast = false;
-    if (!A.s->top_fast && A.s->top_lds) TL = top_lds_load(A, top_storage);
     const uint32_t lane = threadIdx.x & 63u;
     if (A.f->s_counts[SC_OVERFLOW]) return;
     uint32_t total = A.f->s_counts[SC_SHEAVY], split = A.f->s_counts[SC_SHEAVY_SPLIT];
@@ -441,7 +460,7 @@ __global__ __launch_bounds__(BLOCK) void heavy_trace_shadow(const KernelArgs A, 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
     const uint32_t n_waves = gridDim.x * (BLOCK / 64);
     if (first + wave >= total) return;
-    const TopRegs TR = heavy_top_load(A, lane);
+    TopRegs TR = heavy_top_load(A, lane);
     for (uint32_t k = first + wave; k < total; k += n_waves) {
         const uint32_t r = A.f->s_sheavy[k];
         const float4 q0 = A.f->s_shadowq[2 * (size_t)r], q1 = A.f->s_shadowq[2 * (size_t)r + 1];
@@ -453,7 +472,7 @@ __global__ __launch_bounds__(BLOCK) void heavy_trace_shadow(const KernelArgs A, 
         bool have, occluded;
         float bt = 0;
         uint32_t btri = 0, bmesh = 0;
-        heavy_walk<true>(A, TR, R, false, uniform_f(q0.w), have, bt, btri, bmesh, occluded, lane, &TL);
+        heavy_walk<true>(A, TR, R, false, uniform_f(q0.w), have, bt, btri, bmesh, occluded, lane);
         if (lane == 0) A.f->s_occluded[r] = occluded ? 1 : 0;
     }
 }

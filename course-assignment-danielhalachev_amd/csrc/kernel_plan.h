@@ -29,8 +29,18 @@
 #include "kernel_stream.h"
 #include "kernel_walk.h"
 
-// one top-level leaf: {lo.xyz, first entry} {hi.xyz, entry count} {shadow mask lo, hi, -, -} {-}: 16 dwords, one s_load_dwordx16
+// one top-level leaf: {lo.xyz, first entry} {hi.xyz, entry count} {shadow mask words 0..3} {words 4..7}: 16 dwords, one s_load_dwordx16
 constexpr int PLAN_LEAF_DWORDS = 16;
+// The WIDE plan (more than 64 top-level leaves or meshes, up to 256 meshes): the leaves in groups of PLAN_GROUP_LEAVES consecutive
+// ones (visit order is spatial order) under their union box -- {lo.xyz, first leaf} {hi.xyz, leaves}, one s_load_dwordx8.  A ray
+// that passes a leaf's box passes any box containing it (the slab test is monotone, kernel_heavy.h), so a group none of the wave's
+// rays passes holds no leaf any of them passes: skipping it changes nothing.
+constexpr int PLAN_GROUP_LEAVES = 16, PLAN_GROUP_DWORDS = 8;
+typedef float v8f __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(4))) v8f *kv8p;
+__device__ __forceinline__ v8f plan_group(const KernelArgs &A, uint32_t g) {
+    return *(kv8p)((kfp)(const float *)A.s->plan_groups + PLAN_GROUP_DWORDS * (size_t)g);
+}
 
 __device__ __forceinline__ v16f plan_leaf(const KernelArgs &A, uint32_t k) {
     return *(kv16p)((kfp)(const float *)A.s->plan_boxes + PLAN_LEAF_DWORDS * (size_t)k);
@@ -44,9 +54,10 @@ __device__ __forceinline__ uint32_t leaf_cursor_next(uint32_t c) { return (c >> 
 // ---------------------------------------------------------------------------------------------------------------- shadow
 // the shadow rays [first, first + total) of the queue; `cursor` hands them out
 constexpr uint32_t SHADOW_NODE_REPEAT = 2;  // node steps per loop trip (measured: 2 beats 1, 3 and 4)
+template <uint32_t WORDS>  // 32-bit words of a ray's mesh mask: 2 (the plan proper: <= 64 leaves, <= 64 meshes) or 8 (the wide plan)
 __device__ __forceinline__ void shadow_plan_walks(const KernelArgs &A, const uint32_t first, const uint32_t total, uint32_t *cursor) {
-    __shared__ uint32_t root_of_bit[64];  // shadow order -> root node of the mesh's tree
-    if (threadIdx.x < 64u) root_of_bit[threadIdx.x] = threadIdx.x < A.s->plan_shadow_bits ? A.s->meshes[A.s->plan_shadow_mesh[threadIdx.x]].root : END;
+    __shared__ uint32_t root_of_bit[32 * WORDS];  // shadow order -> root node of the mesh's tree
+    if (threadIdx.x < 32u * WORDS) root_of_bit[threadIdx.x] = threadIdx.x < A.s->plan_shadow_bits ? A.s->meshes[A.s->plan_shadow_mesh[threadIdx.x]].root : END;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     if (A.f->s_counts[SC_OVERFLOW]) return;
@@ -55,7 +66,9 @@ __device__ __forceinline__ void shadow_plan_walks(const KernelArgs &A, const uin
 
     Ray R;
     uint32_t wn = END, we = NONE;   // next mesh-tree node, leaf cursor
-    uint32_t mlo = 0, mhi = 0;      // meshes still to walk, bits of the shadow order
+    uint32_t todo[WORDS];           // meshes still to walk, bits of the shadow order
+#pragma unroll
+    for (uint32_t w = 0; w < WORDS; w++) todo[w] = 0;
     float light_dist = 0;
     uint32_t nbox = 0, ntri = 0, nplan = 0;
     int state = ST_FETCH;
@@ -92,15 +105,35 @@ __device__ __forceinline__ void shadow_plan_walks(const KernelArgs &A, const uin
             }
             if (fresh) {
                 // the plan: which meshes does this ray have to walk?  (k is wave-uniform: scalar loads, no gathers)
-                uint32_t lo = 0, hi = 0;
-                for (uint32_t k = 0; k < A.s->plan_leaves; k++) {
-                    const v16f L = plan_leaf(A, k);
-                    const bool hit = slab_test_no_parallel(R, L[0], L[1], L[2], L[4], L[5], L[6]);
-                    lo |= hit ? __float_as_uint(L[8]) : 0u;
-                    hi |= hit ? __float_as_uint(L[9]) : 0u;
+                uint32_t acc[WORDS];
+#pragma unroll
+                for (uint32_t w = 0; w < WORDS; w++) acc[w] = 0;
+                if constexpr (WORDS == 2) {
+                    for (uint32_t k = 0; k < A.s->plan_leaves; k++) {
+                        const v16f L = plan_leaf(A, k);
+                        const bool hit = slab_test_no_parallel(R, L[0], L[1], L[2], L[4], L[5], L[6]);
+                        acc[0] |= hit ? __float_as_uint(L[8]) : 0u;
+                        acc[1] |= hit ? __float_as_uint(L[9]) : 0u;
+                    }
+                    if (A.exec_count) nplan += A.s->plan_leaves;
+                } else {
+                    for (uint32_t g = 0; g < A.s->plan_group_count; g++) {
+                        const v8f G = plan_group(A, g);
+                        const bool gh = slab_test_no_parallel(R, G[0], G[1], G[2], G[4], G[5], G[6]);
+                        const uint32_t k0 = __builtin_amdgcn_readfirstlane(__float_as_uint(G[3]));
+                        const uint32_t n = __ballot(gh) ? __builtin_amdgcn_readfirstlane(__float_as_uint(G[7])) : 0u;
+                        for (uint32_t k = k0; k < k0 + n; k++) {
+                            const v16f L = plan_leaf(A, k);
+                            const bool hit = slab_test_no_parallel(R, L[0], L[1], L[2], L[4], L[5], L[6]);
+#pragma unroll
+                            for (uint32_t w = 0; w < WORDS; w++) acc[w] |= hit ? __float_as_uint(L[8 + w]) : 0u;
+                        }
+                        if (A.exec_count) nplan += 1u + n;
+                    }
                 }
-                if (A.exec_count) nplan += A.s->plan_leaves;
-                mlo = lo; mhi = hi; wn = END; we = NONE;
+#pragma unroll
+                for (uint32_t w = 0; w < WORDS; w++) todo[w] = acc[w];
+                wn = END; we = NONE;
             }
         }
         if (!__ballot(state != ST_DONE)) break;
@@ -110,10 +143,15 @@ __device__ __forceinline__ void shadow_plan_walks(const KernelArgs &A, const uin
             // false: no mesh is left, the walk is complete
             auto node_step = [&]() -> bool {
                 if (wn == END) {
-                    if ((mlo | mhi) == 0u) return false;
-                    const uint32_t bit = mlo ? (uint32_t)__builtin_ctz(mlo) : 32u + (uint32_t)__builtin_ctz(mhi);
-                    if (mlo) mlo &= mlo - 1u; else mhi &= mhi - 1u;
-                    wn = root_of_bit[bit];
+                    uint32_t at = WORDS, word = 0;  // the first word with a mesh left
+#pragma unroll
+                    for (uint32_t w = WORDS; w-- > 0;)
+                        if (todo[w]) { at = w; word = todo[w]; }
+                    if (at == WORDS) return false;
+#pragma unroll
+                    for (uint32_t w = 0; w < WORDS; w++)
+                        if (w == at) todo[w] = word & (word - 1u);
+                    wn = root_of_bit[32u * at + (uint32_t)__builtin_ctz(word)];
                 }
                 const float4 *N = reinterpret_cast<const float4 *>(nodes_b + (size_t)(uint32_t)(wn << 5));
                 const float4 q0 = N[0], q1 = N[1];
@@ -186,8 +224,14 @@ __device__ __forceinline__ void shadow_plan_walks(const KernelArgs &A, const uin
 template <uint32_t pass>  // (a template parameter so that the passes are separate kernels in a profile)
 __global__ __launch_bounds__(BLOCK) void stream_trace_shadow_plan(const KernelArgs A) {
     const uint32_t split = A.f->s_counts[SC_SHADOW_SPLIT];
-    shadow_plan_walks(A, pass == 0 ? 0u : split, pass == 0 ? split : A.f->s_counts[SC_SHADOW] - split,
-                      A.f->s_counts + (pass == 0 ? SC_SHADOW_FETCH : SC_SHADOW_FETCH2));
+    shadow_plan_walks<2>(A, pass == 0 ? 0u : split, pass == 0 ? split : A.f->s_counts[SC_SHADOW] - split,
+                         A.f->s_counts + (pass == 0 ? SC_SHADOW_FETCH : SC_SHADOW_FETCH2));
+}
+template <uint32_t pass>  // the same over the wide plan (SceneArgs::plan_wide)
+__global__ __launch_bounds__(BLOCK) void stream_trace_shadow_plan_wide(const KernelArgs A) {
+    const uint32_t split = A.f->s_counts[SC_SHADOW_SPLIT];
+    shadow_plan_walks<8>(A, pass == 0 ? 0u : split, pass == 0 ? split : A.f->s_counts[SC_SHADOW] - split,
+                         A.f->s_counts + (pass == 0 ? SC_SHADOW_FETCH : SC_SHADOW_FETCH2));
 }
 
 // ---------------------------------------------------------------------------------------------------------- closest hit
@@ -201,33 +245,56 @@ struct PlanList {
 
 // Appends, for every top-level leaf the ray reaches, the meshes it lists that the ray has not met before -- in leaf visit
 // order and list order, i.e. in the order the reference collects their hits (KDTree.cpp:132-155).  Wave-uniform loops:
-// leaf boxes and entries come through scalar loads.
-__device__ __forceinline__ void plan_closest_meshes(const KernelArgs &A, const Ray &R, PlanList &PL, uint32_t &nplan) {
+// leaf boxes and entries come through scalar loads.  WIDE: leaf groups (above), up to 256 meshes, and a list that may not
+// hold them all (SceneArgs::plan_list_words is capped): false when this ray's list is full -- the ray goes to heavy_trace_closest.
+template <bool WIDE>
+__device__ __forceinline__ bool plan_closest_meshes(const KernelArgs &A, const Ray &R, PlanList &PL, uint32_t &nplan) {
     const ku32p entries = (ku32p)A.s->leaf_meshes;
-    uint32_t seen_lo = 0, seen_hi = 0, acc = 0, cnt = 0;
-    for (uint32_t k = 0; k < A.s->plan_leaves; k++) {
+    constexpr uint32_t WORDS = WIDE ? 8u : 2u;
+    uint32_t seen[WORDS];
+#pragma unroll
+    for (uint32_t w = 0; w < WORDS; w++) seen[w] = 0;
+    uint32_t acc = 0, cnt = 0;
+    bool fits = true;
+    const uint32_t cap = A.s->plan_list_words * 4u;
+    auto leaf = [&](const uint32_t k) {
         const v16f L = plan_leaf(A, k);
         const bool hit = slab_test_no_parallel(R, L[0], L[1], L[2], L[4], L[5], L[6]);
         // (no `continue` on the wave-uniform ballot: DESIGN.md "compiler notes")
         const uint32_t first = __builtin_amdgcn_readfirstlane(__float_as_uint(L[3]));
         const uint32_t n = __ballot(hit) ? __builtin_amdgcn_readfirstlane(__float_as_uint(L[7])) : 0u;
         for (uint32_t j = 0; j < n; j++) {
-            const uint32_t m = entries[first + j] & ~LAST;  // uniform, < 64 (plan_ok)
+            const uint32_t m = entries[first + j] & ~LAST;  // uniform, < 32 WORDS (plan_ok / plan_wide)
             const uint32_t bit = 1u << (m & 31u);
-            const bool lo = m < 32u;
-            const bool fresh = hit && !((lo ? seen_lo : seen_hi) & bit);
+            bool fresh = false;
+#pragma unroll
+            for (uint32_t w = 0; w < WORDS; w++)
+                if ((m >> 5) == w) { fresh = hit && !(seen[w] & bit); seen[w] |= fresh ? bit : 0u; }
+            if (WIDE && fresh && cnt >= cap) { fits = false; fresh = false; }
             if (fresh) {
-                if (lo) seen_lo |= bit; else seen_hi |= bit;
                 acc |= m << (8u * (cnt & 3u));
                 cnt++;
                 if ((cnt & 3u) == 0u) { PL.words[((cnt >> 2) - 1u) * BLOCK] = acc; acc = 0; }
             }
         }
+    };
+    if constexpr (!WIDE) {
+        for (uint32_t k = 0; k < A.s->plan_leaves; k++) leaf(k);
+        if (A.exec_count) nplan += A.s->plan_leaves;
+    } else {
+        for (uint32_t g = 0; g < A.s->plan_group_count; g++) {
+            const v8f G = plan_group(A, g);
+            const bool gh = slab_test_no_parallel(R, G[0], G[1], G[2], G[4], G[5], G[6]);
+            const uint32_t k0 = __builtin_amdgcn_readfirstlane(__float_as_uint(G[3]));
+            const uint32_t n = __ballot(gh) ? __builtin_amdgcn_readfirstlane(__float_as_uint(G[7])) : 0u;
+            for (uint32_t k = k0; k < k0 + n; k++) leaf(k);
+            if (A.exec_count) nplan += 1u + n;
+        }
     }
     if (cnt & 3u) PL.words[(cnt >> 2) * BLOCK] = acc;
-    if (A.exec_count) nplan += A.s->plan_leaves;
     PL.count = cnt;
     PL.next = 0;
+    return fits;
 }
 
 __device__ __forceinline__ uint32_t plan_list_pop(PlanList &PL) {
@@ -236,14 +303,16 @@ __device__ __forceinline__ uint32_t plan_list_pop(PlanList &PL) {
 }
 
 // Every ray of recursion level `gen`, one per lane, in the reference's own order: plan, walk of the listed meshes over the binary
-// threaded nodes, material dispatch.  Rays with a parallel axis and walks longer than the step budget go to heavy_trace_closest.
+// threaded nodes, material dispatch.  WIDE: the wide plan (SceneArgs::plan_wide).  Rays with a parallel axis and walks longer than the step budget go to heavy_trace_closest.
 // (Measured and removed, DESIGN.md section 7: 4-wide quad nodes with an LDS stack -- the same frame time; the same nearest slot
 // first with exact distance pruning on loose boxes -- grazing rays, the long walks, have nothing to prune before they hit.)
-__global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArgs A, const uint32_t gen) {
+template <bool WIDE>
+__device__ __forceinline__ void shade_plan_level(const KernelArgs &A, const uint32_t gen) {
     if (A.wave_prio) __builtin_amdgcn_s_setprio(3);  // ahead of the bulk shadow pass's waves on this SIMD
     extern __shared__ uint32_t plan_lds[];  // mesh lists: A.s->plan_list_words x BLOCK
-    __shared__ uint32_t s_tree_root[64];    // per mesh (plan kernels: at most 64 meshes)
-    if (threadIdx.x < 64u) s_tree_root[threadIdx.x] = threadIdx.x < A.s->top_meshes ? A.s->meshes[threadIdx.x].root : END;
+    constexpr uint32_t MESHES = WIDE ? 256u : 64u;
+    __shared__ uint32_t s_tree_root[MESHES];  // per mesh
+    if (threadIdx.x < MESHES) s_tree_root[threadIdx.x] = threadIdx.x < A.s->top_meshes ? A.s->meshes[threadIdx.x].root : END;
     __syncthreads();
     PlanList PL;
     PL.words = plan_lds + threadIdx.x;
@@ -301,10 +370,14 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArg
                 state = ST_TRAVERSE;
             }
             if (fresh) {
-                plan_closest_meshes(A, R, PL, nplan);
+                const bool fits = plan_closest_meshes<WIDE>(A, R, PL, nplan);
                 wn = END; we = NONE; mesh = NONE;
                 mhave = false; mmin = INFINITY; mt = 0; mtri = 0;
                 have = false; tmin = INFINITY; bt = 0; btri = 0; bmesh = 0;
+                if (WIDE && !fits) {  // more meshes than this lane's list holds: the wave-per-ray kernel needs no list
+                    if (evict_ray(A.f->s_heavy, A.f->s_heavy_cap, A.f->s_counts + SC_HEAVY + gen, r, lane)) state = ST_FETCH;
+                    else { A.f->s_counts[SC_OVERFLOW] = 1; state = ST_FETCH; }
+                }
             }
         }
         if (!__ballot(state != ST_DONE)) break;
@@ -382,3 +455,5 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArg
     exec_counters_flush(A, nbox, ntri, lane, nplan);
 }
 
+__global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArgs A, const uint32_t gen) { shade_plan_level<false>(A, gen); }
+__global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan_wide(const KernelArgs A, const uint32_t gen) { shade_plan_level<true>(A, gen); }

@@ -345,6 +345,20 @@ def hw12_scene(width=3840, height=2160, detail=1.0, bitmap_size=1024):
             "lights": _room_lights(), "textures": textures, "materials": materials, "objects": objects}
 
 
+def scatter_meshes(scene, n_objects, seed=7):
+    """The scene with small spheres scattered through its room until it holds n_objects meshes: a top-level tree with hundreds of
+    leaves (the reference's scenes have a handful of meshes; tools/many_meshes.py and the wide-plan tests use this)."""
+    rng = np.random.default_rng(seed)
+    objects = list(scene["objects"])
+    n_mat = len(scene["materials"])
+    while len(objects) < n_objects:
+        c = rng.uniform([-2.6, -1.2, -7.5], [2.6, 2.0, -1.5]).astype(np.float32)
+        m = uv_sphere(int(rng.integers(0, n_mat)), tuple(float(x) for x in c), float(rng.uniform(0.08, 0.25)), 16, 8)
+        m.pop("uvs", None)
+        objects.append(m)
+    return dict(scene, objects=objects)
+
+
 CONFIGS = {
     # name: (generator, width, height, max_depth)
     "hw07": (hw07_scene, 640, 480, 1),

@@ -81,6 +81,24 @@ def test_every_kernel_path_gives_the_same_frame(pkg, scenes, oracle, name, tunin
     assert tracer.stats().fallback_frames == 0
 
 
+@pytest.mark.parametrize("tuning", [None, dict(step_budget=8, shadow_budget=8, level0_budget=8), dict(heavy_level=0),
+                                    dict(step_budget=100000, shadow_budget=100000, heavy_level=0), dict(step_budget=0), dict(mode=1)],
+                         ids=lambda t: "defaults" if t is None else ",".join("%s=%s" % kv for kv in t.items()))
+@pytest.mark.parametrize("n_meshes", [100, 150, 300])
+def test_many_meshes_stay_on_the_plan_kernels(pkg, scenes, oracle, n_meshes, tuning):
+    """A top-level tree with hundreds of leaves (the reference's scenes have a handful of meshes): up to 256 meshes the wide
+    plan kernels render it (eight-word mesh masks, leaf groups; the wave-per-ray kernels walk the top-level leaf sequence 64
+    leaves at a time, and know repeats among the first 128 meshes only), beyond that the faithful kernels.  Same frame."""
+    scene = scenes.scatter_meshes(scenes.make("hw11", width=192, height=108, detail=0.25), n_meshes)
+    want, _ = oracle.OracleScene(scenes.to_blob(scene)).render(4)
+    tracer = make_tracer(pkg, scenes, scene, tuning=tuning)
+    if tuning is None:
+        assert ("plan_wide" in tracer.kernels()["level0"]) == (n_meshes <= 256)
+    for frame in range(2):
+        assert_same_floats(tracer.render(max_depth=4), want, "%d meshes %r frame %d" % (n_meshes, tuning, frame))
+    assert tracer.stats().fallback_frames == 0
+
+
 @pytest.mark.parametrize("caps", [dict(ray_cap=256), dict(node_cap=1), dict(shadow_cap=1 << 14)])
 def test_queue_overflow_hands_the_frame_to_the_fallback(pkg, scenes, oracle, caps):
     """Ray queues too small for the frame: the stream kernels raise the overflow word and stop, render_lanes redoes the

@@ -2,23 +2,15 @@
 tables the fast paths keep in registers / LDS (<= 64 nodes, <= 64 meshes) and the generic walks run.  Prints ms per frame at
 1920x1080 depth 8 and checks the frame against the counting build.  usage: python tools/many_meshes.py [N ...]"""
 import importlib, sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 pkg = importlib.import_module('course-assignment-danielhalachev_amd'); sc = pkg.scenes
 counts = [int(a) for a in sys.argv[1:]] or [40, 200]
 for n in counts:
-    base = sc.make('hw11', detail=0.6)
-    rng = np.random.default_rng(7)
-    objects = list(base['objects'])
-    n_mat = len(base['materials'])
-    while len(objects) < n:
-        c = rng.uniform([-2.6, -1.2, -7.5], [2.6, 2.0, -1.5]).astype(np.float32)
-        m = sc.uv_sphere(int(rng.integers(0, n_mat)), tuple(float(x) for x in c), float(rng.uniform(0.08, 0.25)), 16, 8)
-        m.pop('uvs', None)
-        objects.append(m)
-    scene = dict(base, objects=objects)
+    scene = sc.scatter_meshes(sc.make('hw11', detail=0.6), n)
+    objects = scene['objects']
     hs = pkg.Scene(json_text=sc.to_json(scene))
-    tr = pkg.Tracer(hs)
+    tr = pkg.Tracer(hs, tuning=pkg.tuning_from_string(os.environ.get('CRT_TUNING', '')))   # (the tool, not the library, reads it)
     for _ in range(3): got = tr.render(max_depth=8)
     t0 = time.perf_counter(); k = 10
     for _ in range(k): got = tr.render(max_depth=8)
@@ -28,4 +20,4 @@ for n in counts:
     d = hs.desc
     print('%d meshes, %d triangles, top-level tree of %d leaf entries: %.2f ms per frame incl. copy (device %.2f; levels %.2f, shadow pass %.2f, tail %.2f); '
           'frame == counting build: %s; fallback frames %d' % (len(objects), d.n_triangles, d.n_leaf_meshes, ms, ph[0], ph[1], ph[2], ph[3] + ph[4],
-          bool(np.array_equal(got.view(np.uint32), ref.view(np.uint32))), tr.stats().fallback_frames), flush=True)
+          bool(np.array_equal(got.view(np.uint32), ref.view(np.uint32))), tr.stats().fallback_frames), tr.kernels(), flush=True)

@@ -2,7 +2,7 @@
 settled frame's (tests/test_gpu_parity.py::test_queue_capacities_follow_the_frames is the same room).
 usage: python tools/regrow_time.py [width height]"""
 import importlib, sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module('course-assignment-danielhalachev_amd'); sc = pkg.scenes
 W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (256, 192)
 scene = sc.make("hw11", width=W, height=H, detail=0.15)

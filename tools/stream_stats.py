@@ -1,14 +1,15 @@
 """Dev helper: per-level ray counts / evictions of the ray-stream pass on a full-size BASELINE scene.
 CRT_TUNING="quad=0 heavy_level=0" (crt_tuning fields) selects kernels; the tool, not the library, reads it."""
 import importlib, sys, ctypes as C
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module('course-assignment-danielhalachev_amd'); sc = pkg.scenes
 name = sys.argv[1] if len(sys.argv) > 1 else 'hw14'
 import tempfile
-s = sc.make(name); folder = tempfile.mkdtemp() + '/'
+many = name.startswith('many')   # many200: the room of tools/many_meshes.py with 200 meshes
+s = sc.scatter_meshes(sc.make('hw11', detail=0.6), int(name[4:])) if many else sc.make(name); folder = tempfile.mkdtemp() + '/'
 if s.get('textures'): sc.write_bitmaps(s, folder)
 hs = pkg.Scene(json_text=sc.to_json(s), folder=folder); tr = pkg.Tracer(hs, tuning=pkg.tuning_from_string(__import__('os').environ.get('CRT_TUNING', '')))
-depth = sc.CONFIGS[name][3]
+depth = 8 if many else sc.CONFIGS[name][3]
 for i in range(3):
     tr.render(max_depth=depth)
 print('phase ms', tr.kernel_times_ms(3))
