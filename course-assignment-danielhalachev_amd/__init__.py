@@ -138,14 +138,15 @@ DEVICE_SYMBOLS = ["crt_tuning_defaults", "crt_create_tuned", "crt_create", "crt_
                   "crt_build_tree_device", "crt_built_tree_node_count", "crt_built_tree_index_total", "crt_built_tree_boxes",
                   "crt_built_tree_links", "crt_built_tree_indexes", "crt_built_tree_free", "crt_build_last_error",
                   "crt_multi_create", "crt_multi_set_camera", "crt_multi_render", "crt_multi_read_quantized", "crt_multi_get_stats",
-                  "crt_multi_device_count", "crt_multi_context", "crt_multi_last_error", "crt_multi_destroy"]
+                  "crt_multi_device_count", "crt_multi_context", "crt_multi_last_error", "crt_multi_destroy",
+                  "crt_multi_staged_parts", "crt_multi_peer_note", "crt_debug_multi_force_staged"]
 HOST_SYMBOLS = ["crt_host_scene_parse_file", "crt_host_scene_parse_text", "crt_host_scene_parse_text_ex",
                 "crt_host_scene_build_seconds", "crt_host_scene_free", "crt_host_scene_desc",
                 "crt_host_scene_settings", "crt_host_scene_camera", "crt_host_scene_mesh_count",
                 "crt_host_tree_node_count", "crt_host_tree_index_total", "crt_host_tree_dump", "crt_host_mesh_sizes",
                 "crt_host_mesh_normals", "crt_host_bucket_rects", "crt_host_camera_apply", "crt_host_tracer_create", "crt_host_tracer_create_tuned",
                 "crt_host_tracer_create_multi", "crt_host_tracer_stats",
-                "crt_host_tracer_free", "crt_host_tracer_set_camera", "crt_host_tracer_render", "crt_host_tracer_ctx",
+                "crt_host_tracer_free", "crt_host_tracer_set_camera", "crt_host_tracer_render", "crt_host_tracer_ctx", "crt_host_tracer_multi",
                 "crt_host_export_ppm", "crt_host_last_error"]
 
 _lib = None
@@ -371,6 +372,34 @@ class Tracer:
         if getattr(self, "_h", None):
             lib().crt_host_tracer_free(self._h)
             self._h = None
+
+    # ---- several devices: which parts reach devices[0] over xGMI, which are staged through pinned host memory
+    def _multi(self):
+        L = lib()
+        L.crt_host_tracer_multi.restype = C.c_void_p
+        L.crt_host_tracer_multi.argtypes = [C.c_void_p]
+        m = L.crt_host_tracer_multi(self._h)
+        if not m:
+            raise RuntimeError("not a multi-device tracer")
+        return C.c_void_p(m)
+
+    def staged_parts(self):
+        L = lib()
+        L.crt_multi_staged_parts.restype = C.c_uint32
+        L.crt_multi_staged_parts.argtypes = [C.c_void_p]
+        return int(L.crt_multi_staged_parts(self._multi()))
+
+    def peer_note(self):
+        L = lib()
+        L.crt_multi_peer_note.restype = C.c_char_p
+        L.crt_multi_peer_note.argtypes = [C.c_void_p]
+        return L.crt_multi_peer_note(self._multi()).decode()
+
+    def force_staged(self, on=True):
+        """Tests: every part but the first copies its tiles through pinned host memory, as if no device had peer access."""
+        L = lib()
+        L.crt_debug_multi_force_staged.argtypes = [C.c_void_p, C.c_int]
+        self._check(L.crt_debug_multi_force_staged(self._multi(), 1 if on else 0))
 
     def __del__(self):
         try:

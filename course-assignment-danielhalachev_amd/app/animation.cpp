@@ -53,11 +53,14 @@ struct Writers {  // a few threads that turn quantised frames into PPM files
     jobs.push_back(std::move(job));
     cv.notify_one();
   }
-  void close() {
+  void close() {  // (idempotent: the destructor calls it again)
     { std::lock_guard<std::mutex> lock(m); closing = true; }
     cv.notify_all();
-    for (auto &t : threads) t.join();
+    for (auto &t : threads)
+      if (t.joinable()) t.join();
   }
+  // a frame that throws unwinds through here: joinable threads destroyed un-joined would end the process before main's handler prints the error
+  ~Writers() { close(); }
 };
 }  // namespace
 

@@ -1555,7 +1555,15 @@ struct crt_multi {
     size_t all_items_cap = 0;
     std::vector<std::vector<WorkItem>> part_items;
     std::vector<uint32_t> slot_base;      // first slot of part p in d_staging
-    std::vector<hipEvent_t> done;         // part p's tiles have arrived on device[0]
+    std::vector<hipEvent_t> done;         // part p's tiles have arrived on device[0] (a staged part: in its pinned host buffer)
+    // A part whose device cannot store into device[0]'s memory (hipDeviceCanAccessPeer says no, or hipDeviceEnablePeerAccess fails)
+    // is STAGED: its tiles go to a pinned host buffer on its own stream and from there to device[0] on device[0]'s stream.
+    // crt_multi_create says so (crt_multi_staged_parts, crt_multi_peer_note) instead of leaving the choice to the runtime.
+    std::vector<uint8_t> staged;
+    std::vector<float *> h_stage;
+    std::vector<size_t> h_stage_tiles;
+    std::string peer_note;
+    bool force_staged = false;            // crt_debug_multi_force_staged: every part but the first staged (tests, one-GPU boxes)
     std::vector<crt_rect> cached_rects;
     uint32_t n_all_items = 0;
     uint64_t pixels = 0;
@@ -1579,9 +1587,13 @@ static int multi_part_launch(crt_multi *M, uint32_t p) {
     const uint32_t n = (uint32_t)M->part_items[p].size();
     int rc = launch_render(ctx, M->job_options, n, M->d_packed[p], 1, ctx->stream);
     if (rc) return rc;
-    if (p != 0 && n)  // part 0 renders straight into the staging buffer
-        CRT_HIP_CHECK(ctx, hipMemcpyPeerAsync(M->d_staging + (size_t)M->slot_base[p] * 192, M->devices[0], M->d_packed[p],
-                                              M->devices[p], (size_t)n * 192 * sizeof(float), ctx->stream));
+    if (p != 0 && n) {  // part 0 renders straight into the staging buffer
+        if (M->staged[p] || M->force_staged)
+            CRT_HIP_CHECK(ctx, hipMemcpyAsync(M->h_stage[p], M->d_packed[p], (size_t)n * 192 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        else
+            CRT_HIP_CHECK(ctx, hipMemcpyPeerAsync(M->d_staging + (size_t)M->slot_base[p] * 192, M->devices[0], M->d_packed[p],
+                                                  M->devices[p], (size_t)n * 192 * sizeof(float), ctx->stream));
+    }
     CRT_HIP_CHECK(ctx, hipEventRecord(M->done[p], ctx->stream));
     return CRT_OK;
 }
@@ -1616,6 +1628,7 @@ extern "C" void crt_multi_destroy(crt_multi *M) {
         (void)hipSetDevice(M->devices[p]);
         if (p < M->done.size() && M->done[p]) (void)hipEventDestroy(M->done[p]);
         if (p != 0 && p < M->d_packed.size() && M->d_packed[p]) (void)hipFree(M->d_packed[p]);
+        if (p < M->h_stage.size() && M->h_stage[p]) (void)hipHostFree(M->h_stage[p]);
     }
     if (!M->devices.empty()) {
         (void)hipSetDevice(M->devices[0]);
@@ -1637,6 +1650,9 @@ extern "C" int crt_multi_create(const crt_scene_desc *scene, const int *devices,
     M->ctx.assign(n_devices, nullptr);
     M->d_packed.assign(n_devices, nullptr);
     M->done.assign(n_devices, nullptr);
+    M->staged.assign(n_devices, 0);
+    M->h_stage.assign(n_devices, nullptr);
+    M->h_stage_tiles.assign(n_devices, 0);
     M->part_items.resize(n_devices);
     M->slot_base.assign(n_devices, 0);
     for (uint32_t p = 0; p < n_devices; p++) {
@@ -1647,13 +1663,22 @@ extern "C" int crt_multi_create(const crt_scene_desc *scene, const int *devices,
             crt_multi_destroy(M);
             return CRT_ERR_HIP;
         }
-        // direct xGMI stores to device[0] where the platform allows them (otherwise the copy is staged by the runtime)
+        // direct xGMI stores to device[0] where the platform allows them; where it does not, say so and stage that part's tiles
         if (devices[p] != devices[0]) {
             int can = 0;
-            if (hipDeviceCanAccessPeer(&can, devices[p], devices[0]) == hipSuccess && can) {
-                hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
-                else (void)hipGetLastError();
+            hipError_t e = hipDeviceCanAccessPeer(&can, devices[p], devices[0]);
+            const char *what = "hipDeviceCanAccessPeer";
+            if (e == hipSuccess && can) {
+                what = "hipDeviceEnablePeerAccess";
+                e = hipDeviceEnablePeerAccess(devices[0], 0);
+                if (e == hipErrorPeerAccessAlreadyEnabled) e = hipSuccess;
+            }
+            (void)hipGetLastError();
+            if (e != hipSuccess || !can) {
+                M->staged[p] = 1;
+                M->peer_note += "part " + std::to_string(p) + " (device " + std::to_string(devices[p]) + " -> " + std::to_string(devices[0]) + "): " +
+                                (e != hipSuccess ? std::string(what) + " failed: " + hipGetErrorString(e) : std::string("hipDeviceCanAccessPeer: no peer access")) +
+                                "; its tiles are staged through pinned host memory\n";
             }
         }
     }
@@ -1741,6 +1766,13 @@ extern "C" int crt_multi_render(crt_multi *M, const crt_options *o, const crt_re
                 if (M->d_packed[p]) (void)hipFree(M->d_packed[p]);
                 M->d_packed[p] = nullptr;
                 if (hipMalloc((void **)&M->d_packed[p], (part.size() ? part.size() : 1) * 192 * sizeof(float)) != hipSuccess) { M->error = "out of device memory"; return CRT_ERR_NOMEM; }
+                if ((M->staged[p] || M->force_staged) && part.size() > M->h_stage_tiles[p]) {
+                    if (M->h_stage[p]) (void)hipHostFree(M->h_stage[p]);
+                    M->h_stage[p] = nullptr;
+                    M->h_stage_tiles[p] = 0;
+                    if (hipHostMalloc((void **)&M->h_stage[p], part.size() * 192 * sizeof(float), hipHostMallocPortable) != hipSuccess) { M->error = "out of pinned host memory"; return CRT_ERR_NOMEM; }
+                    M->h_stage_tiles[p] = part.size();
+                }
             }
         }
         M->cached_rects.assign(rects, rects + n_rects);
@@ -1766,7 +1798,12 @@ extern "C" int crt_multi_render(crt_multi *M, const crt_options *o, const crt_re
         return first_rc;
     }
     CRT_HIP_CHECK(c0, hipSetDevice(M->devices[0]));
-    for (uint32_t p = 1; p < N; p++) CRT_HIP_CHECK(c0, hipStreamWaitEvent(c0->stream, M->done[p], 0));
+    for (uint32_t p = 1; p < N; p++) {
+        CRT_HIP_CHECK(c0, hipStreamWaitEvent(c0->stream, M->done[p], 0));
+        if ((M->staged[p] || M->force_staged) && !M->part_items[p].empty())  // the second leg of a staged part: pinned host -> device[0]
+            CRT_HIP_CHECK(c0, hipMemcpyAsync(M->d_staging + (size_t)M->slot_base[p] * 192, M->h_stage[p],
+                                             M->part_items[p].size() * 192 * sizeof(float), hipMemcpyHostToDevice, c0->stream));
+    }
     if (M->n_all_items) {
         const uint64_t threads = (uint64_t)M->n_all_items * 64;
         hipLaunchKernelGGL(unpack_items_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c0->stream, M->d_staging,
@@ -1801,6 +1838,21 @@ extern "C" int crt_multi_render(crt_multi *M, const crt_options *o, const crt_re
     total.total_ms = wall_ms;
     total.counters_valid = o->collect_counters == 1 ? 1u : 0u;
     M->stats = total;
+    return CRT_OK;
+}
+
+extern "C" uint32_t crt_multi_staged_parts(const crt_multi *M) {
+    uint32_t n = 0;
+    if (M) for (size_t p = 1; p < M->staged.size(); p++) n += (M->staged[p] || M->force_staged) ? 1u : 0u;
+    return n;
+}
+
+extern "C" const char *crt_multi_peer_note(const crt_multi *M) { return M ? M->peer_note.c_str() : ""; }
+
+extern "C" int crt_debug_multi_force_staged(crt_multi *M, int on) {
+    if (!M) return CRT_ERR_INVALID;
+    M->force_staged = on != 0;
+    M->cached_rects.clear();  // the next render allocates the pinned buffers
     return CRT_OK;
 }
 

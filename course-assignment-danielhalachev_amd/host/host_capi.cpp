@@ -234,6 +234,7 @@ extern "C" int crt_host_tracer_render(crt_host_tracer *t, const char *ppm_path, 
 }
 
 extern "C" crt_ctx *crt_host_tracer_ctx(crt_host_tracer *t) { return t ? t->tracer->context() : nullptr; }
+extern "C" crt_multi *crt_host_tracer_multi(crt_host_tracer *t) { return t ? t->tracer->multiContext() : nullptr; }
 
 extern "C" int crt_host_tracer_stats(crt_host_tracer *t, crt_stats *out) {
   if (!t || !out) return CRT_ERR_INVALID;

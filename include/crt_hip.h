@@ -280,6 +280,12 @@ int crt_multi_get_stats(crt_multi *multi, crt_stats *out);
 uint32_t crt_multi_device_count(const crt_multi *multi);
 crt_ctx *crt_multi_context(crt_multi *multi, uint32_t part); /* part 0 holds the frame */
 const char *crt_multi_last_error(const crt_multi *multi);
+/* Parts whose device cannot store into device[0]'s memory (hipDeviceCanAccessPeer / hipDeviceEnablePeerAccess said so at
+ * crt_multi_create) copy their tiles through pinned host memory instead of over xGMI: how many there are, and what the
+ * runtime answered for each (one line per part, empty when every part has peer access).  Same pixels either way. */
+uint32_t crt_multi_staged_parts(const crt_multi *multi);
+const char *crt_multi_peer_note(const crt_multi *multi);
+int crt_debug_multi_force_staged(crt_multi *multi, int on); /* tests: stage every part, as if no device had peer access */
 void crt_multi_destroy(crt_multi *multi);
 
 /* ---- the reference's tree built on the GPU (KDTree<T>::build, KDTree.cpp:10-46 / :89-125; BoundingBox.h:60-83): level by

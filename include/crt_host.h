@@ -71,6 +71,7 @@ int crt_host_tracer_set_camera(crt_host_tracer *tracer, const float position[3],
 int crt_host_tracer_render(crt_host_tracer *tracer, const char *ppm_path, int optimization, const crt_options *options,
                            float *out_rgb);
 crt_ctx *crt_host_tracer_ctx(crt_host_tracer *tracer);
+crt_multi *crt_host_tracer_multi(crt_host_tracer *tracer); /* NULL for a single-device tracer */
 /* statistics of the last render (summed over the devices of a multi-device tracer) */
 int crt_host_tracer_stats(crt_host_tracer *tracer, crt_stats *out);
 int crt_host_export_ppm(const char *path, const float *rgb, uint32_t width, uint32_t height);

@@ -367,6 +367,22 @@ def test_multi_device_tracer_renders_the_same_frame(pkg, scenes, oracle, parts):
     assert_same_floats(tracer.render(max_depth=depth), o.render(depth)[0], "%d parts, moved camera" % parts)
 
 
+def test_multi_device_tracer_without_peer_access_stages_its_tiles(pkg, scenes, oracle):
+    """A part whose device cannot store into devices[0]'s memory copies its tiles through pinned host memory (crt_multi_create
+    checks hipDeviceCanAccessPeer / hipDeviceEnablePeerAccess and says which parts those are); forced here, on one device."""
+    scene, depth, _ = small_case(scenes, "hw14")
+    want, _ = oracle.OracleScene(scenes.to_blob(scene)).render(depth)
+    tracer = pkg.Tracer(pkg.Scene(json_text=scenes.to_json(scene)), devices=[0, 0, 0])
+    assert tracer.staged_parts() == 0 and tracer.peer_note() == ""        # the same device three times: nothing to stage
+    assert_same_floats(tracer.render(max_depth=depth), want, "peer copies")
+    tracer.force_staged()
+    assert tracer.staged_parts() == 2
+    for frame in range(2):
+        assert_same_floats(tracer.render(max_depth=depth), want, "staged copies, frame %d" % frame)
+    tracer.force_staged(False)
+    assert_same_floats(tracer.render(max_depth=depth), want, "peer copies again")
+
+
 def test_multi_device_tracer_keeps_uncovered_pixels(pkg, scenes, oracle):
     # bucket_size 7 on 100x60 covers part of the frame only (SURVEY.md section 8 Q5): coverage masks travel with the tiles
     scene = scenes.make("hw08", width=100, height=60, detail=0.3)
