@@ -1,5 +1,5 @@
 """Dev helper: per-level ray counts / evictions of the ray-stream pass on a full-size BASELINE scene.
-CRT_TUNING="quad=0 heavy_level=0" (crt_tuning fields) selects kernels; the tool, not the library, reads it."""
+CRT_TUNING="side_blocks=0 heavy_level=0" (crt_tuning fields) selects kernels; the tool, not the library, reads it."""
 import importlib, sys, ctypes as C
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module('course-assignment-danielhalachev_amd'); sc = pkg.scenes
