@@ -148,6 +148,8 @@ struct crt_ctx {
     uint32_t sizing_seen_fallbacks = 0;
     uint64_t queue_bytes = 0;         // bytes of the per-frame buffers as allocated now
     uint64_t regrows = 0;             // attempts repeated with larger queues (launch_render)
+    uint32_t last_counts_cfg = 0;     // frame_config_of the frame last_counts came from
+    uint32_t slot_cfg[64] = {};       // ... of the frame in each event slot
     hipEvent_t ev_call0 = nullptr, ev_call1 = nullptr;  // around the last crt_render / crt_render_async call's device work
     bool pending = false;             // a frame enqueued by crt_render_async has not been waited for
     crt_options pending_options{};
@@ -659,14 +661,19 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
     }
     {
         // The plan of the top-level tree (kernel_plan.h, kernel_group.h): its leaves in visit order, which is index order.
-        std::vector<float4> boxes;
-        std::vector<uint32_t> order;  // non-refractive meshes, most leaves first
-        for (uint32_t m = 0; m < s->n_meshes; m++)
+        std::vector<float4> boxes, boxes_all;
+        std::vector<uint32_t> order, order_all;  // non-refractive meshes / every mesh (the GI mode's shadow rays), most leaves first
+        for (uint32_t m = 0; m < s->n_meshes; m++) {
             if (!(s->meshes[m].flags & 1u)) order.push_back(m);
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hmesh_host[a].count[0] > hmesh_host[b].count[0]; });
+            order_all.push_back(m);
+        }
+        auto more_leaves = [&](uint32_t a, uint32_t b) { return hmesh_host[a].count[0] > hmesh_host[b].count[0]; };
+        std::stable_sort(order.begin(), order.end(), more_leaves);
+        std::stable_sort(order_all.begin(), order_all.end(), more_leaves);
         constexpr uint32_t MAX_BITS = 256;  // shadow mask bits of the wide plan (kernel_plan.h: 8 words); the plan proper uses the first 64
-        std::vector<uint32_t> bit_of(s->n_meshes, MAX_BITS);
+        std::vector<uint32_t> bit_of(s->n_meshes, MAX_BITS), bit_of_all(s->n_meshes, MAX_BITS);
         for (size_t b = 0; b < order.size() && b < MAX_BITS; b++) bit_of[order[b]] = (uint32_t)b;
+        for (size_t b = 0; b < order_all.size() && b < MAX_BITS; b++) bit_of_all[order_all[b]] = (uint32_t)b;
         const bool contiguous = A.top_count > 0 && A.nested_boxes;  // (top_first / top_count: the top-level nodes are one index range)
         uint32_t n_leaves = 0;
         std::vector<float4> groups;
@@ -675,21 +682,24 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
             if (!is_leaf_link(n.link)) continue;
             const uint32_t begin = n.link & ~CRT_LINK_LEAF;
             uint32_t count = 0;
-            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mask_all[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (uint32_t e = begin; e < s->n_leaf_meshes; e++) {
                 const uint32_t mi = s->leaf_meshes[e] & ~CRT_ENTRY_LAST;
                 if (bit_of[mi] < MAX_BITS) mask[bit_of[mi] >> 5] |= 1u << (bit_of[mi] & 31u);
+                if (bit_of_all[mi] < MAX_BITS) mask_all[bit_of_all[mi] >> 5] |= 1u << (bit_of_all[mi] & 31u);
                 count++;
                 if (s->leaf_meshes[e] & CRT_ENTRY_LAST) break;
             }
             float bb, cb, mf[8];
             memcpy(&bb, &begin, 4);
             memcpy(&cb, &count, 4);
-            memcpy(mf, mask, sizeof(mf));
-            boxes.push_back(make_float4(n.lo[0], n.lo[1], n.lo[2], bb));  // PLAN_LEAF_DWORDS = 16 per leaf (kernel_plan.h)
-            boxes.push_back(make_float4(n.hi[0], n.hi[1], n.hi[2], cb));
-            boxes.push_back(make_float4(mf[0], mf[1], mf[2], mf[3]));
-            boxes.push_back(make_float4(mf[4], mf[5], mf[6], mf[7]));
+            for (std::vector<float4> *table : {&boxes, &boxes_all}) {
+                memcpy(mf, table == &boxes ? mask : mask_all, sizeof(mf));
+                table->push_back(make_float4(n.lo[0], n.lo[1], n.lo[2], bb));  // PLAN_LEAF_DWORDS = 16 per leaf (kernel_plan.h)
+                table->push_back(make_float4(n.hi[0], n.hi[1], n.hi[2], cb));
+                table->push_back(make_float4(mf[0], mf[1], mf[2], mf[3]));
+                table->push_back(make_float4(mf[4], mf[5], mf[6], mf[7]));
+            }
             // the wide plan's groups: PLAN_GROUP_LEAVES consecutive leaves under their union box
             if (n_leaves % PLAN_GROUP_LEAVES == 0) {
                 float first_leaf, zero = 0.0f;
@@ -715,6 +725,9 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
         if (upload(ctx, groups.data(), groups.size(), &A.plan_groups)) return fail(CRT_ERR_HIP);
         if (upload(ctx, boxes.data(), boxes.size(), &A.plan_boxes)) return fail(CRT_ERR_HIP);
         if (upload(ctx, order.data(), order.size(), &A.plan_shadow_mesh)) return fail(CRT_ERR_HIP);
+        A.plan_shadow_bits_all = (uint32_t)std::min<size_t>(order_all.size(), A.plan_ok ? 64u : MAX_BITS);
+        if (upload(ctx, boxes_all.data(), boxes_all.size(), &A.plan_boxes_all)) return fail(CRT_ERR_HIP);
+        if (upload(ctx, order_all.data(), order_all.size(), &A.plan_shadow_mesh_all)) return fail(CRT_ERR_HIP);
     }
     A.bgx = s->background[0]; A.bgy = s->background[1]; A.bgz = s->background[2];
     A.width = s->width; A.height = s->height; A.tiles_x = ctx->tiles_x;
@@ -857,6 +870,7 @@ static void harvest_counts(crt_ctx *ctx) {
         if (ctx->slot_items[slot]) {  // (a frame without work items launched nothing and copied nothing)
             ctx->last_counts.assign(h, h + SC_ALLOC_WORDS);
             ctx->last_counts_items = ctx->slot_items[slot];
+            ctx->last_counts_cfg = ctx->slot_cfg[slot];
             ctx->fallbacks_seen = h[SC_ALLOC_WORDS];
         }
         ctx->next_count_harvest++;
@@ -874,9 +888,9 @@ static void adapt_queue_sizing(crt_ctx *ctx) {
     const uint32_t *c = ctx->last_counts.data();
     if (ctx->fallbacks_seen != ctx->sizing_seen_fallbacks) {
         ctx->sizing_seen_fallbacks = ctx->fallbacks_seen;
-        ctx->node_mult = std::min(64.0, ctx->node_mult * 2.0);
-        ctx->ray_mult = std::min(32.0, ctx->ray_mult * 2.0);
-        ctx->shadow_extra = std::min(32.0, ctx->shadow_extra * 2.0);
+        ctx->node_mult = std::min(4096.0, ctx->node_mult * 2.0);
+        ctx->ray_mult = std::min(4096.0, ctx->ray_mult * 2.0);
+        ctx->shadow_extra = std::min(4096.0, ctx->shadow_extra * 2.0);
         return;
     }
     const FrameArgs &A = ctx->frame;
@@ -888,10 +902,10 @@ static void adapt_queue_sizing(crt_ctx *ctx) {
     // level 0 owns one node per pixel and n_lights fixed shadow slots per pixel: what can run out is the part beyond that
     const uint64_t base_shadow = px * (ctx->n_lights ? ctx->n_lights : 1);
     const uint64_t extra_nodes = nodes > px ? nodes - px : 0, extra_shadow = shadow > base_shadow ? shadow - base_shadow : 0;
-    if (A.s_node_cap > px && extra_nodes * 10 > ((uint64_t)A.s_node_cap - px) * 7) ctx->node_mult = std::min(64.0, ctx->node_mult * 1.5);
-    if (rays * 10 > (uint64_t)A.s_ray_cap * 7) ctx->ray_mult = std::min(32.0, ctx->ray_mult * 1.5);
+    if (A.s_node_cap > px && extra_nodes * 10 > ((uint64_t)A.s_node_cap - px) * 7) ctx->node_mult = std::min(4096.0, ctx->node_mult * 1.5);
+    if (rays * 10 > (uint64_t)A.s_ray_cap * 7) ctx->ray_mult = std::min(4096.0, ctx->ray_mult * 1.5);
     if (A.s_shadow_cap > base_shadow && extra_shadow * 10 > ((uint64_t)A.s_shadow_cap - base_shadow) * 7)
-        ctx->shadow_extra = std::min(32.0, ctx->shadow_extra * 1.5);
+        ctx->shadow_extra = std::min(4096.0, ctx->shadow_extra * 1.5);
 }
 
 static uint64_t queue_bytes_for(const crt_ctx *ctx, uint64_t px, double node_mult, double ray_mult, double shadow_extra) {
@@ -899,14 +913,31 @@ static uint64_t queue_bytes_for(const crt_ctx *ctx, uint64_t px, double node_mul
     return (uint64_t)(px * ray_mult) * (64 + 24) + (uint64_t)(px * lights * (1.0 + shadow_extra)) * 33 + (uint64_t)(px * node_mult) * 32;
 }
 
-// after an attempt that overflowed (launch_render): larger factors, as long as the device has room for them
-static bool grow_queue_sizing(crt_ctx *ctx, uint32_t n_items, double by) {
-    const double node_mult = ctx->node_mult * by, ray_mult = ctx->ray_mult * by, shadow_extra = std::max(0.5, ctx->shadow_extra * by);
-    const uint64_t px = (uint64_t)n_items * 64;
-    if (px * node_mult > 2.0e9 || px * ray_mult > 2.0e9 || px * (ctx->n_lights ? ctx->n_lights : 1) * (1.0 + shadow_extra) > 2.0e9) return false;
+// After an attempt that overflowed (launch_render): capacities from what the attempt learnt.  The level that was emitting when a
+// queue ran out still counted every ray it wanted to queue (the counters are bumped before the capacity check), so the rays of
+// levels 0 .. G are known exactly; the deeper ones are extrapolated with the last growth ratio (a GI frame grows by up to
+// gi_samples + 1 per level, a mirror room by 2, most frames shrink), the shadow rays in proportion to the nodes.  25 % on top;
+// false when the device has no room for that.
+static bool grow_queue_sizing(crt_ctx *ctx, uint32_t vitems, uint32_t max_depth) {
+    const uint32_t *c = ctx->last_counts.data();
+    const double px = (double)vitems * 64.0, lights = ctx->n_lights ? ctx->n_lights : 1;
+    uint32_t G = 0;
+    for (uint32_t g = 1; g <= max_depth && g < (uint32_t)MAX_GENERATIONS; g++) if (c[SC_COUNT + g]) G = g;
+    double known = px, widest = 0, last = px, before = px;
+    for (uint32_t g = 1; g <= G; g++) { before = last; last = c[SC_COUNT + g]; known += last; widest = std::max(widest, last); }
+    const double ratio = G >= 1 ? std::max(1.0, last / std::max(before, 1.0)) : 2.0;
+    double total = known, level = last;
+    for (uint32_t g = G + 1; g <= max_depth; g++) { level *= ratio; total += level; widest = std::max(widest, level); }
+    const double shadows = (double)c[SC_SHADOW] * (total / known);
+    double node_mult = std::max(ctx->node_mult, total * 1.25 / px), ray_mult = std::max(ctx->ray_mult, widest * 1.25 / px);
+    double shadow_extra = std::max(ctx->shadow_extra, shadows * 1.25 / (px * lights) - 1.0);
+    if (node_mult == ctx->node_mult && ray_mult == ctx->ray_mult && shadow_extra == ctx->shadow_extra) {
+        node_mult *= 2.0; ray_mult *= 2.0; shadow_extra = std::max(0.5, shadow_extra * 2.0);  // (the counters explain nothing: an eviction list, say)
+    }
+    if (px * node_mult > 2.0e9 || px * ray_mult > 2.0e9 || px * lights * (1.0 + shadow_extra) > 2.0e9) return false;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return false; }
-    if (queue_bytes_for(ctx, px, node_mult, ray_mult, shadow_extra) > (free_b + ctx->queue_bytes) / 2) return false;
+    if (queue_bytes_for(ctx, (uint64_t)px, node_mult, ray_mult, shadow_extra) > (free_b + ctx->queue_bytes) / 2) return false;
     ctx->node_mult = node_mult; ctx->ray_mult = ray_mult; ctx->shadow_extra = shadow_extra;
     return true;
 }
@@ -962,6 +993,17 @@ static int ensure_stream(crt_ctx *ctx, uint32_t n_items) {
     return CRT_OK;
 }
 
+// level 0 of the ray-stream pass holds this many rays per pixel (RayTracer.cpp:90-104: the centre sample + RAYS_PER_PIXEL - 1 jittered ones)
+static uint32_t level0_samples_of(const crt_options *o) { return o->use_gi && o->rays_per_pixel > 1u ? o->rays_per_pixel : 1u; }
+// a GI frame goes through the ray-stream pass when its level 0 fits 31-bit ray indices (otherwise render_lanes<.., true> renders it pixel by pixel)
+static bool gi_fits_stream(const crt_options *o, uint32_t n_items) {
+    return (uint64_t)n_items * 64u * level0_samples_of(o) * 2u < (1ull << 31) && o->gi_sample_size <= 64u;
+}
+// what, beside its size, decides how many rays a frame queues: two frames are "of the same kind" for the queue sizing when this agrees
+static uint32_t frame_config_of(const crt_options *o) {
+    return (o->use_gi ? 0x80000000u : 0u) | ((o->use_gi ? o->gi_sample_size & 0x7Fu : 0u) << 24) | (o->max_depth & 0xFFFFFFu);
+}
+
 template <typename K, typename... Args>
 static void launch(K kernel, uint32_t blocks, hipStream_t stream, Args... args) {
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK), 0, stream, args...);
@@ -987,7 +1029,11 @@ static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, fl
     F.rays_per_pixel = o->rays_per_pixel;
     F.monte_carlo_bias = o->monte_carlo_bias;
     F.gi_seed = o->gi_seed;
-    const bool stream_mode = ctx->mode == crt_ctx::MODE_STREAM && !gi;
+    // the GI mode's level 0 holds rays_per_pixel rays per pixel: `vitems` work items' worth of rays, which is what queues and grids are sized by
+    const uint32_t samples = level0_samples_of(o);
+    const bool stream_mode = ctx->mode == crt_ctx::MODE_STREAM && (!gi || gi_fits_stream(o, n_items));
+    const uint32_t vitems = stream_mode ? n_items * samples : n_items;
+    F.level0_samples = stream_mode ? samples : 1u;
     if (stream_mode && o->max_depth + 1 > (uint32_t)MAX_GENERATIONS) {
         ctx->error = "max_depth too large for the ray-stream pass";
         return CRT_ERR_INVALID;
@@ -1015,7 +1061,7 @@ static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, fl
         harvest_counts(ctx);
     }
     ctx->slot_items[slot] = 0;
-    const uint32_t lane_need = (n_items * 64u + BLOCK - 1) / BLOCK;
+    const uint32_t lane_need = (vitems * 64u + BLOCK - 1) / BLOCK;
     const uint32_t lane_blocks = std::max(1u, lane_need < ctx->grid_blocks ? lane_need : ctx->grid_blocks);
     CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0[slot], stream));
     if (n_items == 0) {
@@ -1031,11 +1077,11 @@ static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, fl
     const bool lean = heavy && ctx->lean_ok && (SC.plan_ok || SC.plan_wide);
     const bool wide = lean && !SC.plan_ok;  // the wide plan (kernel_plan.h): more than 64 top-level leaves or meshes
     if (stream_mode) {
-        rc = ensure_stream(ctx, n_items);
+        rc = ensure_stream(ctx, vitems);
         if (rc) return rc;
         F.heavy_level_threshold = lean ? ctx->tuning.heavy_level : 0u;
         // level 0 owns the first n_items * 64 * n_lights slots of the shadow queue; the deeper levels append
-        F.fixed0 = (uint64_t)n_items * 64u * ctx->n_lights <= F.s_shadow_cap ? 1u : 0u;
+        F.fixed0 = (uint64_t)vitems * 64u * ctx->n_lights <= F.s_shadow_cap ? 1u : 0u;
     }
     // this frame's argument block, into its own slot (the copy is ordered on `stream` ahead of the kernels that read it)
     ctx->h_frame_ring[slot] = F;
@@ -1055,7 +1101,7 @@ static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, fl
         A.bundle = REFILL_BUNDLE;
         A.wave_prio = 3u;  // the levels' waves (the frame's critical path) ahead of the bulk shadow pass's, which share their SIMDs
         A.force_whole = 0u;
-        if (F.fixed0) CRT_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->d_scounts + SC_SHADOW), (int)((uint32_t)n_items * 64u * ctx->n_lights), 1, stream));
+        if (F.fixed0) CRT_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->d_scounts + SC_SHADOW), (int)((uint32_t)vitems * 64u * ctx->n_lights), 1, stream));
         const uint32_t plds = SC.plan_list_words * BLOCK * (uint32_t)sizeof(uint32_t);  // kernel_plan.h: mesh lists
         KernelArgs S = A;  // argument block of the bulk shadow pass
         S.wave_prio = 0u;
@@ -1068,18 +1114,19 @@ static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, fl
             // rays per lane x ~130 steps per ray (measured average on the benchmark scenes) -- and no more than the cap
             // (crt_tuning::shadow_budget).  A rank that renders 1/8 of the tiles gets 1/8 of the budget.
             const uint64_t lanes = (uint64_t)ctx->num_cus * (side_per_cu ? side_per_cu : 8u) * BLOCK;
-            const uint64_t est = (uint64_t)n_items * 64u * (ctx->n_lights ? ctx->n_lights : 1u) * 130u / (lanes ? lanes : 1u);
+            const uint64_t est = (uint64_t)vitems * 64u * (ctx->n_lights ? ctx->n_lights : 1u) * 130u / (lanes ? lanes : 1u);
             uint32_t budget = est > ctx->tuning.shadow_budget ? ctx->tuning.shadow_budget : (uint32_t)est;
             if (budget < ctx->step_budget) budget = std::min(ctx->step_budget, ctx->tuning.shadow_budget);
             S.step_budget = heavy ? budget : 0u;
         }
         // a completed frame of this size (one that overflowed stopped early: its levels' counts say nothing)
-        const uint32_t *prev = ctx->last_counts_items == n_items && !ctx->last_counts[SC_OVERFLOW] ? ctx->last_counts.data() : nullptr;
+        const uint32_t *prev = ctx->last_counts_items == vitems && ctx->last_counts_cfg == frame_config_of(o) && !ctx->last_counts[SC_OVERFLOW] ? ctx->last_counts.data() : nullptr;
         // (under the wide plan a ray crosses dozens of small mesh trees: a walk of a thousand steps is the rule there, not the outlier the
         //  wave-per-ray kernel is for -- measured on tools/many_meshes.py 200: 32.7 ms per frame with the plain budget, 25.4 with four times it)
-        const uint32_t level_budget = wide ? std::min<uint32_t>(ctx->step_budget * 4u, 1u << 20) : ctx->step_budget;
+        // (the same holds for a GI frame's levels -- millions of incoherent rays each: tools/gi_time.py hw14 960x540 d3 n2 r2 54.7 ms -> 44.2)
+        const uint32_t level_budget = (wide || gi) ? std::min<uint32_t>(ctx->step_budget * 4u, 1u << 20) : ctx->step_budget;
         // the same reasoning for level 0 (one launch over all primary rays, ~70 steps per ray)
-        const uint64_t est0 = (uint64_t)n_items * 64u * 70u / ((uint64_t)lane_blocks * BLOCK);
+        const uint64_t est0 = (uint64_t)vitems * 64u * 70u / ((uint64_t)lane_blocks * BLOCK);
         uint32_t budget0 = est0 >= level_budget ? level_budget : (est0 < 64u ? 64u : (uint32_t)est0);
         if (ctx->tuning.level0_budget) budget0 = ctx->tuning.level0_budget;
         for (uint32_t g = 0; g <= o->max_depth; g++) {
@@ -1093,13 +1140,15 @@ static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, fl
                 const uint32_t want = was < F.heavy_level_threshold ? 64u : std::max<uint32_t>((uint32_t)ctx->num_cus, (was + was / 2u + BLOCK - 1) / BLOCK);
                 level_blocks = std::min(lane_blocks, want);
             }
-            if (count) launch(stream_trace_shade<true>, lane_blocks, stream, A, g);
-            else if (wide) launch_lds(stream_trace_shade_plan_wide, level_blocks, plds, stream, A, g);
-            else if (lean) launch_lds(stream_trace_shade_plan, level_blocks, plds, stream, A, g);
+            if (count) { if (gi) launch(stream_trace_shade<true, true>, lane_blocks, stream, A, g); else launch(stream_trace_shade<true>, lane_blocks, stream, A, g); }
+            else if (wide) launch_lds(gi ? stream_trace_shade_plan_wide_gi : stream_trace_shade_plan_wide, level_blocks, plds, stream, A, g);
+            else if (lean) launch_lds(gi ? stream_trace_shade_plan_gi : stream_trace_shade_plan, level_blocks, plds, stream, A, g);
+            else if (gi) launch(stream_trace_shade<false, true>, lane_blocks, stream, A, g);
             else launch(stream_trace_shade<false>, lane_blocks, stream, A, g);
             if (heavy) {
-                launch(heavy_trace_closest, HEAVY_BLOCKS, stream, A, g);
-                launch(stream_shade_evicted<false>, 256u, stream, A, g);
+                launch(gi ? heavy_trace_closest_gi : heavy_trace_closest, HEAVY_BLOCKS, stream, A, g);
+                if (gi) launch(stream_shade_evicted<false, true>, 256u, stream, A, g);
+                else launch(stream_shade_evicted<false>, 256u, stream, A, g);
             }
             if (g == 0) {
                 // where level 0's shadow rays end; they start now, on the side stream, beside the deeper levels
@@ -1134,9 +1183,11 @@ static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, fl
         {
             // few rays, all tail: the short budget of the levels, or less when this launch is small (the deeper levels
             // queue about a quarter of a shadow ray per pixel on the benchmark scenes)
-            const uint64_t rays1 = prev && prev[SC_SHADOW] >= prev[SC_SHADOW_SPLIT] ? prev[SC_SHADOW] - prev[SC_SHADOW_SPLIT] : (uint64_t)n_items * 16u;
+            const uint64_t rays1 = prev && prev[SC_SHADOW] >= prev[SC_SHADOW_SPLIT] ? prev[SC_SHADOW] - prev[SC_SHADOW_SPLIT] : (uint64_t)vitems * 16u;
             const uint64_t est1 = rays1 * 130u / ((uint64_t)lane_blocks * BLOCK);
-            S1.step_budget = heavy ? (est1 >= level_budget ? level_budget : (est1 < 64u ? 64u : (uint32_t)est1)) : 0u;
+            // (a GI frame queues most of its shadow rays here -- tens of millions: then this pass is a bulk pass like pass 0 and gets its cap)
+            const uint32_t cap1 = std::max(level_budget, ctx->tuning.shadow_budget);
+            S1.step_budget = heavy ? (est1 >= cap1 ? cap1 : (est1 < 64u ? 64u : (uint32_t)est1)) : 0u;
         }
         if (count) launch(stream_trace_shadow<true>, lane_blocks, stream, S1, 1u);
         else if (wide) launch(stream_trace_shadow_plan_wide<1>, lane_blocks, stream, S1);
@@ -1151,9 +1202,12 @@ static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, fl
         if (count) launch(stream_resolve<true>, lane_blocks, stream, A);
         else launch(stream_resolve<false>, lane_blocks, stream, A);
         A.only_if_overflow = 1;
+        const uint32_t fallback_blocks = std::max(1u, std::min(ctx->grid_blocks, (n_items * 64u + BLOCK - 1) / BLOCK));
         if (!last_resort) {}  // a probing attempt (launch_render): the host looks at the overflow word itself
-        else if (count) launch(render_lanes<true>, lane_blocks, stream, A);
-        else launch(render_lanes<false>, lane_blocks, stream, A);
+        else if (gi && count) launch(render_lanes<true, true>, fallback_blocks, stream, A);
+        else if (gi) launch(render_lanes<false, true>, fallback_blocks, stream, A);
+        else if (count) launch(render_lanes<true>, fallback_blocks, stream, A);
+        else launch(render_lanes<false>, fallback_blocks, stream, A);
         CRT_HIP_CHECK(ctx, hipGetLastError());
     } else {
         CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev1[slot], stream));
@@ -1169,7 +1223,8 @@ static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, fl
     uint32_t *h = ctx->h_ring + (size_t)slot * crt_ctx::H_SLOT_WORDS;
     if (stream_mode) CRT_HIP_CHECK(ctx, hipMemcpyAsync(h, ctx->d_scounts, SC_ALLOC_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     CRT_HIP_CHECK(ctx, hipMemcpyAsync(h + SC_ALLOC_WORDS, ctx->d_fallback_total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    ctx->slot_items[slot] = stream_mode ? n_items : 0u;
+    ctx->slot_items[slot] = stream_mode ? vitems : 0u;
+    ctx->slot_cfg[slot] = frame_config_of(o);
     CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev3[slot], stream));
     CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev4[slot], stream));
     ctx->launches++;
@@ -1178,15 +1233,16 @@ static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, fl
 
 // A frame whose queues are not yet known to fit -- the first of its size on this context, or the one after a frame that
 // overflowed -- is PROBED: the stream pass is enqueued without the queue-less fallback behind it, the call waits for it and
-// reads its overflow word, and an attempt that did not fit is repeated with four times the queues until it
+// reads its overflow word, and an attempt that did not fit is repeated with queues sized by what it learnt (grow_queue_sizing) until it
 // does; every attempt ends early at the first overflow, so a failed one costs less than a frame.  Once a frame of this size has
 // completed without overflow the call is asynchronous again, with render_lanes behind the stream pass as the last resort for a
 // frame that outgrows its queues all the same (and for explicit capacities, crt_tuning, which are never regrown).
 static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, float *d_out, uint32_t packed, hipStream_t stream) {
-    const bool stream_mode = ctx->mode == crt_ctx::MODE_STREAM && !o->use_gi;
+    const bool stream_mode = ctx->mode == crt_ctx::MODE_STREAM && (!o->use_gi || gi_fits_stream(o, n_items));
     const bool fixed_caps = ctx->tuning.node_cap || ctx->tuning.ray_cap || ctx->tuning.shadow_cap;
+    const uint32_t vitems = stream_mode ? n_items * level0_samples_of(o) : n_items;
     harvest_counts(ctx);
-    const bool proven = ctx->last_counts_items == n_items && ctx->last_counts[SC_OVERFLOW] == 0;
+    const bool proven = ctx->last_counts_items == vitems && ctx->last_counts_cfg == frame_config_of(o) && ctx->last_counts[SC_OVERFLOW] == 0;
     if (!stream_mode || fixed_caps || proven || n_items == 0) return launch_frame(ctx, o, n_items, d_out, packed, stream, true);
     for (int attempt = 0;; attempt++) {
         const bool last = attempt == 5;
@@ -1195,10 +1251,10 @@ static int launch_render(crt_ctx *ctx, const crt_options *o, uint32_t n_items, f
         if (rc || last) return rc;
         CRT_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev4[slot]));
         harvest_counts(ctx);
-        if (ctx->last_counts_items != n_items) { ctx->error = "internal: a probing frame left no counters"; return CRT_ERR_HIP; }
+        if (ctx->last_counts_items != vitems) { ctx->error = "internal: a probing frame left no counters"; return CRT_ERR_HIP; }
         if (!ctx->last_counts[SC_OVERFLOW]) return CRT_OK;
         ctx->regrows++;
-        const bool can_grow = !ctx->last_counts[SC_GUARD] && grow_queue_sizing(ctx, n_items, 4.0);
+        const bool can_grow = !ctx->last_counts[SC_GUARD] && grow_queue_sizing(ctx, vitems, o->max_depth);
         if (!can_grow) return launch_frame(ctx, o, n_items, d_out, packed, stream, true);  // (a walk beyond its bound, or no memory to grow into)
     }
 }

@@ -86,6 +86,9 @@ struct SceneArgs {
     uint32_t plan_ok;             // the plan kernels may be used
     uint32_t plan_leaves;         // number of top-level leaves (plan_ok: <= 64)
     const float4 *plan_boxes;     // 4 x float4 per leaf: {lo, first entry in leaf_meshes} {hi, number of entries} {shadow mask words 0..3} {words 4..7}
+    const float4 *plan_boxes_all; // the same leaves with masks over EVERY mesh (GI mode: shadow rays do not skip refractive meshes); order plan_shadow_mesh_all
+    const uint32_t *plan_shadow_mesh_all;
+    uint32_t plan_shadow_bits_all;
     const float4 *plan_groups;    // the wide plan: 2 x float4 per group of 16 consecutive leaves: {union lo, first leaf} {union hi, leaves}
     uint32_t plan_group_count;
     uint32_t plan_wide;           // the wide plan kernels may be used (more than 64 leaves or meshes, at most 256 meshes); plan_ok is then 0
@@ -125,7 +128,8 @@ struct FrameArgs {
     float4 *s_hits;               // closest-hit records of evicted rays: {t, triangle, mesh, have}
     uint32_t heavy_level_threshold; // a recursion level with fewer rays than this goes to heavy_trace whole
     uint32_t fixed0;              // level 0's shadow rays go to fixed, tile-ordered slots (kernel_stream.h: level0_shadow_slot)
-    uint32_t use_gi, gi_samples, rays_per_pixel, gi_seed;  // crt_options: the GI / multi-sample mode (kernel_lane.h, gi_random.h)
+    uint32_t use_gi, gi_samples, rays_per_pixel, gi_seed;  // crt_options: the GI / multi-sample mode (kernel_stream.h, kernel_lane.h, gi_random.h)
+    uint32_t level0_samples;      // rays per pixel at level 0 of the ray-stream pass: max(1, rays_per_pixel) in the GI mode, else 1
     float monte_carlo_bias;
 };
 

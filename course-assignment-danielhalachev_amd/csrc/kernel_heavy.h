@@ -211,7 +211,7 @@ __device__ __forceinline__ void heavy_tiny_meshes(const KernelArgs &A, const Ray
     const uint32_t flags = valid ? A.s->tiny_flags[lane] : 0u;
     const float4 b0 = A.s->hbox[2 * at], b1 = A.s->hbox[2 * at + 1];
     if (A.exec_count) H.nbox += A.s->tiny_count;
-    const bool hit = valid && !(SHADOW && (flags & 1u)) && slab_test(R, b0.x, b0.y, b0.z, b1.x, b1.y, b1.z);
+    const bool hit = valid && !(SHADOW && (flags & 1u) && !A.f->use_gi) && slab_test(R, b0.x, b0.y, b0.z, b1.x, b1.y, b1.z);
     unsigned long long m = __ballot(hit);
     if (!m) return;
     const uint32_t begin = __float_as_uint(b0.w), count = __float_as_uint(b1.w);
@@ -303,7 +303,7 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, TopRegs &TR, con
     const bool fast = A.s->top_fast != 0;
     // one mesh of a top-level leaf's list, in list order; false: the walk is over (a shadow ray found its occluder)
     auto visit_mesh = [&](const uint32_t mi, const uint32_t mflags, const uint32_t mpad) -> bool {
-        if ((SHADOW && (mflags & 1u)) || mesh_walk_is_repeat(seen, mi)) return true;  // (kernel_common.h: every mesh once per ray)
+        if ((SHADOW && (mflags & 1u) && !A.f->use_gi) || mesh_walk_is_repeat(seen, mi)) return true;  // (AccelerationStructure.cpp:66-71: not in the GI mode)  // (kernel_common.h: every mesh once per ray)
         if (mpad) {  // a single-leaf mesh: its result has been waiting in lane pad - 1 since the start of the ray
             const int k = (int)mpad - 1;
             H.mhave = __builtin_amdgcn_readlane((int)T.have, k) != 0;
@@ -403,7 +403,8 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, TopRegs &TR, con
 __device__ __forceinline__ float uniform_f(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
 
 // closest hits of the rays evicted from stream_trace_shade(gen); results go to s_hits[k] for list entry k
-__global__ __launch_bounds__(BLOCK, 5) void heavy_trace_closest(const KernelArgs A, const uint32_t gen) {
+template <bool GI>
+__device__ __forceinline__ void heavy_closest_level(const KernelArgs &A, const uint32_t gen) {
     if (A.wave_prio) __builtin_amdgcn_s_setprio(3);  // ahead of the bulk shadow pass's waves on this SIMD
     const uint32_t lane = threadIdx.x & 63u;
     if (A.f->s_counts[SC_OVERFLOW]) return;
@@ -425,9 +426,7 @@ __global__ __launch_bounds__(BLOCK, 5) void heavy_trace_closest(const KernelArgs
         Ray R;
         bool primary = false;
         if (gen == 0) {
-            const WorkItem wi = A.f->items[r >> 6];
-            const uint32_t sub = r & 63u;
-            primary_ray(A, (wi.tile % A.s->tiles_x) * TILE + (sub & 7u), (wi.tile / A.s->tiles_x) * TILE + (sub >> 3), R);
+            level0_ray<GI>(A, level0_decode<GI>(A, r), R);
             primary = true;
         } else {
             const float4 q0 = in_q[2 * (size_t)r], q1 = in_q[2 * (size_t)r + 1];
@@ -446,6 +445,8 @@ __global__ __launch_bounds__(BLOCK, 5) void heavy_trace_closest(const KernelArgs
         if (lane == 0) A.f->s_hits[k] = make_float4(bt, __uint_as_float(btri), __uint_as_float(bmesh), __uint_as_float(have ? 1u : 0u));
     }
 }
+__global__ __launch_bounds__(BLOCK, 5) void heavy_trace_closest(const KernelArgs A, const uint32_t gen) { heavy_closest_level<false>(A, gen); }
+__global__ __launch_bounds__(BLOCK, 5) void heavy_trace_closest_gi(const KernelArgs A, const uint32_t gen) { heavy_closest_level<true>(A, gen); }  // (level 0: jittered samples)
 
 // part 0: the walks shadow pass 0 gave up (list entries below the SC_SHEAVY_SPLIT mark), on the side stream right
 // after that pass; part 1: the rest, after the last pass.

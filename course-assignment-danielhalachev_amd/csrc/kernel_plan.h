@@ -45,6 +45,11 @@ __device__ __forceinline__ v8f plan_group(const KernelArgs &A, uint32_t g) {
 __device__ __forceinline__ v16f plan_leaf(const KernelArgs &A, uint32_t k) {
     return *(kv16p)((kfp)(const float *)A.s->plan_boxes + PLAN_LEAF_DWORDS * (size_t)k);
 }
+// the same leaf with the shadow masks of the table `boxes` (plan_boxes: the non-refractive meshes; plan_boxes_all: every mesh -- the
+// GI mode's shadow rays do not skip refractive meshes, AccelerationStructure.cpp:66-71)
+__device__ __forceinline__ v16f plan_leaf_of(const float4 *boxes, uint32_t k) {
+    return *(kv16p)((kfp)(const float *)boxes + PLAN_LEAF_DWORDS * (size_t)k);
+}
 
 // Leaf cursor of the plan kernels: bits 0..23 = the next entry of the leaf, bits 24..30 = entries that follow it (compact
 // leaf links, KernelArgs::pnodes); NONE = not inside a leaf.
@@ -57,7 +62,13 @@ constexpr uint32_t SHADOW_NODE_REPEAT = 2;  // node steps per loop trip (measure
 template <uint32_t WORDS>  // 32-bit words of a ray's mesh mask: 2 (the plan proper: <= 64 leaves, <= 64 meshes) or 8 (the wide plan)
 __device__ __forceinline__ void shadow_plan_walks(const KernelArgs &A, const uint32_t first, const uint32_t total, uint32_t *cursor) {
     __shared__ uint32_t root_of_bit[32 * WORDS];  // shadow order -> root node of the mesh's tree
-    if (threadIdx.x < 32u * WORDS) root_of_bit[threadIdx.x] = threadIdx.x < A.s->plan_shadow_bits ? A.s->meshes[A.s->plan_shadow_mesh[threadIdx.x]].root : END;
+    const bool every_mesh = A.f->use_gi != 0;     // (uniform over the launch)
+    const float4 *leaf_table = every_mesh ? A.s->plan_boxes_all : A.s->plan_boxes;
+    {
+        const uint32_t bits = every_mesh ? A.s->plan_shadow_bits_all : A.s->plan_shadow_bits;
+        const uint32_t *order = every_mesh ? A.s->plan_shadow_mesh_all : A.s->plan_shadow_mesh;
+        if (threadIdx.x < 32u * WORDS) root_of_bit[threadIdx.x] = threadIdx.x < bits ? A.s->meshes[order[threadIdx.x]].root : END;
+    }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     if (A.f->s_counts[SC_OVERFLOW]) return;
@@ -110,7 +121,7 @@ __device__ __forceinline__ void shadow_plan_walks(const KernelArgs &A, const uin
                 for (uint32_t w = 0; w < WORDS; w++) acc[w] = 0;
                 if constexpr (WORDS == 2) {
                     for (uint32_t k = 0; k < A.s->plan_leaves; k++) {
-                        const v16f L = plan_leaf(A, k);
+                        const v16f L = plan_leaf_of(leaf_table, k);
                         const bool hit = slab_test_no_parallel(R, L[0], L[1], L[2], L[4], L[5], L[6]);
                         acc[0] |= hit ? __float_as_uint(L[8]) : 0u;
                         acc[1] |= hit ? __float_as_uint(L[9]) : 0u;
@@ -123,7 +134,7 @@ __device__ __forceinline__ void shadow_plan_walks(const KernelArgs &A, const uin
                         const uint32_t k0 = __builtin_amdgcn_readfirstlane(__float_as_uint(G[3]));
                         const uint32_t n = __ballot(gh) ? __builtin_amdgcn_readfirstlane(__float_as_uint(G[7])) : 0u;
                         for (uint32_t k = k0; k < k0 + n; k++) {
-                            const v16f L = plan_leaf(A, k);
+                            const v16f L = plan_leaf_of(leaf_table, k);
                             const bool hit = slab_test_no_parallel(R, L[0], L[1], L[2], L[4], L[5], L[6]);
 #pragma unroll
                             for (uint32_t w = 0; w < WORDS; w++) acc[w] |= hit ? __float_as_uint(L[8 + w]) : 0u;
@@ -306,7 +317,7 @@ __device__ __forceinline__ uint32_t plan_list_pop(PlanList &PL) {
 // threaded nodes, material dispatch.  WIDE: the wide plan (SceneArgs::plan_wide).  Rays with a parallel axis and walks longer than the step budget go to heavy_trace_closest.
 // (Measured and removed, DESIGN.md section 7: 4-wide quad nodes with an LDS stack -- the same frame time; the same nearest slot
 // first with exact distance pruning on loose boxes -- grazing rays, the long walks, have nothing to prune before they hit.)
-template <bool WIDE>
+template <bool WIDE, bool GI>
 __device__ __forceinline__ void shade_plan_level(const KernelArgs &A, const uint32_t gen) {
     if (A.wave_prio) __builtin_amdgcn_s_setprio(3);  // ahead of the bulk shadow pass's waves on this SIMD
     extern __shared__ uint32_t plan_lds[];  // mesh lists: A.s->plan_list_words x BLOCK
@@ -343,16 +354,13 @@ __device__ __forceinline__ void shade_plan_level(const KernelArgs &A, const uint
                 r = wave_fetch(A.f->s_counts + SC_FETCH + gen, lane);
                 if (r >= count) { state = ST_DONE; break; }
                 if (gen == 0) {
-                    const WorkItem wi = A.f->items[r >> 6];
-                    const uint32_t sub = r & 63u;
-                    const uint32_t px = (wi.tile % A.s->tiles_x) * TILE + (sub & 7u);
-                    const uint32_t py = (wi.tile / A.s->tiles_x) * TILE + (sub >> 3);
-                    if (!((wi.mask >> sub) & 1ull) || px >= A.s->width || py >= A.s->height) {
+                    const Level0Ray P = level0_decode<GI>(A, r);
+                    if (!P.covered) {
                         reinterpret_cast<uint32_t *>(A.f->s_nodes + 2 * (size_t)r)[3] = TN_SKIP;
                         level0_release_shadow_slots(A, r);
                         continue;
                     }
-                    primary_ray(A, px, py, R);
+                    level0_ray<GI>(A, P, R);
                 } else {
                     const float4 q0 = in_q[2 * (size_t)r], q1 = in_q[2 * (size_t)r + 1];
                     R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
@@ -444,7 +452,7 @@ __device__ __forceinline__ void shade_plan_level(const KernelArgs &A, const uint
             }
             if (done) {
                 if (have) btri = A.s->leaf_tris[btri] & ~LAST;  // leaf entry -> triangle
-                shade_and_emit<false>(A, gen, r, node_base, child_base, R, have, bt, btri, bmesh, nullptr, lane);
+                shade_and_emit<false, GI>(A, gen, r, node_base, child_base, R, have, bt, btri, bmesh, nullptr, lane);
                 state = ST_FETCH;
             } else if (steps >= A.step_budget) {
                 if (evict_ray(A.f->s_heavy, A.f->s_heavy_cap, A.f->s_counts + SC_HEAVY + gen, r, lane)) state = ST_FETCH;
@@ -455,5 +463,8 @@ __device__ __forceinline__ void shade_plan_level(const KernelArgs &A, const uint
     exec_counters_flush(A, nbox, ntri, lane, nplan);
 }
 
-__global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArgs A, const uint32_t gen) { shade_plan_level<false>(A, gen); }
-__global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan_wide(const KernelArgs A, const uint32_t gen) { shade_plan_level<true>(A, gen); }
+__global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArgs A, const uint32_t gen) { shade_plan_level<false, false>(A, gen); }
+__global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan_wide(const KernelArgs A, const uint32_t gen) { shade_plan_level<true, false>(A, gen); }
+// the GI / multi-sample mode's builds (RayTracer.cpp:90-104, 331-354): jittered level-0 samples, gi_samples child rays per diffuse hit
+__global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan_gi(const KernelArgs A, const uint32_t gen) { shade_plan_level<false, true>(A, gen); }
+__global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan_wide_gi(const KernelArgs A, const uint32_t gen) { shade_plan_level<true, true>(A, gen); }

@@ -30,7 +30,10 @@ struct TNode {          // one node of a pixel's ray tree, 32 bytes
     uint32_t pad;
 };
 enum : uint32_t { TN_CONST = 0, TN_DIFFUSE = 1, TN_REFLECT = 2, TN_REFRACT = 3, TN_SKIP = 4, TN_KIND_MASK = 0xFFu,
-                  TN_BITMAP = 0x100u };
+                  TN_BITMAP = 0x100u, TN_PARKED = 0x200u,  // stream_resolve: a partial result is parked in the node
+                  // the GI mode (RayTracer.cpp:331-354): a DIFFUSE node with gi_samples children at consecutive node indices
+                  // from `f` on (CHILD_BG: beyond MAX_DEPTH, background each); resolve counts the finished ones in bits 16..23
+                  TN_GI = 0x400u, TN_GI_DONE_SHIFT = 16 };
 constexpr uint32_t CHILD_BG = 0xFFFFFFFFu;     // child ray beyond MAX_DEPTH: background without tracing (RayTracer.cpp:427-429)
 constexpr uint32_t CHILD_NONE = 0xFFFFFFFEu;   // total internal reflection: no refraction child (RayTracer.cpp:416)
 constexpr int MAX_GENERATIONS = 64;
@@ -46,8 +49,38 @@ static_assert(SC_WORDS <= SC_HEAVY_DIAG, "counter block too small");
 
 static_assert(SC_OVERFLOW == SC_OVERFLOW_WORD, "kernel_common.h SC_OVERFLOW_WORD must match");
 
+// Level 0 holds level0_samples rays per pixel (the GI mode's RAYS_PER_PIXEL, RayTracer.cpp:90-104; otherwise one): ray r is
+// pixel r & 63 of work item (r >> 6) % n_items, sample (r >> 6) / n_items -- the samples are whole copies of the item list, so
+// that 64 consecutive rays are still one 8x8 tile and the fixed shadow slots (below) keep their layout.
 __device__ __forceinline__ uint32_t stream_level_count(const KernelArgs &A, uint32_t g) {
-    return g == 0 ? A.f->n_items * 64u : A.f->s_counts[SC_COUNT + g];
+    return g == 0 ? A.f->n_items * 64u * A.f->level0_samples : A.f->s_counts[SC_COUNT + g];
+}
+struct Level0Ray { uint32_t item, sub, sample, px, py; bool covered; };
+template <bool GI>  // (the kernels of the GI mode are builds of their own: the plain ones carry none of its code)
+__device__ __forceinline__ Level0Ray level0_decode(const KernelArgs &A, const uint32_t r) {
+    Level0Ray P;
+    const uint32_t slot = r >> 6;
+    P.sample = GI && A.f->level0_samples > 1u ? slot / A.f->n_items : 0u;
+    P.item = slot - P.sample * A.f->n_items;
+    P.sub = r & 63u;
+    const WorkItem wi = A.f->items[P.item];
+    P.px = (wi.tile % A.s->tiles_x) * TILE + (P.sub & 7u);
+    P.py = (wi.tile / A.s->tiles_x) * TILE + (P.sub >> 3);
+    P.covered = ((wi.mask >> P.sub) & 1ull) && P.px < A.s->width && P.py < A.s->height;
+    return P;
+}
+// the key of the shootRay invocation of level-0 ray P (gi_random.h)
+__device__ __forceinline__ uint32_t level0_key(const KernelArgs &A, const Level0Ray &P) {
+    return crt_gi_mix(crt_gi_mix(A.f->gi_seed, P.py * A.s->width + P.px), P.sample);
+}
+// getRay for it: the pixel centre, or -- samples 1 .. RAYS_PER_PIXEL-1 -- a jittered position (RayTracer.cpp:61-80, 96)
+template <bool GI>
+__device__ __forceinline__ void level0_ray(const KernelArgs &A, const Level0Ray &P, Ray &R) {
+    if (!GI || P.sample == 0u) { primary_ray(A, P.px, P.py, R); return; }
+    if constexpr (GI) {
+        const uint32_t key = level0_key(A, P);
+        primary_ray_offset(A, P.px, P.py, crt_gi_uniform(key, 0u), crt_gi_uniform(key, 1u), R);
+    }
 }
 // Levels below the threshold skip the per-lane kernel: list entry k of the wave-per-ray kernel is ray k itself.
 // (force_whole: the host did not launch the per-lane kernel for this level at all -- a frame ago the level was far below the
@@ -105,10 +138,12 @@ struct Shaded {
     bool reflect, transmit;  // child rays to trace (false beyond MAX_DEPTH: such a child is background without tracing)
     float rox, roy, roz, rdx, rdy, rdz;   // reflection ray (both mirror materials)
     float tox, toy, toz, tdx, tdy, tdz;   // transmission ray
+    bool gi;                               // a diffuse hit in the GI mode whose gi_samples child rays are to be traced
+    float hpx, hpy, hpz, hnx, hny, hnz;   // ... its hit point and normal (the sample directions: gi_sample_direction)
 };
 
 // Called by every lane whose walk has just ended (any subset of the wave); shadow-slot allocation is aggregated over them.
-template <bool COUNT>
+template <bool COUNT, bool GI>
 __device__ __forceinline__ void shade_hit(const KernelArgs &A, const uint32_t gen, const uint32_t r, const Ray &R, const bool have,
                                           const float bt, const uint32_t btri, const uint32_t bmesh, uint32_t *cnt,
                                           const uint32_t lane, Shaded &E, bool *out_diffuse = nullptr,
@@ -118,7 +153,8 @@ __device__ __forceinline__ void shade_hit(const KernelArgs &A, const uint32_t ge
     TNode &N = E.N;
     N.cx = A.s->bgx; N.cy = A.s->bgy; N.cz = A.s->bgz;
     N.kind = TN_CONST; N.a = 0; N.b = 0; N.f = 0; N.pad = 0;
-    E.reflect = false; E.transmit = false;
+    E.reflect = false; E.transmit = false; E.gi = false;
+    E.hpx = E.hpy = E.hpz = E.hnx = E.hny = E.hnz = 0;
     E.rox = E.roy = E.roz = E.rdx = E.rdy = E.rdz = 0;
     E.tox = E.toy = E.toz = E.tdx = E.tdy = E.tdz = 0;
     if (have) {
@@ -147,9 +183,14 @@ __device__ __forceinline__ void shade_hit(const KernelArgs &A, const uint32_t ge
                 A.f->s_counts[SC_OVERFLOW] = 1;
                 N.cx = N.cy = N.cz = 0;  // the frame is redone by the fallback path
             } else {
-                N.kind = TN_DIFFUSE | (bitmap ? TN_BITMAP : 0u);
+                N.kind = TN_DIFFUSE | (bitmap ? TN_BITMAP : 0u) | (GI ? TN_GI : 0u);
                 N.a = base + rank;
                 N.b = cntd;
+                if constexpr (GI) {  // the indirect term's child rays enter shootRay at depth gen + 1 (RayTracer.cpp:349-350)
+                    N.f = __uint_as_float(CHILD_BG);
+                    E.gi = spawn_allowed && A.f->gi_samples > 0u;
+                    E.hpx = S.px; E.hpy = S.py; E.hpz = S.pz; E.hnx = S.nx; E.hny = S.ny; E.hnz = S.nz;
+                }
                 if (out_diffuse) { *out_diffuse = true; *out_first = N.a; *out_stride = cntd; }
                 for (uint32_t li = 0; li < A.s->n_lights; li++) {
                     Ray SR;
@@ -216,50 +257,65 @@ __device__ __forceinline__ void store_tnode(const KernelArgs &A, const size_t in
     dst[1] = make_float4(__uint_as_float(N.a), __uint_as_float(N.b), N.f, 0.0f);
 }
 
-// A child ray in a closest-hit queue: {origin, recursion level} {direction, index of its ray-tree node}
+// A child ray in a closest-hit queue: {origin, key of its shootRay invocation (GI mode; gi_random.h)} {direction, index of its ray-tree node}
 __device__ __forceinline__ void store_child_ray(float4 *q, const size_t index, const float ox, const float oy, const float oz,
-                                                const float dx, const float dy, const float dz, const uint32_t level,
+                                                const float dx, const float dy, const float dz, const uint32_t key,
                                                 const uint32_t node) {
-    q[2 * index] = make_float4(ox, oy, oz, __uint_as_float(level));
+    q[2 * index] = make_float4(ox, oy, oz, __uint_as_float(key));
     q[2 * index + 1] = make_float4(dx, dy, dz, __uint_as_float(node));
 }
 
 // shade_hit + the per-level queues: ray `r` of level `gen` writes node node_base + r, its children are appended to the
-// queue of level gen+1 (child k of that queue owns node child_base + k).  Allocations are aggregated over the calling lanes.
-template <bool COUNT>
+// queue of level gen+1 (child k of that queue owns node child_base + k).  Allocations are aggregated over the calling lanes:
+// the reflection rays, then the transmission rays, then -- GI mode -- gi_samples consecutive rays per diffuse hit.
+template <bool COUNT, bool GI>
 __device__ __forceinline__ void shade_and_emit(const KernelArgs &A, const uint32_t gen, const uint32_t r, const uint32_t node_base,
                                        const uint32_t child_base, const Ray &R, const bool have, const float bt,
                                        const uint32_t btri, const uint32_t bmesh, uint32_t *cnt, const uint32_t lane,
                                        bool *out_diffuse = nullptr, uint32_t *out_first = nullptr, uint32_t *out_stride = nullptr) {
     Shaded E;
-    shade_hit<COUNT>(A, gen, r, R, have, bt, btri, bmesh, cnt, lane, E, out_diffuse, out_first, out_stride);
-    if (E.reflect) {
+    shade_hit<COUNT, GI>(A, gen, r, R, have, bt, btri, bmesh, cnt, lane, E, out_diffuse, out_first, out_stride);
+    constexpr bool gi_mode = GI;
+    if (E.reflect || (GI && E.gi)) {
         float4 *out_q = A.f->s_rayq[(gen + 1u) & 1u];
         uint32_t *out_count = A.f->s_counts + SC_COUNT + gen + 1;
-        // wave-aggregated append of 1 or 2 child rays per lane
-        const unsigned long long m1 = __ballot(1), m2 = __ballot(E.transmit);
+        // this invocation's key: the children's keys and the sample directions' random numbers derive from it
+        uint32_t key = 0;
+        if constexpr (GI) key = gen == 0 ? level0_key(A, level0_decode<true>(A, r)) : __float_as_uint(A.f->s_rayq[gen & 1u][2 * (size_t)r].w);
+        // wave-aggregated append of 1 or 2 (mirror materials) or gi_samples (diffuse, GI mode) child rays per lane
+        const unsigned long long m0 = __ballot(1), m1 = __ballot(E.reflect), m2 = __ballot(E.transmit), m3 = GI ? __ballot(E.gi) : 0ull;
         const unsigned long long below = (1ull << lane) - 1ull;
-        const uint32_t n1 = (uint32_t)__popcll(m1), n2 = (uint32_t)__popcll(m2);
+        const uint32_t n1 = (uint32_t)__popcll(m1), n2 = (uint32_t)__popcll(m2), n3 = GI ? (uint32_t)__popcll(m3) * A.f->gi_samples : 0u;
         uint32_t base = 0;
-        if ((m1 & below) == 0) base = atomicAdd(out_count, n1 + n2);
-        base = __shfl(base, __ffsll((long long)m1) - 1);
-        if ((uint64_t)base + n1 + n2 > A.f->s_ray_cap || (uint64_t)child_base + base + n1 + n2 > A.f->s_node_cap) {
+        if ((m0 & below) == 0) base = atomicAdd(out_count, n1 + n2 + n3);
+        base = __shfl(base, __ffsll((long long)m0) - 1);
+        if ((uint64_t)base + n1 + n2 + n3 > A.f->s_ray_cap || (uint64_t)child_base + base + n1 + n2 + n3 > A.f->s_node_cap) {
             A.f->s_counts[SC_OVERFLOW] = 1;
-        } else {
+        } else if (E.reflect) {
             const uint32_t i1 = base + (uint32_t)__popcll(m1 & below);
-            store_child_ray(out_q, i1, E.rox, E.roy, E.roz, E.rdx, E.rdy, E.rdz, gen + 1u, child_base + i1);
+            store_child_ray(out_q, i1, E.rox, E.roy, E.roz, E.rdx, E.rdy, E.rdz, gi_mode ? crt_gi_child_key(key, 0u) : gen + 1u, child_base + i1);
             E.N.a = child_base + i1;
             if (E.transmit) {
                 const uint32_t i2 = base + n1 + (uint32_t)__popcll(m2 & below);
-                store_child_ray(out_q, i2, E.tox, E.toy, E.toz, E.tdx, E.tdy, E.tdz, gen + 1u, child_base + i2);
+                store_child_ray(out_q, i2, E.tox, E.toy, E.toz, E.tdx, E.tdy, E.tdz, gi_mode ? crt_gi_child_key(key, 1u) : gen + 1u, child_base + i2);
                 E.N.b = child_base + i2;
             }
+        } else if constexpr (GI) {
+            // RayTracer.cpp:333-350: sample i's direction from the invocation's numbers 2 + 2i, 3 + 2i, its origin off the surface
+            const uint32_t i3 = base + n1 + n2 + (uint32_t)__popcll(m3 & below) * A.f->gi_samples;
+            for (uint32_t i = 0; i < A.f->gi_samples; i++) {
+                float dx, dy, dz;
+                gi_sample_direction(R.dx, R.dy, R.dz, E.hnx, E.hny, E.hnz, crt_gi_uniform(key, 2u + 2u * i), crt_gi_uniform(key, 3u + 2u * i), dx, dy, dz);
+                store_child_ray(out_q, i3 + i, E.hpx + E.hnx * A.f->monte_carlo_bias, E.hpy + E.hny * A.f->monte_carlo_bias,
+                                E.hpz + E.hnz * A.f->monte_carlo_bias, dx, dy, dz, crt_gi_child_key(key, 2u + i), child_base + i3 + i);
+            }
+            E.N.f = __uint_as_float(child_base + i3);
         }
     }
     store_tnode(A, (size_t)node_base + r, E.N);
 }
 
-template <bool COUNT>
+template <bool COUNT, bool GI = false>
 __global__ __launch_bounds__(BLOCK) void stream_trace_shade(const KernelArgs A, const uint32_t gen) {
     const uint32_t lane = threadIdx.x & 63u;
     if (A.f->s_counts[SC_OVERFLOW]) return;  // the fallback path redoes the frame
@@ -284,16 +340,13 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade(const KernelArgs A, 
                 r = wave_fetch(A.f->s_counts + SC_FETCH + gen, lane);
                 if (r >= count) { state = ST_DONE; break; }
                 if (gen == 0) {
-                    const WorkItem wi = A.f->items[r >> 6];
-                    const uint32_t sub = r & 63u;
-                    const uint32_t px = (wi.tile % A.s->tiles_x) * TILE + (sub & 7u);
-                    const uint32_t py = (wi.tile / A.s->tiles_x) * TILE + (sub >> 3);
-                    if (!((wi.mask >> sub) & 1ull) || px >= A.s->width || py >= A.s->height) {
+                    const Level0Ray P = level0_decode<GI>(A, r);
+                    if (!P.covered) {
                         reinterpret_cast<uint32_t *>(A.f->s_nodes + 2 * (size_t)r)[3] = TN_SKIP;
                         level0_release_shadow_slots(A, r);
                         continue;
                     }
-                    primary_ray(A, px, py, R);
+                    level0_ray<GI>(A, P, R);
                     L.rtype = RAY_PRIMARY;
                     if (COUNT) cnt[C_PRIMARY]++;
                 } else {
@@ -323,7 +376,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade(const KernelArgs A, 
 
         // ------------------------------------------------------------------ shade, or hand a long walk to heavy_trace
         if (finished) {
-            shade_and_emit<COUNT>(A, gen, r, node_base, child_base, R, L.have, L.bt, L.btri, L.bmesh, cnt, lane);
+            shade_and_emit<COUNT, GI>(A, gen, r, node_base, child_base, R, L.have, L.bt, L.btri, L.bmesh, cnt, lane);
             steps = 0;
             state = ST_FETCH;
         } else if (state == ST_TRAVERSE && A.step_budget && steps >= A.step_budget) {
@@ -350,7 +403,7 @@ __global__ __launch_bounds__(BLOCK) void stream_trace_shade(const KernelArgs A, 
 }
 
 // Shading of the rays stream_trace_shade(gen) evicted, after heavy_trace_closest(gen) has found their hits.
-template <bool COUNT>
+template <bool COUNT, bool GI = false>
 __global__ __launch_bounds__(BLOCK) void stream_shade_evicted(const KernelArgs A, const uint32_t gen) {
     if (A.wave_prio) __builtin_amdgcn_s_setprio(3);  // ahead of the bulk shadow pass's waves on this SIMD
     const uint32_t lane = threadIdx.x & 63u;
@@ -368,9 +421,7 @@ __global__ __launch_bounds__(BLOCK) void stream_shade_evicted(const KernelArgs A
         const uint32_t r = whole ? k : A.f->s_heavy[k];
         Ray R;
         if (gen == 0) {
-            const WorkItem wi = A.f->items[r >> 6];
-            const uint32_t sub = r & 63u;
-            primary_ray(A, (wi.tile % A.s->tiles_x) * TILE + (sub & 7u), (wi.tile / A.s->tiles_x) * TILE + (sub >> 3), R);
+            level0_ray<GI>(A, level0_decode<GI>(A, r), R);
         } else {
             const float4 q0 = in_q[2 * (size_t)r], q1 = in_q[2 * (size_t)r + 1];
             R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
@@ -379,7 +430,7 @@ __global__ __launch_bounds__(BLOCK) void stream_shade_evicted(const KernelArgs A
             ray_prepare(R);
         }
         const float4 h = A.f->s_hits[k];
-        shade_and_emit<COUNT>(A, gen, r, node_base, child_base, R, __float_as_uint(h.w) != 0, h.x, __float_as_uint(h.y),
+        shade_and_emit<COUNT, GI>(A, gen, r, node_base, child_base, R, __float_as_uint(h.w) != 0, h.x, __float_as_uint(h.y),
                               __float_as_uint(h.z), cnt, lane);
     }
     if (COUNT) {
@@ -494,7 +545,8 @@ __device__ __forceinline__ void resolve_leaf(const KernelArgs &A, const float4 &
 }
 
 // Per pixel: evaluate its ray tree in post-order -- reflection subtree, then refraction subtree, then the
-// parent's own expression -- exactly the order of the reference's recursion.
+// parent's own expression; a GI diffuse node: its direct light, then its samples' subtrees one after the other -- exactly the
+// order of the reference's recursion.  GI mode: the pixel's level0_samples trees, summed in order and averaged (RayTracer.cpp:90-104).
 template <bool COUNT>
 __global__ __launch_bounds__(BLOCK) void stream_resolve(const KernelArgs A) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -505,55 +557,90 @@ __global__ __launch_bounds__(BLOCK) void stream_resolve(const KernelArgs A) {
     uint32_t cnt[C_N];
     if (COUNT) for (int k = 0; k < C_N; k++) cnt[k] = 0;
     uint32_t stack[MAX_GENERATIONS];
+    const bool gi_mode = A.f->use_gi != 0;
+    const float gi_inv = 1.0f / (float)(A.f->gi_samples + 1u);  // RayTracer.cpp:352-353
 
     for (uint32_t q = blockIdx.x * BLOCK + threadIdx.x; q < total; q += gridDim.x * BLOCK) {
-        const float4 root0 = nodes[2 * (size_t)q];
-        if ((__float_as_uint(root0.w) & TN_KIND_MASK) == TN_SKIP) continue;
+        if ((__float_as_uint(nodes[2 * (size_t)q].w) & TN_KIND_MASK) == TN_SKIP) continue;  // (coverage is the same for every sample)
+        float sumx = 0, sumy = 0, sumz = 0;
         float cx = 0, cy = 0, cz = 0;
-        int sp = 0;
-        uint32_t cur = q;
-        bool descending = true;
-        // iterative post-order: `descending` = entering node `cur`; otherwise (cx,cy,cz) is the value returned
-        // by the child just finished and stack[sp-1] is its parent.
-        for (;;) {
-            if (descending) {
-                if (cur == CHILD_BG) { cx = A.s->bgx; cy = A.s->bgy; cz = A.s->bgz; descending = false; }
-                else {
-                    const float4 n0 = nodes[2 * (size_t)cur], n1 = nodes[2 * (size_t)cur + 1];
-                    const uint32_t kind = __float_as_uint(n0.w) & TN_KIND_MASK;
-                    if (kind == TN_REFLECT || kind == TN_REFRACT) {
-                        stack[sp++] = cur;
-                        cur = __float_as_uint(n1.x);  // the reflection ray is shot first (RayTracer.cpp:366, 398-400)
-                    } else {
-                        resolve_leaf<COUNT>(A, n0, n1, cx, cy, cz, cnt);
-                        descending = false;
-                    }
-                }
-            }
-            if (!descending) {
-                if (sp == 0) break;
-                const uint32_t p = stack[sp - 1];
-                const float4 p0 = nodes[2 * (size_t)p], p1 = nodes[2 * (size_t)p + 1];
-                const uint32_t kind = __float_as_uint(p0.w);
-                if ((kind & TN_KIND_MASK) == TN_REFLECT) {
-                    cx = 0.0f + p0.x * cx; cy = 0.0f + p0.y * cy; cz = 0.0f + p0.z * cz;  // RayTracer.cpp:368-372
-                    sp--;
-                } else if (kind & 0x200u) {
-                    // both children done: fresnel * reflection + (1 - fresnel) * refraction (RayTracer.cpp:414)
-                    const float f = p1.z;
-                    cx = f * p0.x + (1 - f) * cx; cy = f * p0.y + (1 - f) * cy; cz = f * p0.z + (1 - f) * cz;
-                    sp--;
-                } else {
-                    const uint32_t refr = __float_as_uint(p1.y);
-                    if (refr == CHILD_NONE) { sp--; }  // `return reflectionColor`, RayTracer.cpp:416
+        for (uint32_t sample = 0; sample < A.f->level0_samples; sample++) {
+            int sp = 0;
+            uint32_t cur = sample * total + q;
+            bool descending = true;
+            // iterative post-order: `descending` = entering node `cur`; otherwise (cx,cy,cz) is the value returned
+            // by the child just finished and stack[sp-1] is its parent.
+            for (;;) {
+                if (descending) {
+                    if (cur == CHILD_BG) { cx = A.s->bgx; cy = A.s->bgy; cz = A.s->bgz; descending = false; }
                     else {
-                        // park the reflection colour in the node, mark it, descend into the refraction child
-                        wnodes[2 * (size_t)p] = make_float4(cx, cy, cz, __uint_as_float(kind | 0x200u));
-                        cur = refr;
-                        descending = true;
+                        const float4 n0 = nodes[2 * (size_t)cur], n1 = nodes[2 * (size_t)cur + 1];
+                        const uint32_t kind = __float_as_uint(n0.w) & TN_KIND_MASK;
+                        if (kind == TN_REFLECT || kind == TN_REFRACT) {
+                            stack[sp++] = cur;
+                            cur = __float_as_uint(n1.x);  // the reflection ray is shot first (RayTracer.cpp:366, 398-400)
+                        } else {
+                            resolve_leaf<COUNT>(A, n0, n1, cx, cy, cz, cnt);
+                            if (__float_as_uint(n0.w) & TN_GI) {
+                                if (A.f->gi_samples == 0u) {  // finalColor += (0, 0, 0); return finalColor * (1 / 1)
+                                    cx = (cx + 0.0f) * gi_inv; cy = (cy + 0.0f) * gi_inv; cz = (cz + 0.0f) * gi_inv;
+                                    descending = false;
+                                } else {
+                                    // park the direct light and an empty indirect sum in the node, descend into sample 0
+                                    const uint32_t first = __float_as_uint(n1.z);
+                                    wnodes[2 * (size_t)cur] = make_float4(cx, cy, cz, __uint_as_float((__float_as_uint(n0.w) & 0xFFFFu) | TN_PARKED));
+                                    wnodes[2 * (size_t)cur + 1] = make_float4(0.0f, 0.0f, n1.z, 0.0f);
+                                    stack[sp++] = cur;
+                                    cur = first;
+                                }
+                            } else descending = false;
+                        }
+                    }
+                }
+                if (!descending) {
+                    if (sp == 0) break;
+                    const uint32_t p = stack[sp - 1];
+                    const float4 p0 = nodes[2 * (size_t)p], p1 = nodes[2 * (size_t)p + 1];
+                    const uint32_t kind = __float_as_uint(p0.w);
+                    if ((kind & TN_KIND_MASK) == TN_DIFFUSE) {
+                        // indirectLightContribution += shootRay(sample i) (RayTracer.cpp:350); {x, y, w} of the second word hold the sum
+                        const float ix = p1.x + cx, iy = p1.y + cy, iz = p1.w + cz;
+                        const uint32_t done = (kind >> TN_GI_DONE_SHIFT) + 1u;
+                        if (done < A.f->gi_samples) {
+                            wnodes[2 * (size_t)p] = make_float4(p0.x, p0.y, p0.z, __uint_as_float((kind & 0xFFFFu) | (done << TN_GI_DONE_SHIFT)));
+                            wnodes[2 * (size_t)p + 1] = make_float4(ix, iy, p1.z, iz);
+                            const uint32_t first = __float_as_uint(p1.z);
+                            cur = first == CHILD_BG ? CHILD_BG : first + done;
+                            descending = true;
+                        } else {
+                            cx = (p0.x + ix) * gi_inv; cy = (p0.y + iy) * gi_inv; cz = (p0.z + iz) * gi_inv;  // RayTracer.cpp:351-353
+                            sp--;
+                        }
+                    } else if ((kind & TN_KIND_MASK) == TN_REFLECT) {
+                        cx = 0.0f + p0.x * cx; cy = 0.0f + p0.y * cy; cz = 0.0f + p0.z * cz;  // RayTracer.cpp:368-372
+                        sp--;
+                    } else if (kind & TN_PARKED) {
+                        // both children done: fresnel * reflection + (1 - fresnel) * refraction (RayTracer.cpp:414)
+                        const float f = p1.z;
+                        cx = f * p0.x + (1 - f) * cx; cy = f * p0.y + (1 - f) * cy; cz = f * p0.z + (1 - f) * cz;
+                        sp--;
+                    } else {
+                        const uint32_t refr = __float_as_uint(p1.y);
+                        if (refr == CHILD_NONE) { sp--; }  // `return reflectionColor`, RayTracer.cpp:416
+                        else {
+                            // park the reflection colour in the node, mark it, descend into the refraction child
+                            wnodes[2 * (size_t)p] = make_float4(cx, cy, cz, __uint_as_float(kind | TN_PARKED));
+                            cur = refr;
+                            descending = true;
+                        }
                     }
                 }
             }
+            if (gi_mode) { sumx = sumx + cx; sumy = sumy + cy; sumz = sumz + cz; }  // std::accumulate from Color(0, 0, 0), RayTracer.cpp:101
+        }
+        if (gi_mode) {
+            const float inv = 1.0f / (float)A.f->level0_samples;
+            cx = sumx * inv; cy = sumy * inv; cz = sumz * inv;
         }
         const WorkItem wi = A.f->items[q >> 6];
         const uint32_t sub = q & 63u;

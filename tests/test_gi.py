@@ -207,6 +207,33 @@ def test_gi_frame_equals_the_oracles(pkg, scenes, oracle, case, tmp_path):
     assert_same_floats(plain, o.render(max_depth=depth)[0], "non-GI frame after a GI frame")
 
 
+GI_PATHS = [dict(mode=1),                                                  # render_lanes: the whole recursion per lane
+            dict(step_budget=0),                                           # faithful ray-stream kernels
+            dict(step_budget=8, shadow_budget=8, level0_budget=8),         # nearly every walk through the wave-per-ray kernels
+            dict(heavy_level=0), dict(heavy_level=1000000),                # the levels per lane first / by the wave-per-ray kernel whole
+            dict(step_budget=100000, shadow_budget=100000, heavy_level=0), # nothing evicted
+            dict(side_blocks=0)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tuning", GI_PATHS, ids=lambda t: ",".join("%s=%s" % kv for kv in t.items()))
+@pytest.mark.parametrize("name,meshes", [("hw11", 0), ("hw14", 0), ("hw11", 100)], ids=["hw11", "hw14", "hw11+93-meshes"])
+def test_gi_frame_on_every_kernel_path(pkg, scenes, oracle, name, meshes, tuning):
+    """The GI mode on the ray stream (jittered level-0 samples, gi_sample_size child rays per diffuse hit through the level queues,
+    shadow rays that do not skip refractive meshes, the N-ary post-order in stream_resolve) and on every other path: the oracle's
+    frame for the seed, bit for bit; 100 meshes: the wide plan."""
+    scene = scenes.make(name, width=96, height=64, detail=0.04 if name == "hw14" else 0.2)
+    if meshes:
+        scene = scenes.scatter_meshes(scene, meshes)
+    opts = dict(use_gi=1, gi_sample_size=2, rays_per_pixel=3, gi_seed=77)
+    want, _ = oracle.OracleScene(scenes.to_blob(scene)).render(options=oracle.make_options(3, **opts))
+    tracer = pkg.Tracer(pkg.Scene(json_text=scenes.to_json(scene)), tuning=pkg.make_tuning(**tuning))
+    for frame in range(2):   # (the second frame is not probed and sizes its launches by the first)
+        got = tracer.render(options=pkg.make_options(3, use_gi=True, gi_sample_size=2, rays_per_pixel=3, gi_seed=77))
+        assert_same_floats(got, want, "GI %s %r frame %d" % (name, tuning, frame))
+    assert tracer.stats().fallback_frames == 0
+
+
 @pytest.mark.gpu
 def test_gi_frame_does_not_depend_on_how_the_image_is_split(pkg, scenes, oracle):
     """Keys are (seed, pixel, sample, position in the ray tree): the same frame from one context, from two contexts sharing the

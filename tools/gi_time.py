@@ -1,7 +1,7 @@
 """Dev helper (GPU box): one GI frame (crt_options::use_gi) of a BASELINE scene, timed, with the counting build's ray counts.
 usage: python tools/gi_time.py hw14 960 540 3 2 2   (scene width height depth GI_SAMPLE_SIZE RAYS_PER_PIXEL)"""
-import importlib, sys, time
-sys.path.insert(0, '.')
+import importlib, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 pkg = importlib.import_module('course-assignment-danielhalachev_amd'); sc = pkg.scenes
 name = sys.argv[1] if len(sys.argv) > 1 else 'hw14'
@@ -10,14 +10,16 @@ scene = sc.make(name, width=w, height=h)
 import tempfile
 folder = tempfile.mkdtemp() + '/'
 if scene.get('textures'): sc.write_bitmaps(scene, folder)
-tr = pkg.Tracer(pkg.Scene(json_text=sc.to_json(scene), folder=folder))
+tr = pkg.Tracer(pkg.Scene(json_text=sc.to_json(scene), folder=folder), tuning=pkg.tuning_from_string(os.environ.get('CRT_TUNING', '')))   # e.g. mode=1: render_lanes
 opts = dict(use_gi=True, gi_sample_size=n, rays_per_pixel=r)
 tr.render(options=pkg.make_options(depth, gi_seed=0, **opts))
-t0 = time.perf_counter(); k = 3
+for i in range(2): tr.render(options=pkg.make_options(depth, gi_seed=20 + i, **opts))
+t0 = time.perf_counter(); k = 5
 for i in range(k): got = tr.render(options=pkg.make_options(depth, gi_seed=1 + i, **opts))
 ms = (time.perf_counter() - t0) / k * 1e3
 tr.render(options=pkg.make_options(depth, counters=True, gi_seed=1, **opts))
 c = tr.stats().counters()
 rays = c['primary_rays'] + c['secondary_rays'] + c['shadow_rays']
 print('%s %dx%d depth %d GI_SAMPLE_SIZE %d RAYS_PER_PIXEL %d: %.1f ms per frame, %.1f M rays per frame (%.0f M rays/s), mean colour %.4f'
-      % (name, w, h, depth, n, r, ms, rays / 1e6, rays / ms / 1e3, float(got.mean())), flush=True)
+      % (name, w, h, depth, n, r, ms, rays / 1e6, rays / ms / 1e3, float(got.mean())), 'device ms (total, levels, shadow pass 0 beside them, shadow pass 1 + evicted walks, resolve)', [tuple(round(x, 2) for x in t) for t in tr.kernel_times_ms(2)][:1],
+      'fallback frames', tr.stats().fallback_frames, 'regrows', tr.stats().queue_regrows, 'queues %.0f MB' % (tr.stats().queue_bytes / 1e6), tr.kernels(), flush=True)

@@ -6,12 +6,15 @@ pkg = importlib.import_module('course-assignment-danielhalachev_amd'); sc = pkg.
 name = sys.argv[1] if len(sys.argv) > 1 else 'hw14'
 import tempfile
 many = name.startswith('many')   # many200: the room of tools/many_meshes.py with 200 meshes
-s = sc.scatter_meshes(sc.make('hw11', detail=0.6), int(name[4:])) if many else sc.make(name); folder = tempfile.mkdtemp() + '/'
+import os
+gi = [int(v) for v in os.environ.get('CRT_GI', '').split()]   # CRT_GI='width height depth samples rays_per_pixel': a GI frame of that size
+s = sc.scatter_meshes(sc.make('hw11', detail=0.6), int(name[4:])) if many else (sc.make(name, width=gi[0], height=gi[1]) if gi else sc.make(name)); folder = tempfile.mkdtemp() + '/'
 if s.get('textures'): sc.write_bitmaps(s, folder)
 hs = pkg.Scene(json_text=sc.to_json(s), folder=folder); tr = pkg.Tracer(hs, tuning=pkg.tuning_from_string(__import__('os').environ.get('CRT_TUNING', '')))
-depth = 8 if many else sc.CONFIGS[name][3]
+depth = 8 if many else (gi[2] if gi else sc.CONFIGS[name][3])
 for i in range(3):
-    tr.render(max_depth=depth)
+    if gi: tr.render(options=pkg.make_options(depth, use_gi=True, gi_sample_size=gi[3], rays_per_pixel=gi[4], gi_seed=i))
+    else: tr.render(max_depth=depth)
 print('phase ms', tr.kernel_times_ms(3))
 out = (C.c_uint32 * 512)()
 L = pkg.lib(); L.crt_debug_stream_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]
@@ -21,6 +24,7 @@ print('evicted per level', [out[128 + g] for g in range(depth + 1)])
 print('shadow rays', out[320], 'level-0 split', out[327], 'evicted shadow', out[323], 'overflow', out[322], 'guard', out[326], 'fallback frames', tr.stats().fallback_frames)
 
 # what the group-per-ray (or wave-per-ray) walks of a frame consist of (a render with counters=2 tallies them)
+if gi: sys.exit(0)
 tr.render(max_depth=depth, counters=2)
 L.crt_debug_stream_counts(tr.ctx, out, 512)
 for label, o in (('closest-hit', 384), ('shadow', 392)):
