@@ -154,7 +154,7 @@ struct crt_ctx {
     bool pending = false;             // a frame enqueued by crt_render_async has not been waited for
     crt_options pending_options{};
     uint32_t heavy_cap = 0;
-    uint32_t step_budget = 256;       // crt_tuning::step_budget (0 = never evict: also set when a mesh has too many leaves for the wave-per-ray walk)
+    uint32_t step_budget = 384;       // crt_tuning::step_budget (0 = never evict: also set when a mesh has too many leaves for the wave-per-ray walk)
     bool lean_ok = true;              // 32-bit byte offsets reach every node and leaf entry
     uint64_t stream_items = 0;        // work items the stream buffers are sized for
     uint64_t overflows = 0;           // frames redone by the fallback (diagnostic)
@@ -358,7 +358,7 @@ extern "C" void crt_tuning_defaults(crt_tuning *t) {
     memset(t, 0, sizeof(*t));
     t->size = (uint32_t)sizeof(*t);
     t->mode = CRT_MODE_STREAM;
-    t->step_budget = 256; t->shadow_budget = 4096; t->level0_budget = 0;
+    t->step_budget = 384; t->shadow_budget = 4096; t->level0_budget = 0;
     t->heavy_level = 100000; t->side_blocks = 3;
     t->node_cap = t->ray_cap = t->shadow_cap = 0;
 }

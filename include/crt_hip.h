@@ -184,7 +184,7 @@ enum { CRT_MODE_STREAM = 0, CRT_MODE_LANES = 1 };
 typedef struct crt_tuning {
     uint32_t size;            /* sizeof(crt_tuning), filled in by crt_tuning_defaults */
     uint32_t mode;            /* CRT_MODE_STREAM (ray stream, default) | CRT_MODE_LANES (full recursion per lane, queue-less) */
-    uint32_t step_budget;     /* 256: steps after which a closest-hit walk goes to the wave-per-ray kernel; 0 = faithful kernels only */
+    uint32_t step_budget;     /* 384: steps after which a closest-hit walk goes to the wave-per-ray kernel; 0 = faithful kernels only */
     uint32_t shadow_budget;   /* 4096: cap of the same for the bulk shadow pass (the launch scales it down with its size) */
     uint32_t level0_budget;   /* 0 (= min(step_budget, what a lane gets through in the launch)): the same for PRIMARY rays */
     uint32_t heavy_level;     /* 100000: recursion levels with fewer rays skip the per-lane kernel */
