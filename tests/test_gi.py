@@ -215,9 +215,13 @@ GI_PATHS = [dict(mode=1),                                                  # ren
             dict(side_blocks=0)]
 
 
+# every path on the room; the knot scene and the wide plan on the paths that differ there
+GI_PATH_CASES = [("hw11", 0, t) for t in GI_PATHS] + [("hw14", 0, GI_PATHS[k]) for k in (2, 3, 5)] + [("hw11", 100, GI_PATHS[k]) for k in (1, 2, 5)]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("tuning", GI_PATHS, ids=lambda t: ",".join("%s=%s" % kv for kv in t.items()))
-@pytest.mark.parametrize("name,meshes", [("hw11", 0), ("hw14", 0), ("hw11", 100)], ids=["hw11", "hw14", "hw11+93-meshes"])
+@pytest.mark.parametrize("name,meshes,tuning", GI_PATH_CASES,
+                         ids=lambda v: v if isinstance(v, str) else (str(v) if isinstance(v, int) else ",".join("%s=%s" % kv for kv in v.items())))
 def test_gi_frame_on_every_kernel_path(pkg, scenes, oracle, name, meshes, tuning):
     """The GI mode on the ray stream (jittered level-0 samples, gi_sample_size child rays per diffuse hit through the level queues,
     shadow rays that do not skip refractive meshes, the N-ary post-order in stream_resolve) and on every other path: the oracle's

@@ -81,10 +81,12 @@ def test_every_kernel_path_gives_the_same_frame(pkg, scenes, oracle, name, tunin
     assert tracer.stats().fallback_frames == 0
 
 
-@pytest.mark.parametrize("tuning", [None, dict(step_budget=8, shadow_budget=8, level0_budget=8), dict(heavy_level=0),
-                                    dict(step_budget=100000, shadow_budget=100000, heavy_level=0), dict(step_budget=0), dict(mode=1)],
-                         ids=lambda t: "defaults" if t is None else ",".join("%s=%s" % kv for kv in t.items()))
-@pytest.mark.parametrize("n_meshes", [100, 150, 300])
+MANY_PATHS = [None, dict(step_budget=8, shadow_budget=8, level0_budget=8), dict(heavy_level=0),
+              dict(step_budget=100000, shadow_budget=100000, heavy_level=0), dict(step_budget=0), dict(mode=1)]
+
+
+@pytest.mark.parametrize("n_meshes,tuning", [(100, t) for t in MANY_PATHS] + [(150, MANY_PATHS[k]) for k in (0, 1, 3)] + [(300, MANY_PATHS[k]) for k in (0, 1)],
+                         ids=lambda v: str(v) if isinstance(v, int) else ("defaults" if v is None else ",".join("%s=%s" % kv for kv in v.items())))
 def test_many_meshes_stay_on_the_plan_kernels(pkg, scenes, oracle, n_meshes, tuning):
     """A top-level tree with hundreds of leaves (the reference's scenes have a handful of meshes): up to 256 meshes the wide
     plan kernels render it (eight-word mesh masks, leaf groups; the wave-per-ray kernels walk the top-level leaf sequence 64
