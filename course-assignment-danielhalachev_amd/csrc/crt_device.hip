@@ -1013,6 +1013,163 @@ static void launch_lds(K kernel, uint32_t blocks, uint32_t lds_bytes, hipStream_
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK), lds_bytes, stream, args...);
 }
 
+// What launch_frame decides once per frame and its three launch helpers read.
+struct FramePlan {
+    int slot;                     // event / pinned-counter / argument-block slot of this frame
+    uint32_t n_items, vitems;     // work items; work items' worth of level-0 rays (the GI mode: x rays_per_pixel)
+    uint32_t lane_blocks;         // grid of the kernels that take one ray (or pixel) per lane
+    bool gi, count, exec_count;   // GI mode; counting build; production kernels tallying the tests they execute
+    bool heavy, lean, wide;       // wave-per-ray kernels on; plan kernels; the wide plan
+    uint32_t level_budget;        // steps after which a deeper level's per-lane walk is evicted
+    const uint32_t *prev;         // counters of a completed frame of this size and kind, or null
+    bool last_resort;             // render_lanes behind the stream pass
+};
+
+// Levels 0 .. MAX_DEPTH on `stream`; after level 0 the bulk shadow pass (and the walks it gives up) on the side stream.
+static int launch_stream_levels(crt_ctx *ctx, const crt_options *o, FramePlan &P, KernelArgs &A, hipStream_t stream) {
+    CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_scounts, 0, SC_ALLOC_WORDS * sizeof(uint32_t), stream));
+    const uint32_t side_per_cu = ctx->tuning.side_blocks;  // workgroups per CU of the bulk shadow pass beside the levels
+    A.exec_count = P.exec_count ? 1u : 0u;
+    A.exec_counters = ctx->d_exec;
+    A.exec_plan = ctx->d_exec + 4;
+    if (P.exec_count) CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_exec, 0, 6 * sizeof(unsigned long long), stream));
+    // the plan kernels pay a wave-uniform loop per refill, whatever the number of new rays: refill in bundles
+    A.bundle = REFILL_BUNDLE;
+    A.wave_prio = 3u;  // the levels' waves (the frame's critical path) ahead of the bulk shadow pass's, which share their SIMDs
+    A.force_whole = 0u;
+    if (ctx->frame.fixed0) CRT_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->d_scounts + SC_SHADOW), (int)((uint32_t)P.vitems * 64u * ctx->n_lights), 1, stream));
+    const uint32_t plds = ctx->scene.plan_list_words * BLOCK * (uint32_t)sizeof(uint32_t);  // kernel_plan.h: mesh lists
+    KernelArgs S = A;  // argument block of the bulk shadow pass
+    S.wave_prio = 0u;
+    S.counters = ctx->d_counters + C_N;
+    S.exec_counters = ctx->d_exec + 2;  // it tallies on its own
+    S.exec_plan = ctx->d_exec + 5;
+    {
+        // The pass is one persistent launch: it ends when its longest walk ends, so the budget after which a walk is
+        // handed to heavy_trace_shadow should be about the steps one lane gets through in the whole launch --
+        // rays per lane x ~130 steps per ray (measured average on the benchmark scenes) -- and no more than the cap
+        // (crt_tuning::shadow_budget).  A rank that renders 1/8 of the tiles gets 1/8 of the budget.
+        const uint64_t lanes = (uint64_t)ctx->num_cus * (side_per_cu ? side_per_cu : 8u) * BLOCK;
+        const uint64_t est = (uint64_t)P.vitems * 64u * (ctx->n_lights ? ctx->n_lights : 1u) * 130u / (lanes ? lanes : 1u);
+        uint32_t budget = est > ctx->tuning.shadow_budget ? ctx->tuning.shadow_budget : (uint32_t)est;
+        if (budget < ctx->step_budget) budget = std::min(ctx->step_budget, ctx->tuning.shadow_budget);
+        S.step_budget = P.heavy ? budget : 0u;
+    }
+    // a completed frame of this size (one that overflowed stopped early: its levels' counts say nothing)
+    const uint32_t *prev = ctx->last_counts_items == P.vitems && ctx->last_counts_cfg == frame_config_of(o) && !ctx->last_counts[SC_OVERFLOW] ? ctx->last_counts.data() : nullptr;
+    // (under the P.wide plan a ray crosses dozens of small mesh trees: a walk of a thousand steps is the rule there, not the outlier the
+    //  wave-per-ray kernel is for -- measured on tools/many_meshes.py 200: 32.7 ms per frame with the plain budget, 25.4 with four times it)
+    // (the same holds for a GI frame's levels -- millions of incoherent rays each: tools/gi_time.py hw14 960x540 d3 n2 r2 54.7 ms -> 44.2)
+    const uint32_t level_budget = (P.wide || P.gi) ? std::min<uint32_t>(ctx->step_budget * 4u, 1u << 20) : ctx->step_budget;
+    P.prev = prev; P.level_budget = level_budget;  // (launch_stream_tail sizes its pass by them too)
+    // the same reasoning for level 0 (one launch over all primary rays, ~70 steps per ray)
+    const uint64_t est0 = (uint64_t)P.vitems * 64u * 70u / ((uint64_t)P.lane_blocks * BLOCK);
+    uint32_t budget0 = est0 >= level_budget ? level_budget : (est0 < 64u ? 64u : (uint32_t)est0);
+    if (ctx->tuning.level0_budget) budget0 = ctx->tuning.level0_budget;
+    for (uint32_t g = 0; g <= o->max_depth; g++) {
+        A.step_budget = P.heavy ? (g == 0 ? budget0 : level_budget) : 0u;
+        // The per-lane kernel of a deeper level fetches its rays through a cursor, so any grid does the whole level; beside
+        // the bulk shadow pass every workgroup of it waits for a free P.slot, and a level below heavy_level_threshold has
+        // nothing for it to do (measured: 0.15 ms for an empty full-size grid).  Sized by what the level held a frame ago.
+        uint32_t level_blocks = P.lane_blocks;
+        if (g >= 1 && P.lean && prev) {
+            const uint32_t was = prev[SC_COUNT + g];
+            const uint32_t want = was < ctx->frame.heavy_level_threshold ? 64u : std::max<uint32_t>((uint32_t)ctx->num_cus, (was + was / 2u + BLOCK - 1) / BLOCK);
+            level_blocks = std::min(P.lane_blocks, want);
+        }
+        if (P.count) { if (P.gi) launch(stream_trace_shade<true, true>, P.lane_blocks, stream, A, g); else launch(stream_trace_shade<true>, P.lane_blocks, stream, A, g); }
+        else if (P.wide) launch_lds(P.gi ? stream_trace_shade_plan_wide_gi : stream_trace_shade_plan_wide, level_blocks, plds, stream, A, g);
+        else if (P.lean) launch_lds(P.gi ? stream_trace_shade_plan_gi : stream_trace_shade_plan, level_blocks, plds, stream, A, g);
+        else if (P.gi) launch(stream_trace_shade<false, true>, P.lane_blocks, stream, A, g);
+        else launch(stream_trace_shade<false>, P.lane_blocks, stream, A, g);
+        if (P.heavy) {
+            launch(P.gi ? heavy_trace_closest_gi : heavy_trace_closest, HEAVY_BLOCKS, stream, A, g);
+            if (P.gi) launch(stream_shade_evicted<false, true>, 256u, stream, A, g);
+            else launch(stream_shade_evicted<false>, 256u, stream, A, g);
+        }
+        if (g == 0) {
+            // where level 0's shadow rays end; they start now, on the side stream, beside the deeper levels
+            hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, stream, A, (uint32_t)SC_SHADOW_SPLIT, (uint32_t)SC_SHADOW);
+            hipStream_t where = side_per_cu ? ctx->side : stream;
+            if (side_per_cu) {
+                CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork[P.slot], stream));
+                CRT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork[P.slot], 0));
+            }
+            CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s0[P.slot], where));
+            // (beside the levels its persistent waves must leave wave slots on every CU for the level kernels)
+            const uint32_t blocks0 = side_per_cu ? (uint32_t)ctx->num_cus * side_per_cu : ctx->grid_blocks;
+            if (P.count) launch(stream_trace_shadow<true>, blocks0, where, S, 0u);
+            else if (P.wide) launch(stream_trace_shadow_plan_wide<0>, blocks0, where, S);
+            else if (P.lean) launch(stream_trace_shadow_plan<0>, blocks0, where, S);
+            else launch(stream_trace_shadow<false>, blocks0, where, S, 0u);
+            // ... and behind it the walks it gave up, still beside the levels; the mark comes before the event the
+            // caller's stream waits for, so nothing the later pass appends is below it
+            if (P.heavy) hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, where, S, (uint32_t)SC_SHEAVY_SPLIT, (uint32_t)SC_SHEAVY);
+            CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s1[P.slot], where));
+            if (P.heavy) launch(heavy_trace_shadow, HEAVY_BLOCKS, where, S, 0u);
+            CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s2[P.slot], where));
+        }
+    }
+    return CRT_OK;
+}
+
+// The deeper levels' shadow rays, the wave-per-ray walks of both passes, the per-pixel combination, the last resort.
+static int launch_stream_tail(crt_ctx *ctx, FramePlan &P, KernelArgs &A, hipStream_t stream) {
+    const uint32_t side_per_cu = ctx->tuning.side_blocks;
+    const uint32_t *prev = P.prev;
+    const uint32_t level_budget = P.level_budget;
+    CRT_HIP_CHECK(ctx, hipGetLastError());
+    CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev1[P.slot], stream));
+    // the shadow rays of the deeper levels (queued behind level 0's), then the wave-per-ray walks of both passes
+    if (side_per_cu) CRT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_s1[P.slot], 0));
+    KernelArgs S1 = A;
+    S1.wave_prio = 0u;
+    S1.counters = ctx->d_counters + 2 * C_N;
+    {
+        // few rays, all tail: the short budget of the levels, or less when this launch is small (the deeper levels
+        // queue about a quarter of a shadow ray per pixel on the benchmark scenes)
+        const uint64_t rays1 = prev && prev[SC_SHADOW] >= prev[SC_SHADOW_SPLIT] ? prev[SC_SHADOW] - prev[SC_SHADOW_SPLIT] : (uint64_t)P.vitems * 16u;
+        const uint64_t est1 = rays1 * 130u / ((uint64_t)P.lane_blocks * BLOCK);
+        // (a GI frame queues most of its shadow rays here -- tens of millions: then this pass is a bulk pass like pass 0 and gets its cap)
+        const uint32_t cap1 = std::max(level_budget, ctx->tuning.shadow_budget);
+        S1.step_budget = P.heavy ? (est1 >= cap1 ? cap1 : (est1 < 64u ? 64u : (uint32_t)est1)) : 0u;
+    }
+    if (P.count) launch(stream_trace_shadow<true>, P.lane_blocks, stream, S1, 1u);
+    else if (P.wide) launch(stream_trace_shadow_plan_wide<1>, P.lane_blocks, stream, S1);
+    else if (P.lean) launch(stream_trace_shadow_plan<1>, P.lane_blocks, stream, S1);
+    else launch(stream_trace_shadow<false>, P.lane_blocks, stream, S1, 1u);
+    if (side_per_cu) CRT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_s2[P.slot], 0));
+    if (P.heavy) launch(heavy_trace_shadow, HEAVY_BLOCKS, stream, S1, 1u);
+    CRT_HIP_CHECK(ctx, hipGetLastError());
+    CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev2[P.slot], stream));
+    A.counters = ctx->d_counters + 2 * C_N;
+    // post-order combination per pixel, then the queue-less fallback, which only runs after an overflow
+    if (P.count) launch(stream_resolve<true>, P.lane_blocks, stream, A);
+    else launch(stream_resolve<false>, P.lane_blocks, stream, A);
+    A.only_if_overflow = 1;
+    const uint32_t fallback_blocks = std::max(1u, std::min(ctx->grid_blocks, (P.n_items * 64u + BLOCK - 1) / BLOCK));
+    if (!P.last_resort) {}  // a probing attempt (launch_render): the host looks at the overflow word itself
+    else if (P.gi && P.count) launch(render_lanes<true, true>, fallback_blocks, stream, A);
+    else if (P.gi) launch(render_lanes<false, true>, fallback_blocks, stream, A);
+    else if (P.count) launch(render_lanes<true>, fallback_blocks, stream, A);
+    else launch(render_lanes<false>, fallback_blocks, stream, A);
+    CRT_HIP_CHECK(ctx, hipGetLastError());
+    return CRT_OK;
+}
+
+// The whole frame by render_lanes: crt_tuning::mode = lanes, and GI frames too large for the ray-stream pass.
+static int launch_lanes_pass(crt_ctx *ctx, FramePlan &P, KernelArgs &A, hipStream_t stream) {
+    CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev1[P.slot], stream));
+    A.counters = ctx->d_counters + C_N;
+    if (P.gi && P.count) launch(render_lanes<true, true>, P.lane_blocks, stream, A);
+    else if (P.gi) launch(render_lanes<false, true>, P.lane_blocks, stream, A);
+    else if (P.count) launch(render_lanes<true>, P.lane_blocks, stream, A);
+    else launch(render_lanes<false>, P.lane_blocks, stream, A);
+    CRT_HIP_CHECK(ctx, hipGetLastError());
+    for (hipEvent_t e : {ctx->ev_s0[P.slot], ctx->ev_s1[P.slot], ctx->ev_s2[P.slot], ctx->ev2[P.slot]}) CRT_HIP_CHECK(ctx, hipEventRecord(e, stream));
+    return CRT_OK;
+}
+
 // One frame's launches.  Ray-stream path (kernel_stream.h), per recursion level g = 0 .. MAX_DEPTH on `stream`:
 //   the per-lane kernel (plan kernels; the faithful kernel for the counting build and for scenes without a plan),
 //   heavy_trace_closest for the walks it handed over (or the whole level), stream_shade_evicted for their hits;
@@ -1090,135 +1247,10 @@ static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, fl
     A.s = (scene_args_p)ctx->d_scene;
     A.f = (frame_args_p)(ctx->d_frame_ring + slot);
     A.counters = ctx->d_counters;
-    if (stream_mode) {
-        CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_scounts, 0, SC_ALLOC_WORDS * sizeof(uint32_t), stream));
-        const uint32_t side_per_cu = ctx->tuning.side_blocks;  // workgroups per CU of the bulk shadow pass beside the levels
-        A.exec_count = exec_count ? 1u : 0u;
-        A.exec_counters = ctx->d_exec;
-        A.exec_plan = ctx->d_exec + 4;
-        if (exec_count) CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_exec, 0, 6 * sizeof(unsigned long long), stream));
-        // the plan kernels pay a wave-uniform loop per refill, whatever the number of new rays: refill in bundles
-        A.bundle = REFILL_BUNDLE;
-        A.wave_prio = 3u;  // the levels' waves (the frame's critical path) ahead of the bulk shadow pass's, which share their SIMDs
-        A.force_whole = 0u;
-        if (F.fixed0) CRT_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->d_scounts + SC_SHADOW), (int)((uint32_t)vitems * 64u * ctx->n_lights), 1, stream));
-        const uint32_t plds = SC.plan_list_words * BLOCK * (uint32_t)sizeof(uint32_t);  // kernel_plan.h: mesh lists
-        KernelArgs S = A;  // argument block of the bulk shadow pass
-        S.wave_prio = 0u;
-        S.counters = ctx->d_counters + C_N;
-        S.exec_counters = ctx->d_exec + 2;  // it tallies on its own
-        S.exec_plan = ctx->d_exec + 5;
-        {
-            // The pass is one persistent launch: it ends when its longest walk ends, so the budget after which a walk is
-            // handed to heavy_trace_shadow should be about the steps one lane gets through in the whole launch --
-            // rays per lane x ~130 steps per ray (measured average on the benchmark scenes) -- and no more than the cap
-            // (crt_tuning::shadow_budget).  A rank that renders 1/8 of the tiles gets 1/8 of the budget.
-            const uint64_t lanes = (uint64_t)ctx->num_cus * (side_per_cu ? side_per_cu : 8u) * BLOCK;
-            const uint64_t est = (uint64_t)vitems * 64u * (ctx->n_lights ? ctx->n_lights : 1u) * 130u / (lanes ? lanes : 1u);
-            uint32_t budget = est > ctx->tuning.shadow_budget ? ctx->tuning.shadow_budget : (uint32_t)est;
-            if (budget < ctx->step_budget) budget = std::min(ctx->step_budget, ctx->tuning.shadow_budget);
-            S.step_budget = heavy ? budget : 0u;
-        }
-        // a completed frame of this size (one that overflowed stopped early: its levels' counts say nothing)
-        const uint32_t *prev = ctx->last_counts_items == vitems && ctx->last_counts_cfg == frame_config_of(o) && !ctx->last_counts[SC_OVERFLOW] ? ctx->last_counts.data() : nullptr;
-        // (under the wide plan a ray crosses dozens of small mesh trees: a walk of a thousand steps is the rule there, not the outlier the
-        //  wave-per-ray kernel is for -- measured on tools/many_meshes.py 200: 32.7 ms per frame with the plain budget, 25.4 with four times it)
-        // (the same holds for a GI frame's levels -- millions of incoherent rays each: tools/gi_time.py hw14 960x540 d3 n2 r2 54.7 ms -> 44.2)
-        const uint32_t level_budget = (wide || gi) ? std::min<uint32_t>(ctx->step_budget * 4u, 1u << 20) : ctx->step_budget;
-        // the same reasoning for level 0 (one launch over all primary rays, ~70 steps per ray)
-        const uint64_t est0 = (uint64_t)vitems * 64u * 70u / ((uint64_t)lane_blocks * BLOCK);
-        uint32_t budget0 = est0 >= level_budget ? level_budget : (est0 < 64u ? 64u : (uint32_t)est0);
-        if (ctx->tuning.level0_budget) budget0 = ctx->tuning.level0_budget;
-        for (uint32_t g = 0; g <= o->max_depth; g++) {
-            A.step_budget = heavy ? (g == 0 ? budget0 : level_budget) : 0u;
-            // The per-lane kernel of a deeper level fetches its rays through a cursor, so any grid does the whole level; beside
-            // the bulk shadow pass every workgroup of it waits for a free slot, and a level below heavy_level_threshold has
-            // nothing for it to do (measured: 0.15 ms for an empty full-size grid).  Sized by what the level held a frame ago.
-            uint32_t level_blocks = lane_blocks;
-            if (g >= 1 && lean && prev) {
-                const uint32_t was = prev[SC_COUNT + g];
-                const uint32_t want = was < F.heavy_level_threshold ? 64u : std::max<uint32_t>((uint32_t)ctx->num_cus, (was + was / 2u + BLOCK - 1) / BLOCK);
-                level_blocks = std::min(lane_blocks, want);
-            }
-            if (count) { if (gi) launch(stream_trace_shade<true, true>, lane_blocks, stream, A, g); else launch(stream_trace_shade<true>, lane_blocks, stream, A, g); }
-            else if (wide) launch_lds(gi ? stream_trace_shade_plan_wide_gi : stream_trace_shade_plan_wide, level_blocks, plds, stream, A, g);
-            else if (lean) launch_lds(gi ? stream_trace_shade_plan_gi : stream_trace_shade_plan, level_blocks, plds, stream, A, g);
-            else if (gi) launch(stream_trace_shade<false, true>, lane_blocks, stream, A, g);
-            else launch(stream_trace_shade<false>, lane_blocks, stream, A, g);
-            if (heavy) {
-                launch(gi ? heavy_trace_closest_gi : heavy_trace_closest, HEAVY_BLOCKS, stream, A, g);
-                if (gi) launch(stream_shade_evicted<false, true>, 256u, stream, A, g);
-                else launch(stream_shade_evicted<false>, 256u, stream, A, g);
-            }
-            if (g == 0) {
-                // where level 0's shadow rays end; they start now, on the side stream, beside the deeper levels
-                hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, stream, A, (uint32_t)SC_SHADOW_SPLIT, (uint32_t)SC_SHADOW);
-                hipStream_t where = side_per_cu ? ctx->side : stream;
-                if (side_per_cu) {
-                    CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork[slot], stream));
-                    CRT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork[slot], 0));
-                }
-                CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s0[slot], where));
-                // (beside the levels its persistent waves must leave wave slots on every CU for the level kernels)
-                const uint32_t blocks0 = side_per_cu ? (uint32_t)ctx->num_cus * side_per_cu : ctx->grid_blocks;
-                if (count) launch(stream_trace_shadow<true>, blocks0, where, S, 0u);
-                else if (wide) launch(stream_trace_shadow_plan_wide<0>, blocks0, where, S);
-                else if (lean) launch(stream_trace_shadow_plan<0>, blocks0, where, S);
-                else launch(stream_trace_shadow<false>, blocks0, where, S, 0u);
-                // ... and behind it the walks it gave up, still beside the levels; the mark comes before the event the
-                // caller's stream waits for, so nothing the later pass appends is below it
-                if (heavy) hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, where, S, (uint32_t)SC_SHEAVY_SPLIT, (uint32_t)SC_SHEAVY);
-                CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s1[slot], where));
-                if (heavy) launch(heavy_trace_shadow, HEAVY_BLOCKS, where, S, 0u);
-                CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s2[slot], where));
-            }
-        }
-        CRT_HIP_CHECK(ctx, hipGetLastError());
-        CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev1[slot], stream));
-        // the shadow rays of the deeper levels (queued behind level 0's), then the wave-per-ray walks of both passes
-        if (side_per_cu) CRT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_s1[slot], 0));
-        KernelArgs S1 = A;
-        S1.wave_prio = 0u;
-        S1.counters = ctx->d_counters + 2 * C_N;
-        {
-            // few rays, all tail: the short budget of the levels, or less when this launch is small (the deeper levels
-            // queue about a quarter of a shadow ray per pixel on the benchmark scenes)
-            const uint64_t rays1 = prev && prev[SC_SHADOW] >= prev[SC_SHADOW_SPLIT] ? prev[SC_SHADOW] - prev[SC_SHADOW_SPLIT] : (uint64_t)vitems * 16u;
-            const uint64_t est1 = rays1 * 130u / ((uint64_t)lane_blocks * BLOCK);
-            // (a GI frame queues most of its shadow rays here -- tens of millions: then this pass is a bulk pass like pass 0 and gets its cap)
-            const uint32_t cap1 = std::max(level_budget, ctx->tuning.shadow_budget);
-            S1.step_budget = heavy ? (est1 >= cap1 ? cap1 : (est1 < 64u ? 64u : (uint32_t)est1)) : 0u;
-        }
-        if (count) launch(stream_trace_shadow<true>, lane_blocks, stream, S1, 1u);
-        else if (wide) launch(stream_trace_shadow_plan_wide<1>, lane_blocks, stream, S1);
-        else if (lean) launch(stream_trace_shadow_plan<1>, lane_blocks, stream, S1);
-        else launch(stream_trace_shadow<false>, lane_blocks, stream, S1, 1u);
-        if (side_per_cu) CRT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_s2[slot], 0));
-        if (heavy) launch(heavy_trace_shadow, HEAVY_BLOCKS, stream, S1, 1u);
-        CRT_HIP_CHECK(ctx, hipGetLastError());
-        CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev2[slot], stream));
-        A.counters = ctx->d_counters + 2 * C_N;
-        // post-order combination per pixel, then the queue-less fallback, which only runs after an overflow
-        if (count) launch(stream_resolve<true>, lane_blocks, stream, A);
-        else launch(stream_resolve<false>, lane_blocks, stream, A);
-        A.only_if_overflow = 1;
-        const uint32_t fallback_blocks = std::max(1u, std::min(ctx->grid_blocks, (n_items * 64u + BLOCK - 1) / BLOCK));
-        if (!last_resort) {}  // a probing attempt (launch_render): the host looks at the overflow word itself
-        else if (gi && count) launch(render_lanes<true, true>, fallback_blocks, stream, A);
-        else if (gi) launch(render_lanes<false, true>, fallback_blocks, stream, A);
-        else if (count) launch(render_lanes<true>, fallback_blocks, stream, A);
-        else launch(render_lanes<false>, fallback_blocks, stream, A);
-        CRT_HIP_CHECK(ctx, hipGetLastError());
-    } else {
-        CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev1[slot], stream));
-        A.counters = ctx->d_counters + C_N;
-        if (gi && count) launch(render_lanes<true, true>, lane_blocks, stream, A);
-        else if (gi) launch(render_lanes<false, true>, lane_blocks, stream, A);
-        else if (count) launch(render_lanes<true>, lane_blocks, stream, A);
-        else launch(render_lanes<false>, lane_blocks, stream, A);
-        CRT_HIP_CHECK(ctx, hipGetLastError());
-        for (hipEvent_t e : {ctx->ev_s0[slot], ctx->ev_s1[slot], ctx->ev_s2[slot], ctx->ev2[slot]}) CRT_HIP_CHECK(ctx, hipEventRecord(e, stream));
-    }
+    FramePlan P{slot, n_items, vitems, lane_blocks, gi, count, exec_count, heavy, lean, wide, 0u, nullptr, last_resort};
+    rc = stream_mode ? launch_stream_levels(ctx, o, P, A, stream) : launch_lanes_pass(ctx, P, A, stream);
+    if (rc == CRT_OK && stream_mode) rc = launch_stream_tail(ctx, P, A, stream);
+    if (rc) return rc;
     // what this frame leaves for the next ones: its counter block and the fallback total, into this frame's own pinned slot
     uint32_t *h = ctx->h_ring + (size_t)slot * crt_ctx::H_SLOT_WORDS;
     if (stream_mode) CRT_HIP_CHECK(ctx, hipMemcpyAsync(h, ctx->d_scounts, SC_ALLOC_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
