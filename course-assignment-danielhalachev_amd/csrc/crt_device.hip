@@ -132,6 +132,7 @@ struct crt_ctx {
     uint32_t *d_heavy = nullptr;      // evicted ray ids
     uint32_t *d_sheavy = nullptr;     // evicted shadow ray ids
     float4 *d_hits = nullptr;         // their closest hits
+    float4 *d_hits_all = nullptr;     // a level's closest hits by ray index (kernel_plan.h: the walk-only builds)
     hipStream_t side = nullptr;       // shadow pass 0 overlaps the deeper recursion levels on this stream
     // What a finished frame tells the next ones (queue sizing, launch sizes, fallback count): every frame copies its counter
     // block and the fallback total to ITS slot of this pinned ring, and the host reads a slot only once that frame's last
@@ -785,6 +786,7 @@ extern "C" void crt_destroy(crt_ctx *ctx) {
     if (ctx->d_heavy) (void)hipFree(ctx->d_heavy);
     if (ctx->d_sheavy) (void)hipFree(ctx->d_sheavy);
     if (ctx->d_hits) (void)hipFree(ctx->d_hits);
+    if (ctx->d_hits_all) (void)hipFree(ctx->d_hits_all);
     if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
     if (ctx->h_frame_ring) (void)hipHostFree(ctx->h_frame_ring);
     if (ctx->d_frame_ring) (void)hipFree(ctx->d_frame_ring);
@@ -910,7 +912,7 @@ static void adapt_queue_sizing(crt_ctx *ctx) {
 
 static uint64_t queue_bytes_for(const crt_ctx *ctx, uint64_t px, double node_mult, double ray_mult, double shadow_extra) {
     const uint64_t lights = ctx->n_lights ? ctx->n_lights : 1;
-    return (uint64_t)(px * ray_mult) * (64 + 24) + (uint64_t)(px * lights * (1.0 + shadow_extra)) * 33 + (uint64_t)(px * node_mult) * 32;
+    return (uint64_t)(px * std::max(ray_mult, 1.0)) * 16 + (uint64_t)(px * ray_mult) * (64 + 24) + (uint64_t)(px * lights * (1.0 + shadow_extra)) * 33 + (uint64_t)(px * node_mult) * 32;
 }
 
 // After an attempt that overflowed (launch_render): capacities from what the attempt learnt.  The level that was emitting when a
@@ -970,7 +972,7 @@ static int ensure_stream(crt_ctx *ctx, uint32_t n_items) {
             shadow_cap = std::max<uint64_t>(shadow_cap, A.s_shadow_cap);
         }
         void **bufs[] = {(void **)&ctx->d_rayq[0], (void **)&ctx->d_rayq[1], (void **)&ctx->d_shadowq, (void **)&ctx->d_occluded,
-                         (void **)&ctx->d_nodes, (void **)&ctx->d_heavy, (void **)&ctx->d_sheavy, (void **)&ctx->d_hits};
+                         (void **)&ctx->d_nodes, (void **)&ctx->d_heavy, (void **)&ctx->d_sheavy, (void **)&ctx->d_hits, (void **)&ctx->d_hits_all};
         for (void **b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
         ctx->stream_items = 0;
         A.s_node_cap = A.s_ray_cap = A.s_shadow_cap = 0;
@@ -983,13 +985,14 @@ static int ensure_stream(crt_ctx *ctx, uint32_t n_items) {
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_heavy, (size_t)ctx->heavy_cap * sizeof(uint32_t) + 64));
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_sheavy, (size_t)ctx->heavy_cap * sizeof(uint32_t) + 64));
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_hits, (size_t)ctx->heavy_cap * sizeof(float4)));
+        CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_hits_all, (size_t)std::max<uint64_t>(ray_cap, px) * sizeof(float4)));  // (level 0 holds px rays, a deeper level at most ray_cap)
         A.s_ray_cap = (uint32_t)ray_cap; A.s_shadow_cap = (uint32_t)shadow_cap; A.s_node_cap = (uint32_t)node_cap;
         ctx->stream_items = n_items;
-        ctx->queue_bytes = ray_cap * 64 + shadow_cap * 33 + node_cap * 32 + (size_t)ctx->heavy_cap * 24;
+        ctx->queue_bytes = ray_cap * 64 + shadow_cap * 33 + node_cap * 32 + (size_t)ctx->heavy_cap * 24 + std::max<uint64_t>(ray_cap, px) * 16;
     }
     A.s_rayq[0] = ctx->d_rayq[0]; A.s_rayq[1] = ctx->d_rayq[1];
     A.s_shadowq = ctx->d_shadowq; A.s_occluded = ctx->d_occluded; A.s_nodes = ctx->d_nodes;
-    A.s_heavy = ctx->d_heavy; A.s_sheavy = ctx->d_sheavy; A.s_hits = ctx->d_hits; A.s_heavy_cap = ctx->heavy_cap;
+    A.s_heavy = ctx->d_heavy; A.s_sheavy = ctx->d_sheavy; A.s_hits = ctx->d_hits; A.s_hits_all = ctx->d_hits_all; A.s_heavy_cap = ctx->heavy_cap;
     return CRT_OK;
 }
 
@@ -1078,8 +1081,14 @@ static int launch_stream_levels(crt_ctx *ctx, const crt_options *o, FramePlan &P
             level_blocks = std::min(P.lane_blocks, want);
         }
         if (P.count) { if (P.gi) launch(stream_trace_shade<true, true>, P.lane_blocks, stream, A, g); else launch(stream_trace_shade<true>, P.lane_blocks, stream, A, g); }
-        else if (P.wide) launch_lds(P.gi ? stream_trace_shade_plan_wide_gi : stream_trace_shade_plan_wide, level_blocks, plds, stream, A, g);
-        else if (P.lean) launch_lds(P.gi ? stream_trace_shade_plan_gi : stream_trace_shade_plan, level_blocks, plds, stream, A, g);
+        else if (P.lean && P.gi) {
+            // the GI mode: the walk alone, then the level's shading -- sample directions, gi_samples child rays -- with every lane busy
+            // (kernel_plan.h, SPLIT; tools/gi_time.py hw14 960x540 d3 n2 r2: 42.3 ms on the device against 44.0 with the shading inside the walk)
+            launch_lds(P.wide ? stream_trace_plan_wide_gi : stream_trace_plan_gi, level_blocks, plds, stream, A, g);
+            launch(stream_shade_all<true>, level_blocks, stream, A, g);
+        }
+        else if (P.wide) launch_lds(stream_trace_shade_plan_wide, level_blocks, plds, stream, A, g);
+        else if (P.lean) launch_lds(stream_trace_shade_plan, level_blocks, plds, stream, A, g);
         else if (P.gi) launch(stream_trace_shade<false, true>, P.lane_blocks, stream, A, g);
         else launch(stream_trace_shade<false>, P.lane_blocks, stream, A, g);
         if (P.heavy) {

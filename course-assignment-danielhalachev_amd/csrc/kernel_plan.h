@@ -317,7 +317,10 @@ __device__ __forceinline__ uint32_t plan_list_pop(PlanList &PL) {
 // threaded nodes, material dispatch.  WIDE: the wide plan (SceneArgs::plan_wide).  Rays with a parallel axis and walks longer than the step budget go to heavy_trace_closest.
 // (Measured and removed, DESIGN.md section 7: 4-wide quad nodes with an LDS stack -- the same frame time; the same nearest slot
 // first with exact distance pruning on loose boxes -- grazing rays, the long walks, have nothing to prune before they hit.)
-template <bool WIDE, bool GI>
+// SPLIT: the walk only -- the closest hit goes to s_hits_all[r] and stream_shade_all (kernel_stream.h) shades the level in a
+// launch of its own, every lane busy; the GI mode's levels run this way (the sample code inlined into the walk loop costs it
+// 30 vector registers and 60 spilled scalar ones).
+template <bool WIDE, bool GI, bool SPLIT = false>
 __device__ __forceinline__ void shade_plan_level(const KernelArgs &A, const uint32_t gen) {
     if (A.wave_prio) __builtin_amdgcn_s_setprio(3);  // ahead of the bulk shadow pass's waves on this SIMD
     extern __shared__ uint32_t plan_lds[];  // mesh lists: A.s->plan_list_words x BLOCK
@@ -358,6 +361,7 @@ __device__ __forceinline__ void shade_plan_level(const KernelArgs &A, const uint
                     if (!P.covered) {
                         reinterpret_cast<uint32_t *>(A.f->s_nodes + 2 * (size_t)r)[3] = TN_SKIP;
                         level0_release_shadow_slots(A, r);
+                        if (SPLIT) A.f->s_hits_all[r] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(3u));
                         continue;
                     }
                     level0_ray<GI>(A, P, R);
@@ -369,6 +373,7 @@ __device__ __forceinline__ void shade_plan_level(const KernelArgs &A, const uint
                     ray_prepare(R);
                 }
                 if (R.parmask != 0) {
+                    if (SPLIT) A.f->s_hits_all[r] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(2u));
                     if (evict_ray(A.f->s_heavy, A.f->s_heavy_cap, A.f->s_counts + SC_HEAVY + gen, r, lane)) continue;
                     A.f->s_counts[SC_OVERFLOW] = 1;  // cannot walk it here: let the fallback redo the frame
                     continue;
@@ -383,6 +388,7 @@ __device__ __forceinline__ void shade_plan_level(const KernelArgs &A, const uint
                 mhave = false; mmin = INFINITY; mt = 0; mtri = 0;
                 have = false; tmin = INFINITY; bt = 0; btri = 0; bmesh = 0;
                 if (WIDE && !fits) {  // more meshes than this lane's list holds: the wave-per-ray kernel needs no list
+                    if (SPLIT) A.f->s_hits_all[r] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(2u));
                     if (evict_ray(A.f->s_heavy, A.f->s_heavy_cap, A.f->s_counts + SC_HEAVY + gen, r, lane)) state = ST_FETCH;
                     else { A.f->s_counts[SC_OVERFLOW] = 1; state = ST_FETCH; }
                 }
@@ -452,10 +458,14 @@ __device__ __forceinline__ void shade_plan_level(const KernelArgs &A, const uint
             }
             if (done) {
                 if (have) btri = A.s->leaf_tris[btri] & ~LAST;  // leaf entry -> triangle
-                shade_and_emit<false, GI>(A, gen, r, node_base, child_base, R, have, bt, btri, bmesh, nullptr, lane);
+                if constexpr (SPLIT) A.f->s_hits_all[r] = make_float4(bt, __uint_as_float(btri), __uint_as_float(bmesh), __uint_as_float(have ? 1u : 0u));
+                else shade_and_emit<false, GI>(A, gen, r, node_base, child_base, R, have, bt, btri, bmesh, nullptr, lane);
                 state = ST_FETCH;
             } else if (steps >= A.step_budget) {
-                if (evict_ray(A.f->s_heavy, A.f->s_heavy_cap, A.f->s_counts + SC_HEAVY + gen, r, lane)) state = ST_FETCH;
+                if (evict_ray(A.f->s_heavy, A.f->s_heavy_cap, A.f->s_counts + SC_HEAVY + gen, r, lane)) {
+                    if (SPLIT) A.f->s_hits_all[r] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(2u));
+                    state = ST_FETCH;
+                }
                 steps = 0;
             }
         }
@@ -465,6 +475,7 @@ __device__ __forceinline__ void shade_plan_level(const KernelArgs &A, const uint
 
 __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArgs A, const uint32_t gen) { shade_plan_level<false, false>(A, gen); }
 __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan_wide(const KernelArgs A, const uint32_t gen) { shade_plan_level<true, false>(A, gen); }
-// the GI / multi-sample mode's builds (RayTracer.cpp:90-104, 331-354): jittered level-0 samples, gi_samples child rays per diffuse hit
-__global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan_gi(const KernelArgs A, const uint32_t gen) { shade_plan_level<false, true>(A, gen); }
-__global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan_wide_gi(const KernelArgs A, const uint32_t gen) { shade_plan_level<true, true>(A, gen); }
+// The GI / multi-sample mode's builds (RayTracer.cpp:90-104, 331-354; jittered level-0 samples) are walk-only (SPLIT): stream_shade_all<true>
+// shades the level -- gi_samples child rays per diffuse hit.  (Measured for the plain frame too: HW14 344 vs 356, HW12 421 vs 432 Mpixels/s -- not used there.)
+__global__ __launch_bounds__(BLOCK) void stream_trace_plan_gi(const KernelArgs A, const uint32_t gen) { shade_plan_level<false, true, true>(A, gen); }
+__global__ __launch_bounds__(BLOCK) void stream_trace_plan_wide_gi(const KernelArgs A, const uint32_t gen) { shade_plan_level<true, true, true>(A, gen); }

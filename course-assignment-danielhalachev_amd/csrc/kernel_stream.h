@@ -442,6 +442,33 @@ __global__ __launch_bounds__(BLOCK) void stream_shade_evicted(const KernelArgs A
     }
 }
 
+// Shading of every ray of level `gen` whose walk a walk-only kernel (kernel_plan.h: SPLIT) finished: one ray per lane, all lanes busy.
+template <bool GI>
+__global__ __launch_bounds__(BLOCK) void stream_shade_all(const KernelArgs A, const uint32_t gen) {
+    if (A.wave_prio) __builtin_amdgcn_s_setprio(3);
+    const uint32_t lane = threadIdx.x & 63u;
+    if (A.f->s_counts[SC_OVERFLOW]) return;
+    const uint32_t count = stream_level_count(A, gen);
+    if (stream_level_is_whole_heavy(A, gen, count)) return;  // (no walk-only launch did anything: stream_shade_evicted has the level)
+    const uint32_t node_base = stream_level_base(A, gen);
+    const uint32_t child_base = node_base + count;
+    const float4 *in_q = A.f->s_rayq[gen & 1u];
+    for (uint32_t r = blockIdx.x * BLOCK + threadIdx.x; r < count; r += gridDim.x * BLOCK) {
+        const float4 h = A.f->s_hits_all[r];
+        if (__float_as_uint(h.w) >= 2u) continue;  // evicted (stream_shade_evicted shades it) or not a ray
+        Ray R;
+        if (gen == 0) level0_ray<GI>(A, level0_decode<GI>(A, r), R);
+        else {
+            const float4 q0 = in_q[2 * (size_t)r], q1 = in_q[2 * (size_t)r + 1];
+            R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
+            R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;
+            normalize3(R.dx, R.dy, R.dz);
+            ray_prepare(R);
+        }
+        shade_and_emit<false, GI>(A, gen, r, node_base, child_base, R, __float_as_uint(h.w) != 0, h.x, __float_as_uint(h.y), __float_as_uint(h.z), nullptr, lane);
+    }
+}
+
 // Every shadow ray of the frame: RayTracer::hasIntersection in tree mode (RayTracer.cpp:507-517 ->
 // AccelerationStructure.cpp:56-94).  Writes 1 to s_occluded[i] when the light is blocked.
 // The shadow queue is traced in two passes so that the first can overlap the deeper recursion levels:
