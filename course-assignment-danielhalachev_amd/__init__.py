@@ -139,7 +139,7 @@ DEVICE_SYMBOLS = ["crt_tuning_defaults", "crt_create_tuned", "crt_create", "crt_
                   "crt_built_tree_links", "crt_built_tree_indexes", "crt_built_tree_free", "crt_build_last_error",
                   "crt_multi_create", "crt_multi_set_camera", "crt_multi_render", "crt_multi_read_quantized", "crt_multi_get_stats",
                   "crt_multi_device_count", "crt_multi_context", "crt_multi_last_error", "crt_multi_destroy",
-                  "crt_multi_staged_parts", "crt_multi_peer_note", "crt_debug_multi_force_staged"]
+                  "crt_multi_staged_parts", "crt_multi_peer_note", "crt_debug_multi_force_staged", "crt_debug_multi_fail_next_alloc"]
 HOST_SYMBOLS = ["crt_host_scene_parse_file", "crt_host_scene_parse_text", "crt_host_scene_parse_text_ex",
                 "crt_host_scene_build_seconds", "crt_host_scene_free", "crt_host_scene_desc",
                 "crt_host_scene_settings", "crt_host_scene_camera", "crt_host_scene_mesh_count",
@@ -394,6 +394,12 @@ class Tracer:
         L.crt_multi_peer_note.restype = C.c_char_p
         L.crt_multi_peer_note.argtypes = [C.c_void_p]
         return L.crt_multi_peer_note(self._multi()).decode()
+
+    def fail_next_alloc(self):
+        """Tests: the next re-partition of a multi-device tracer stops half-way with CRT_ERR_NOMEM."""
+        L = lib()
+        L.crt_debug_multi_fail_next_alloc.argtypes = [C.c_void_p]
+        self._check(L.crt_debug_multi_fail_next_alloc(self._multi()))
 
     def force_staged(self, on=True):
         """Tests: every part but the first copies its tiles through pinned host memory, as if no device had peer access."""

@@ -1661,6 +1661,7 @@ struct crt_multi {
     std::vector<size_t> h_stage_tiles;
     std::string peer_note;
     bool force_staged = false;            // crt_debug_multi_force_staged: every part but the first staged (tests, one-GPU boxes)
+    bool fail_next_alloc = false;         // crt_debug_multi_fail_next_alloc: the next re-partition fails at a part's buffer (tests)
     std::vector<crt_rect> cached_rects;
     uint32_t n_all_items = 0;
     uint64_t pixels = 0;
@@ -1862,7 +1863,11 @@ extern "C" int crt_multi_render(crt_multi *M, const crt_options *o, const crt_re
             if (p != 0) {
                 if (M->d_packed[p]) (void)hipFree(M->d_packed[p]);
                 M->d_packed[p] = nullptr;
-                if (hipMalloc((void **)&M->d_packed[p], (part.size() ? part.size() : 1) * 192 * sizeof(float)) != hipSuccess) { M->error = "out of device memory"; return CRT_ERR_NOMEM; }
+                if (M->fail_next_alloc || hipMalloc((void **)&M->d_packed[p], (part.size() ? part.size() : 1) * 192 * sizeof(float)) != hipSuccess) {
+                    M->fail_next_alloc = false;  // (crt_debug_multi_fail_next_alloc: the rebuild stops half-way, as a failed allocation would leave it)
+                    M->error = "out of device memory";
+                    return CRT_ERR_NOMEM;
+                }
                 if ((M->staged[p] || M->force_staged) && part.size() > M->h_stage_tiles[p]) {
                     if (M->h_stage[p]) (void)hipHostFree(M->h_stage[p]);
                     M->h_stage[p] = nullptr;
@@ -1950,6 +1955,12 @@ extern "C" int crt_debug_multi_force_staged(crt_multi *M, int on) {
     if (!M) return CRT_ERR_INVALID;
     M->force_staged = on != 0;
     M->cached_rects.clear();  // the next render allocates the pinned buffers
+    return CRT_OK;
+}
+
+extern "C" int crt_debug_multi_fail_next_alloc(crt_multi *M) {
+    if (!M) return CRT_ERR_INVALID;
+    M->fail_next_alloc = true;
     return CRT_OK;
 }
 

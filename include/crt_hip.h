@@ -286,6 +286,7 @@ const char *crt_multi_last_error(const crt_multi *multi);
 uint32_t crt_multi_staged_parts(const crt_multi *multi);
 const char *crt_multi_peer_note(const crt_multi *multi);
 int crt_debug_multi_force_staged(crt_multi *multi, int on); /* tests: stage every part, as if no device had peer access */
+int crt_debug_multi_fail_next_alloc(crt_multi *multi);       /* tests: the next re-partition stops at a part's buffer with CRT_ERR_NOMEM */
 void crt_multi_destroy(crt_multi *multi);
 
 /* ---- the reference's tree built on the GPU (KDTree<T>::build, KDTree.cpp:10-46 / :89-125; BoundingBox.h:60-83): level by

@@ -385,6 +385,19 @@ def test_multi_device_tracer_without_peer_access_stages_its_tiles(pkg, scenes, o
     assert_same_floats(tracer.render(max_depth=depth), want, "peer copies again")
 
 
+def test_multi_device_tracer_redoes_a_partition_that_failed_half_way(pkg, scenes, oracle):
+    """A re-partition that stops at a failed allocation leaves no cached rectangles behind: the call reports the error, and the
+    next call with the very same rectangles rebuilds everything instead of launching into half-built buffers."""
+    scene, depth, _ = small_case(scenes, "hw11")
+    want, _ = oracle.OracleScene(scenes.to_blob(scene)).render(depth)
+    tracer = pkg.Tracer(pkg.Scene(json_text=scenes.to_json(scene)), devices=[0, 0])
+    tracer.fail_next_alloc()
+    with pytest.raises(Exception):
+        tracer.render(max_depth=depth)
+    assert_same_floats(tracer.render(max_depth=depth), want, "after the failed partition")
+    assert_same_floats(tracer.render(max_depth=depth), want, "and with the partition cached")
+
+
 def test_multi_device_tracer_keeps_uncovered_pixels(pkg, scenes, oracle):
     # bucket_size 7 on 100x60 covers part of the frame only (SURVEY.md section 8 Q5): coverage masks travel with the tiles
     scene = scenes.make("hw08", width=100, height=60, detail=0.3)
