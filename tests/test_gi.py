@@ -239,6 +239,19 @@ def test_gi_frame_on_every_kernel_path(pkg, scenes, oracle, name, meshes, tuning
 
 
 @pytest.mark.gpu
+def test_gi_frame_that_overflows_fixed_queues_is_redone_by_the_lane_kernel(pkg, scenes, oracle):
+    """Explicit capacities (crt_tuning) are never regrown: a GI frame that overflows them is redone in the same call by
+    render_lanes<., true>, the queue-less last resort -- same frame, and crt_stats says so."""
+    scene = scenes.make("hw11", width=96, height=64, detail=0.2)
+    want, _ = oracle.OracleScene(scenes.to_blob(scene)).render(options=oracle.make_options(2, use_gi=1, gi_sample_size=2, rays_per_pixel=2, gi_seed=9))
+    tracer = pkg.Tracer(pkg.Scene(json_text=scenes.to_json(scene)), tuning=pkg.make_tuning(ray_cap=512))
+    for frame in (1, 2):
+        got = tracer.render(options=pkg.make_options(2, use_gi=True, gi_sample_size=2, rays_per_pixel=2, gi_seed=9))
+        assert_same_floats(got, want, "GI frame through the last resort")
+        assert tracer.stats().fallback_frames == frame
+
+
+@pytest.mark.gpu
 def test_gi_frame_does_not_depend_on_how_the_image_is_split(pkg, scenes, oracle):
     """Keys are (seed, pixel, sample, position in the ray tree): the same frame from one context, from two contexts sharing the
     tiles (crt_multi with the same device twice), and under every bucket mode of RayTracer::render."""
