@@ -473,7 +473,7 @@ __device__ __forceinline__ void shade_plan_level(const KernelArgs &A, const uint
     exec_counters_flush(A, nbox, ntri, lane, nplan);
 }
 
-__global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan(const KernelArgs A, const uint32_t gen) { shade_plan_level<false, false>(A, gen); }
+__global__ __launch_bounds__(BLOCK, 4) void stream_trace_shade_plan(const KernelArgs A, const uint32_t gen) { shade_plan_level<false, false>(A, gen); }
 __global__ __launch_bounds__(BLOCK) void stream_trace_shade_plan_wide(const KernelArgs A, const uint32_t gen) { shade_plan_level<true, false>(A, gen); }
 // The GI / multi-sample mode's builds (RayTracer.cpp:90-104, 331-354; jittered level-0 samples) are walk-only (SPLIT): stream_shade_all<true>
 // shades the level -- gi_samples child rays per diffuse hit.  (Measured for the plain frame too: HW14 344 vs 356, HW12 421 vs 432 Mpixels/s -- not used there.)
