@@ -1092,7 +1092,7 @@ static int launch_stream_levels(crt_ctx *ctx, const crt_options *o, FramePlan &P
         else if (P.gi) launch(stream_trace_shade<false, true>, P.lane_blocks, stream, A, g);
         else launch(stream_trace_shade<false>, P.lane_blocks, stream, A, g);
         if (P.heavy) {
-            launch(P.gi ? heavy_trace_closest_gi : heavy_trace_closest, HEAVY_BLOCKS, stream, A, g);
+            launch(P.gi ? heavy_trace_closest_gi : P.exec_count ? heavy_trace_closest_tally : heavy_trace_closest, HEAVY_BLOCKS, stream, A, g);
             if (P.gi) launch(stream_shade_evicted<false, true>, 256u, stream, A, g);
             else launch(stream_shade_evicted<false>, 256u, stream, A, g);
         }
@@ -1115,7 +1115,7 @@ static int launch_stream_levels(crt_ctx *ctx, const crt_options *o, FramePlan &P
             // caller's stream waits for, so nothing the later pass appends is below it
             if (P.heavy) hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, where, S, (uint32_t)SC_SHEAVY_SPLIT, (uint32_t)SC_SHEAVY);
             CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s1[P.slot], where));
-            if (P.heavy) launch(heavy_trace_shadow, HEAVY_BLOCKS, where, S, 0u);
+            if (P.heavy) launch(P.exec_count ? heavy_trace_shadow_tally : heavy_trace_shadow, HEAVY_BLOCKS, where, S, 0u);
             CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s2[P.slot], where));
         }
     }
@@ -1148,7 +1148,7 @@ static int launch_stream_tail(crt_ctx *ctx, FramePlan &P, KernelArgs &A, hipStre
     else if (P.lean) launch(stream_trace_shadow_plan<1>, P.lane_blocks, stream, S1);
     else launch(stream_trace_shadow<false>, P.lane_blocks, stream, S1, 1u);
     if (side_per_cu) CRT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_s2[P.slot], 0));
-    if (P.heavy) launch(heavy_trace_shadow, HEAVY_BLOCKS, stream, S1, 1u);
+    if (P.heavy) launch(P.exec_count ? heavy_trace_shadow_tally : heavy_trace_shadow, HEAVY_BLOCKS, stream, S1, 1u);
     CRT_HIP_CHECK(ctx, hipGetLastError());
     CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev2[P.slot], stream));
     A.counters = ctx->d_counters + 2 * C_N;

@@ -61,12 +61,12 @@ __device__ __forceinline__ float wave_min(float v) {
 }
 
 // One batch of up to 64 triangles (lane j tests list entry e when `valid`), lanes in list order.
-template <bool SHADOW>
+template <bool SHADOW, bool EXEC>
 __device__ __forceinline__ void heavy_batch(const KernelArgs &A, const Ray &R, const bool primary, const bool valid,
                                             const size_t e, HeavyState &H) {
     const float4 a = A.s->ltris[4 * e + 0], b = A.s->ltris[4 * e + 1], c = A.s->ltris[4 * e + 2], d = A.s->ltris[4 * e + 3];
     float t = 0;
-    if (A.exec_count) { H.ntri += (uint32_t)__popcll(__ballot(valid)); H.n_batches++; }
+    if (EXEC) { H.ntri += (uint32_t)__popcll(__ballot(valid)); H.n_batches++; }
     const bool acc = valid && triangle_test(R, primary, a, b, c, d.x, t);
     const unsigned long long am = __ballot(acc);
     if (!am) return;
@@ -95,7 +95,7 @@ __device__ __forceinline__ void heavy_batch(const KernelArgs &A, const Ray &R, c
 // The triangles of all leaves of one 64-leaf chunk whose box the ray passes (`hit` lanes: leaf = lane,
 // list [begin, begin+count)), concatenated in leaf order and tested 64 at a time.  The concatenation is laid
 // over the lanes with wave-uniform arithmetic: `off` lanes of the batch under construction are taken.
-template <bool SHADOW>
+template <bool SHADOW, bool EXEC>
 __device__ __forceinline__ void heavy_leaves(const KernelArgs &A, const Ray &R, const bool primary, const bool hit,
                                              const uint32_t begin, const uint32_t count, HeavyState &H, const uint32_t lane) {
     unsigned long long m = __ballot(hit);
@@ -112,13 +112,13 @@ __device__ __forceinline__ void heavy_leaves(const KernelArgs &A, const Ray &R, 
             off += take; bg += take; cnt -= take;
             if (off == 64u) {
                 H.guard--;
-                heavy_batch<SHADOW>(A, R, primary, valid, (size_t)e, H);
+                heavy_batch<SHADOW, EXEC>(A, R, primary, valid, (size_t)e, H);
                 off = 0;
                 valid = false;
             }
         }
     }
-    if (off && H.go()) heavy_batch<SHADOW>(A, R, primary, valid, (size_t)e, H);
+    if (off && H.go()) heavy_batch<SHADOW, EXEC>(A, R, primary, valid, (size_t)e, H);
 }
 
 struct ChunkBoxes { float4 b0, b1; bool valid; };
@@ -134,13 +134,13 @@ __device__ __forceinline__ ChunkBoxes heavy_chunk_load(const KernelArgs &A, cons
     return C;
 }
 
-template <int LEVEL, bool SHADOW>
+template <int LEVEL, bool SHADOW, bool EXEC>
 __device__ __forceinline__ void heavy_chunk(const KernelArgs &A, const Ray &R, const bool primary, const HeavyMesh &M,
                                             const uint32_t chunk, const ChunkBoxes &C, HeavyState &H, const uint32_t lane) {
-    if (A.exec_count) { H.nbox += (uint32_t)__popcll(__ballot(C.valid)); H.n_chunks++; }
+    if (EXEC) { H.nbox += (uint32_t)__popcll(__ballot(C.valid)); H.n_chunks++; }
     bool hit = C.valid && slab_test(R, C.b0.x, C.b0.y, C.b0.z, C.b1.x, C.b1.y, C.b1.z);
     if constexpr (LEVEL == 0) {
-        if (__ballot(hit)) heavy_leaves<SHADOW>(A, R, primary, hit, __float_as_uint(C.b0.w), __float_as_uint(C.b1.w), H, lane);
+        if (__ballot(hit)) heavy_leaves<SHADOW, EXEC>(A, R, primary, hit, __float_as_uint(C.b0.w), __float_as_uint(C.b1.w), H, lane);
     } else {
         unsigned long long m = __ballot(hit);
         if (!m) return;
@@ -149,7 +149,7 @@ __device__ __forceinline__ void heavy_chunk(const KernelArgs &A, const Ray &R, c
             const int k = __ffsll((long long)m) - 1;
             m &= m - 1;
             const ChunkBoxes cur = heavy_chunk_load<LEVEL - 1>(A, M, chunk * 64u + (uint32_t)k, lane);
-            heavy_chunk<LEVEL - 1, SHADOW>(A, R, primary, M, chunk * 64u + (uint32_t)k, cur, H, lane);
+            heavy_chunk<LEVEL - 1, SHADOW, EXEC>(A, R, primary, M, chunk * 64u + (uint32_t)k, cur, H, lane);
         }
     }
 }
@@ -166,12 +166,12 @@ struct TinyResults {  // per lane k < tiny_count: the closest hit in single-leaf
     uint32_t mtri;
 };
 
-template <bool SHADOW>
+template <bool SHADOW, bool EXEC>
 __device__ __forceinline__ void heavy_tiny_batch(const KernelArgs &A, const Ray &R, const bool primary, const bool valid, const size_t e,
                                                  const uint32_t tag, unsigned long long tags, TinyResults &T, HeavyState &H, const uint32_t lane) {
     const float4 a = A.s->ltris[4 * e + 0], b = A.s->ltris[4 * e + 1], c = A.s->ltris[4 * e + 2], d = A.s->ltris[4 * e + 3];
     float t = 0;
-    if (A.exec_count) { H.ntri += (uint32_t)__popcll(__ballot(valid)); H.n_batches++; }
+    if (EXEC) { H.ntri += (uint32_t)__popcll(__ballot(valid)); H.n_batches++; }
     const bool acc = valid && triangle_test(R, primary, a, b, c, d.x, t);
     if (!__ballot(acc)) return;
     while (tags) {  // the meshes that have triangles in this batch, one masked reduction each (registers only)
@@ -201,7 +201,7 @@ __device__ __forceinline__ void heavy_tiny_batch(const KernelArgs &A, const Ray 
     }
 }
 
-template <bool SHADOW>
+template <bool SHADOW, bool EXEC>
 __device__ __forceinline__ void heavy_tiny_meshes(const KernelArgs &A, const Ray &R, const bool primary, TinyResults &T, HeavyState &H,
                                                   const uint32_t lane) {
     T.have = false; T.mmin = INFINITY; T.mt = 0; T.mtri = 0;
@@ -210,7 +210,7 @@ __device__ __forceinline__ void heavy_tiny_meshes(const KernelArgs &A, const Ray
     const size_t at = valid ? A.s->tiny_at[lane] : A.s->tiny_at[0];
     const uint32_t flags = valid ? A.s->tiny_flags[lane] : 0u;
     const float4 b0 = A.s->hbox[2 * at], b1 = A.s->hbox[2 * at + 1];
-    if (A.exec_count) H.nbox += A.s->tiny_count;
+    if (EXEC) H.nbox += A.s->tiny_count;
     const bool hit = valid && !(SHADOW && (flags & 1u) && !A.f->use_gi) && slab_test(R, b0.x, b0.y, b0.z, b1.x, b1.y, b1.z);
     unsigned long long m = __ballot(hit);
     if (!m) return;
@@ -230,16 +230,16 @@ __device__ __forceinline__ void heavy_tiny_meshes(const KernelArgs &A, const Ray
             off += take; bg += take; cnt -= take;
             if (off == 64u) {
                 H.guard--;
-                heavy_tiny_batch<SHADOW>(A, R, primary, tvalid, (size_t)e, tag, tags, T, H, lane);
+                heavy_tiny_batch<SHADOW, EXEC>(A, R, primary, tvalid, (size_t)e, tag, tags, T, H, lane);
                 off = 0; tvalid = false; tags = 0;
             }
         }
     }
-    if (off) heavy_tiny_batch<SHADOW>(A, R, primary, tvalid, (size_t)e, tag, tags, T, H, lane);
+    if (off) heavy_tiny_batch<SHADOW, EXEC>(A, R, primary, tvalid, (size_t)e, tag, tags, T, H, lane);
 }
 
 // closest hit of the (wave-uniform) ray in one mesh
-template <bool SHADOW>
+template <bool SHADOW, bool EXEC>
 __device__ __forceinline__ void heavy_mesh(const KernelArgs &A, const Ray &R, const bool primary, const uint32_t mesh,
                                            HeavyState &H, const uint32_t lane) {
     const HeavyMesh M = A.s->hmesh[mesh];
@@ -250,10 +250,10 @@ __device__ __forceinline__ void heavy_mesh(const KernelArgs &A, const Ray &R, co
     H.mt = 0;
     H.mtri = 0;
     switch (M.n_levels) {
-        case 1: heavy_chunk<0, SHADOW>(A, R, primary, M, 0, heavy_chunk_load<0>(A, M, 0, lane), H, lane); break;
-        case 2: heavy_chunk<1, SHADOW>(A, R, primary, M, 0, heavy_chunk_load<1>(A, M, 0, lane), H, lane); break;
-        case 3: heavy_chunk<2, SHADOW>(A, R, primary, M, 0, heavy_chunk_load<2>(A, M, 0, lane), H, lane); break;
-        case 4: heavy_chunk<3, SHADOW>(A, R, primary, M, 0, heavy_chunk_load<3>(A, M, 0, lane), H, lane); break;
+        case 1: heavy_chunk<0, SHADOW, EXEC>(A, R, primary, M, 0, heavy_chunk_load<0>(A, M, 0, lane), H, lane); break;
+        case 2: heavy_chunk<1, SHADOW, EXEC>(A, R, primary, M, 0, heavy_chunk_load<1>(A, M, 0, lane), H, lane); break;
+        case 3: heavy_chunk<2, SHADOW, EXEC>(A, R, primary, M, 0, heavy_chunk_load<2>(A, M, 0, lane), H, lane); break;
+        case 4: heavy_chunk<3, SHADOW, EXEC>(A, R, primary, M, 0, heavy_chunk_load<3>(A, M, 0, lane), H, lane); break;
         default: break;
     }
 }
@@ -284,7 +284,7 @@ __device__ __forceinline__ TopRegs heavy_top_load(const KernelArgs &A, const uin
 // The top-level tree comes in one of two forms: in registers (TopRegs, <= 64 nodes), or as its LEAF SEQUENCE (SceneArgs::plan_boxes,
 // any size: the leaves in visit order, 64 boxes per instruction -- the argument at the top of this file holds for the top-level
 // tree as it does for a mesh's).  (A tree with neither form -- its nodes not one index range -- keeps its rays in the per-lane kernels.)
-template <bool SHADOW>
+template <bool SHADOW, bool EXEC>
 __device__ __forceinline__ void heavy_walk(const KernelArgs &A, TopRegs &TR, const Ray &R, const bool primary, const float light_dist,
                                            bool &have, float &bt, uint32_t &btri, uint32_t &bmesh, bool &occluded,
                                            const uint32_t lane) {
@@ -299,7 +299,7 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, TopRegs &TR, con
     H.light_dist = light_dist;
     H.nbox = 0; H.ntri = 0; H.n_chunks = 0; H.n_batches = 0; H.n_meshes = 0;
     TinyResults T;
-    heavy_tiny_meshes<SHADOW>(A, R, primary, T, H, lane);
+    heavy_tiny_meshes<SHADOW, EXEC>(A, R, primary, T, H, lane);
     const bool fast = A.s->top_fast != 0;
     // one mesh of a top-level leaf's list, in list order; false: the walk is over (a shadow ray found its occluder)
     auto visit_mesh = [&](const uint32_t mi, const uint32_t mflags, const uint32_t mpad) -> bool {
@@ -311,8 +311,8 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, TopRegs &TR, con
             H.mtri = lane_value(T.mtri, k);
             H.mmin = lane_value(T.mmin, k);
         } else {
-            if (A.exec_count) H.n_meshes++;
-            heavy_mesh<SHADOW>(A, R, primary, mi, H, lane);
+            if (EXEC) H.n_meshes++;
+            heavy_mesh<SHADOW, EXEC>(A, R, primary, mi, H, lane);
         }
         if (SHADOW && H.stop) { occluded = true; return false; }
         if (H.mhave) {
@@ -340,7 +340,7 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, TopRegs &TR, con
                     H.guard--;
                     const int i = (int)(ti - A.s->top_first);
                     const uint32_t miss = lane_value(__float_as_uint(TR.q0.w), i), link = lane_value(__float_as_uint(TR.q1.w), i);
-                    H.nbox++;
+                    if (EXEC) H.nbox++;
                     if (!((top_hits >> i) & 1ull)) { ti = miss; continue; }
                     if (!is_leaf_link(link)) { ti = link; continue; }
                     e = link & ~LEAF; next_ti = miss;
@@ -382,7 +382,7 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, TopRegs &TR, con
             const bool valid = k < A.s->plan_leaves;
             const float4 *L = reinterpret_cast<const float4 *>(A.s->plan_boxes) + 4 * (size_t)(valid ? k : 0u);
             TR.q0 = L[0]; TR.q1 = L[1];
-            H.nbox += (uint32_t)__popcll(__ballot(valid));
+            if (EXEC) H.nbox += (uint32_t)__popcll(__ballot(valid));
             leaves = __ballot(valid && slab_test(R, TR.q0.x, TR.q0.y, TR.q0.z, TR.q1.x, TR.q1.y, TR.q1.z));
             chunk++;
         }
@@ -392,7 +392,7 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, TopRegs &TR, con
         if (!next_mesh(mi, mflags, mpad) || !visit_mesh(mi, mflags, mpad) || !H.go()) break;
     }
     if (!H.guard && lane == 0) { A.f->s_counts[SC_GUARD] = 1; A.f->s_counts[SC_OVERFLOW] = 1; }  // bound hit: let the fallback redo the frame
-    if (A.exec_count && lane == 0) {
+    if (EXEC && lane == 0) {
         atomicAdd(&A.exec_counters[0], (unsigned long long)H.nbox); atomicAdd(&A.exec_counters[1], (unsigned long long)H.ntri);
         uint32_t *diag = A.f->s_counts + SC_HEAVY_DIAG + (SHADOW ? 8 : 0);  // tools/stream_stats.py: what a wave-per-ray walk consists of
         atomicAdd(diag + 0, 1u); atomicAdd(diag + 1, H.n_chunks); atomicAdd(diag + 2, H.n_batches); atomicAdd(diag + 3, H.n_meshes);
@@ -403,7 +403,7 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, TopRegs &TR, con
 __device__ __forceinline__ float uniform_f(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
 
 // closest hits of the rays evicted from stream_trace_shade(gen); results go to s_hits[k] for list entry k
-template <bool GI>
+template <bool GI, bool EXEC>
 __device__ __forceinline__ void heavy_closest_level(const KernelArgs &A, const uint32_t gen) {
     if (A.wave_prio) __builtin_amdgcn_s_setprio(3);  // ahead of the bulk shadow pass's waves on this SIMD
     const uint32_t lane = threadIdx.x & 63u;
@@ -441,16 +441,19 @@ __device__ __forceinline__ void heavy_closest_level(const KernelArgs &A, const u
         bool have = false, occluded = false;
         float bt = 0;
         uint32_t btri = 0, bmesh = 0;
-        heavy_walk<false>(A, TR, R, primary, 0.0f, have, bt, btri, bmesh, occluded, lane);
+        heavy_walk<false, EXEC>(A, TR, R, primary, 0.0f, have, bt, btri, bmesh, occluded, lane);
         if (lane == 0) A.f->s_hits[k] = make_float4(bt, __uint_as_float(btri), __uint_as_float(bmesh), __uint_as_float(have ? 1u : 0u));
     }
 }
-__global__ __launch_bounds__(BLOCK, 5) void heavy_trace_closest(const KernelArgs A, const uint32_t gen) { heavy_closest_level<false>(A, gen); }
-__global__ __launch_bounds__(BLOCK, 5) void heavy_trace_closest_gi(const KernelArgs A, const uint32_t gen) { heavy_closest_level<true>(A, gen); }  // (level 0: jittered samples)
+__global__ __launch_bounds__(BLOCK, 5) void heavy_trace_closest(const KernelArgs A, const uint32_t gen) { heavy_closest_level<false, false>(A, gen); }
+__global__ __launch_bounds__(BLOCK, 5) void heavy_trace_closest_gi(const KernelArgs A, const uint32_t gen) { heavy_closest_level<true, false>(A, gen); }  // (level 0: jittered samples)
+// the build that tallies the tests it executes (crt_options::collect_counters == 2): its five tallies are wave-uniform state the walk has no registers for
+__global__ __launch_bounds__(BLOCK, 5) void heavy_trace_closest_tally(const KernelArgs A, const uint32_t gen) { heavy_closest_level<false, true>(A, gen); }
 
 // part 0: the walks shadow pass 0 gave up (list entries below the SC_SHEAVY_SPLIT mark), on the side stream right
 // after that pass; part 1: the rest, after the last pass.
-__global__ __launch_bounds__(BLOCK) void heavy_trace_shadow(const KernelArgs A, const uint32_t part) {
+template <bool EXEC>
+__device__ __forceinline__ void heavy_shadow_part(const KernelArgs &A, const uint32_t part) {
     const uint32_t lane = threadIdx.x & 63u;
     if (A.f->s_counts[SC_OVERFLOW]) return;
     uint32_t total = A.f->s_counts[SC_SHEAVY], split = A.f->s_counts[SC_SHEAVY_SPLIT];
@@ -473,7 +476,9 @@ __global__ __launch_bounds__(BLOCK) void heavy_trace_shadow(const KernelArgs A, 
         bool have, occluded;
         float bt = 0;
         uint32_t btri = 0, bmesh = 0;
-        heavy_walk<true>(A, TR, R, false, uniform_f(q0.w), have, bt, btri, bmesh, occluded, lane);
+        heavy_walk<true, EXEC>(A, TR, R, false, uniform_f(q0.w), have, bt, btri, bmesh, occluded, lane);
         if (lane == 0) A.f->s_occluded[r] = occluded ? 1 : 0;
     }
 }
+__global__ __launch_bounds__(BLOCK) void heavy_trace_shadow(const KernelArgs A, const uint32_t part) { heavy_shadow_part<false>(A, part); }
+__global__ __launch_bounds__(BLOCK) void heavy_trace_shadow_tally(const KernelArgs A, const uint32_t part) { heavy_shadow_part<true>(A, part); }
