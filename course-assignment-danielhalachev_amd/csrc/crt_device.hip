@@ -661,7 +661,7 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
         A.nested_boxes = nested ? 1u : 0u;
     }
     {
-        // The plan of the top-level tree (kernel_plan.h, kernel_group.h): its leaves in visit order, which is index order.
+        // The plan of the top-level tree (kernel_plan.h; kernel_heavy.h walks the same table as a leaf sequence): its leaves in visit order, which is index order.
         std::vector<float4> boxes, boxes_all;
         std::vector<uint32_t> order, order_all;  // non-refractive meshes / every mesh (the GI mode's shadow rays), most leaves first
         for (uint32_t m = 0; m < s->n_meshes; m++) {
@@ -837,7 +837,7 @@ static int ensure_items(crt_ctx *ctx, size_t n) {
     if (ctx->d_items) (void)hipFree(ctx->d_items);
     ctx->d_items = nullptr;
     ctx->items_cap = 0;
-    CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_items, (n + 4) * sizeof(WorkItem)));  // (+: the group kernels read 48 bytes per record)
+    CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_items, (n + 4) * sizeof(WorkItem)));  // (+: padding, so that a 16-byte read at the last record stays inside)
     ctx->items_cap = n;
     ctx->cached_rects.clear();
     ctx->cached_is_partition = false;
@@ -976,7 +976,7 @@ static int ensure_stream(crt_ctx *ctx, uint32_t n_items) {
         for (void **b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
         ctx->stream_items = 0;
         A.s_node_cap = A.s_ray_cap = A.s_shadow_cap = 0;
-        // (+ 64 bytes: the group kernels read 48 bytes per record, whatever its kind)
+        // (+ 64 bytes of padding behind the queues)
         for (int i = 0; i < 2; i++) CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_rayq[i], ray_cap * 2 * sizeof(float4) + 64));
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_shadowq, shadow_cap * 2 * sizeof(float4) + 64));
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_occluded, shadow_cap));

@@ -132,7 +132,7 @@ __device__ __forceinline__ void level0_release_shadow_slots(const KernelArgs &A,
 // shootRay's dispatch on the closest hit (RayTracer.cpp:431-450), in two steps.  shade_hit: everything but the child
 // rays' queue slots -- the ray-tree node's contents, the shadow rays (appended to the shadow queue), and the child rays
 // themselves (reflection, and transmission for a refractive hit without total internal reflection).  The caller then
-// allocates the children and stores the node: shade_and_emit for the per-level queues, kernel_deep.h for the level-free one.
+// allocates the children and stores the node (shade_and_emit).
 struct Shaded {
     TNode N;               // N.a / N.b: CHILD_BG / CHILD_NONE / 0 until the caller fills in the children's node indices
     bool reflect, transmit;  // child rays to trace (false beyond MAX_DEPTH: such a child is background without tracing)
