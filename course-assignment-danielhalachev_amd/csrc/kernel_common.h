@@ -129,7 +129,7 @@ struct FrameArgs {
     float4 *s_hits_all;           // ... of every ray of the current level, by ray index, when the per-lane walk leaves the shading to stream_shade_all
                                   //     (w: 0 / 1 no hit / hit, 2 evicted -- stream_shade_evicted shades it --, 3 not a ray)
     uint32_t heavy_level_threshold; // a recursion level with fewer rays than this goes to heavy_trace whole
-    uint32_t fixed0;              // level 0's shadow rays go to fixed, tile-ordered slots (kernel_stream.h: level0_shadow_slot)
+    uint32_t fixed0;              // level 0's shadow rays go to fixed, tile-ordered slots (kernel_stream.h: level0_shadow_place)
     uint32_t use_gi, gi_samples, rays_per_pixel, gi_seed;  // crt_options: the GI / multi-sample mode (kernel_stream.h, kernel_lane.h, gi_random.h)
     uint32_t level0_samples;      // rays per pixel at level 0 of the ray-stream pass: max(1, rays_per_pixel) in the GI mode, else 1
     float monte_carlo_bias;
