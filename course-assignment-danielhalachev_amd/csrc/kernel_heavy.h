@@ -328,29 +328,26 @@ __device__ __forceinline__ void heavy_walk(const KernelArgs &A, TopRegs &TR, con
     };
     // The meshes of the top-level leaves the ray reaches, one per call, in the reference's order (all state wave-uniform but the
     // registers of TR, which in the leaf-sequence form hold the current 64 leaves and the current 64 list entries).
-    uint32_t ti = A.s->top_root, next_ti = END;          // registers form: node, and the node after the current leaf
     uint32_t e = NONE;                                    // both forms: next entry of the current leaf's list (NONE: not in a leaf)
     uint32_t chunk = 0, left = 0, bi = 0, bn = 0;         // leaf-sequence form: next chunk, entries left in the list, batch cursor / size
     unsigned long long leaves = 0;                        // ... leaves of the current chunk that pass and are still to visit
-    const unsigned long long top_hits = fast ? __ballot(lane < A.s->top_count && slab_test(R, TR.q0.x, TR.q0.y, TR.q0.z, TR.q1.x, TR.q1.y, TR.q1.z)) : 0ull;
+    // registers form: every top-level box against this ray in one instruction; the leaves among the nodes that pass are the leaves the
+    // reference reaches (nested boxes: a leaf's box passes only if all its ancestors' do), in index order, which is visit order
+    unsigned long long pending = fast ? __ballot(lane < A.s->top_count && is_leaf_link(__float_as_uint(TR.q1.w)) &&
+                                                 slab_test(R, TR.q0.x, TR.q0.y, TR.q0.z, TR.q1.x, TR.q1.y, TR.q1.z)) : 0ull;
+    if (EXEC && fast) H.nbox += A.s->top_count;
     auto next_mesh = [&](uint32_t &mi, uint32_t &mflags, uint32_t &mpad) -> bool {
         if (fast) {
             if (e == NONE) {
-                while (ti != END && H.go()) {  // node by node, uniformly; every box was tested above, in one instruction
-                    H.guard--;
-                    const int i = (int)(ti - A.s->top_first);
-                    const uint32_t miss = lane_value(__float_as_uint(TR.q0.w), i), link = lane_value(__float_as_uint(TR.q1.w), i);
-                    if (EXEC) H.nbox++;
-                    if (!((top_hits >> i) & 1ull)) { ti = miss; continue; }
-                    if (!is_leaf_link(link)) { ti = link; continue; }
-                    e = link & ~LEAF; next_ti = miss;
-                    break;
-                }
-                if (e == NONE) return false;
+                if (!pending || !H.go()) return false;
+                H.guard--;
+                const int i = __ffsll((long long)pending) - 1;
+                pending &= pending - 1ull;
+                e = lane_value(__float_as_uint(TR.q1.w), i) & ~LEAF;
             }
             const uint32_t ent = e < 64u ? lane_value(TR.entry, (int)e) : lane_value(TR.entry2, (int)(e - 64u));
             e++;
-            if (ent & LAST) { e = NONE; ti = next_ti; }
+            if (ent & LAST) e = NONE;
             mi = ent & ~LAST;
             mflags = lane_value(TR.mflags, (int)mi); mpad = lane_value(TR.mpad, (int)mi);
             return true;
