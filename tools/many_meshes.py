@@ -1,6 +1,6 @@
-"""Dev helper (GPU box): a room with N small meshes scattered through it -- the top-level tree is then larger than the
-tables the fast paths keep in registers / LDS (<= 64 nodes, <= 64 meshes) and the generic walks run.  Prints ms per frame at
-1920x1080 depth 8 and checks the frame against the counting build.  usage: python tools/many_meshes.py [N ...]"""
+"""Dev helper (GPU box): a room with N small meshes scattered through it -- beyond 64 top-level leaves or meshes the WIDE plan
+kernels run (up to 256 meshes; kernel_plan.h) and the wave-per-ray kernels walk the top-level leaf sequence.  Prints ms per frame at
+1920x1080 depth 8 and checks the frame against the counting build.  usage: python tools/many_meshes.py [N ...]   (CRT_TUNING is passed on)"""
 import importlib, sys, time
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
