@@ -43,11 +43,14 @@ def algorithmic_bytes(c, width, height, textured=False):
             + 12 * width * height)
 
 
-def cpu_baseline(sc, scene_name, depth, w, h, budget_s=30.0):
+def cpu_baseline(sc, scene_name, depth, w, h, budget_s=30.0, gpu_frame=None):
     """Times the REAL reference (oracle/_ref, built from /root/reference in the dev container and shipped as
     a binary) -- or, if that binary is absent, the oracle's C restatement -- on the same workload at the same
     resolution (one frame; about 9 s for the headline configuration on the GPU box's host cores).  A frame that
-    would take longer than the budget is sampled at a quarter of the width and height instead, and says so."""
+    would take longer than the budget is sampled at a quarter of the width and height instead, and says so.
+    The frame the reference renders here is not thrown away: `gpu_frame` (the last frame the timed region delivered to host
+    memory) is compared with it float for float -- the reference as CHECKER of the whole full-size frame, in this very run
+    (`frame_matches_gpu`, `differing_floats`; null when the baseline is a sample of another size)."""
     from oracle import oracle_api as oa
     full = (w, h)
     if w * h > 2500000:  # HW12 at 3840x2160 would take minutes: sample it
@@ -63,16 +66,24 @@ def cpu_baseline(sc, scene_name, depth, w, h, budget_s=30.0):
     buckets = int(scene["settings"]["image_settings"]["bucket_size"])
     size_note = "the full %dx%d frame" % (w, h) if (w, h) == full else "%dx%d (a 1/16 sample of %dx%d)" % (w, h, full[0], full[1])
     if oa.reference_available(textured=bool(scene.get("textures"))):
-        _, info = oa.reference_render(blob, max_depth=depth)
+        ref_frame, info = oa.reference_render(blob, max_depth=depth)
         rep = 1
         if info["render_s"] * 3 < budget_s:
             rep = max(1, min(8, int(budget_s / max(info["render_s"], 1e-3)) - 1))
-            _, info = oa.reference_render(blob, max_depth=depth, repeat=rep)
+            ref_frame, info = oa.reference_render(blob, max_depth=depth, repeat=rep)
         secs = info["render_s"]
+        matches, differing = None, None
+        if gpu_frame is not None and (w, h) == full:
+            import numpy as np
+            g = np.ascontiguousarray(gpu_frame, dtype=np.float32).reshape(h, w, 3)
+            diff = (g.view(np.uint32) != ref_frame.view(np.uint32)) & ~(np.isnan(g) & np.isnan(ref_frame))
+            differing = int(diff.sum())
+            matches = differing == 0
         # the reference's thread pool has hardware_concurrency threads, but only one job per bucket (RayTracer.cpp:141-158)
         busy = min(int(info["threads"]), buckets)
         return {"value": round(w * h / secs / 1e6, 5), "unit": "Mpixels/s", "cores": busy,
                 "kind": "reference", "host_threads": int(info["threads"]), "seconds": round(secs, 4),
+                "frame_matches_gpu": matches, "differing_floats": differing,
                 "sample": "same %s-like scene (%d triangles), %s, depth %d: the reference's own RayTracer::render "
                           "(oracle/_ref, BVHBucketsThreadPool mode: %d buckets, so at most %d busy threads of the %d the "
                           "pool starts), best of %d"
@@ -241,10 +252,11 @@ def main():
     # THE timed region: K frames, each one ending in pinned host memory on rank 0 (frame k's copy beside frame k + 1's kernels)
     elapsed = timed(args.steps, True)
     kernel_ms = tracer.kernel_times_ms(min(args.steps, 64))
-    host_ok = None
+    host_ok, host_frame = None, None
     if rank == 0:
         last = (step_no[0] - 1) % 2
         host_ok = bool(torch.equal(hosts2[last].view(torch.int32), frames2[last].cpu().view(torch.int32)))
+        host_frame = hosts2[last].numpy().copy()   # what the timed region delivered: compared with the reference's frame below
     # the same loop with the frame left in HBM (reported beside `value`)
     resident_elapsed = timed(args.steps, False)
 
@@ -259,53 +271,56 @@ def main():
     pipelined = None
     F = max(0, args.in_flight if args.in_flight is not None else 3)
     if F >= 2:
-        trs = [tracer] + [pkg.Tracer(hs, device=local_rank, tuning=pkg.tuning_from_string(args.tuning)) for _ in range(F - 1)]
-        strs = [torch.cuda.Stream(dev) for _ in range(F)]
-        packs = [packed] + [torch.zeros_like(packed) for _ in range(F - 1)]
-        gaths = [gathered] + [(torch.zeros_like(gathered) if dist_on else packs[i + 1]) for i in range(F - 1)]
-        frames_f = [frame] + [torch.zeros_like(frame) for _ in range(F - 1)] if rank == 0 else [frame] * F
-        reference_frame = frame.clone() if rank == 0 else None
+        try:   # (never lose the line -- `value` -- over the extra measurement: on several GPUs this path is rehearsed, not yet run)
+            trs = [tracer] + [pkg.Tracer(hs, device=local_rank, tuning=pkg.tuning_from_string(args.tuning)) for _ in range(F - 1)]
+            strs = [torch.cuda.Stream(dev) for _ in range(F)]
+            packs = [packed] + [torch.zeros_like(packed) for _ in range(F - 1)]
+            gaths = [gathered] + [(torch.zeros_like(gathered) if dist_on else packs[i + 1]) for i in range(F - 1)]
+            frames_f = [frame] + [torch.zeros_like(frame) for _ in range(F - 1)] if rank == 0 else [frame] * F
+            reference_frame = frame.clone() if rank == 0 else None
 
-        def pstep(k):
-            i = k % F
-            with torch.cuda.stream(strs[i]):
-                trs[i].render_tiles_device(opts, rank, world, packs[i].data_ptr(), strs[i].cuda_stream)
-                if dist_on and args.rehearse_gloo:
-                    strs[i].synchronize()
-                    parts = [torch.empty(part_floats) for _ in range(world)]
-                    dist.all_gather(parts, packs[i].cpu())
-                    gaths[i].copy_(torch.cat(parts))
-                elif dist_on:
-                    dist.all_gather_into_tensor(gaths[i], packs[i])
-                if rank == 0:
-                    trs[i].unpack_tiles_device(gaths[i].data_ptr(), world, part_floats, frames_f[i].data_ptr(), strs[i].cuda_stream)
+            def pstep(k):
+                i = k % F
+                with torch.cuda.stream(strs[i]):
+                    trs[i].render_tiles_device(opts, rank, world, packs[i].data_ptr(), strs[i].cuda_stream)
+                    if dist_on and args.rehearse_gloo:
+                        strs[i].synchronize()
+                        parts = [torch.empty(part_floats) for _ in range(world)]
+                        dist.all_gather(parts, packs[i].cpu())
+                        gaths[i].copy_(torch.cat(parts))
+                    elif dist_on:
+                        dist.all_gather_into_tensor(gaths[i], packs[i])
+                    if rank == 0:
+                        trs[i].unpack_tiles_device(gaths[i].data_ptr(), world, part_floats, frames_f[i].data_ptr(), strs[i].cuda_stream)
 
-        for k in range(max(args.warmup, 2 * F)):
-            pstep(k)
-        fence()
-        for t_ in trs:
-            t_.synchronize()
-        fb0 = sum(int(t_.stats().fallback_frames) for t_ in trs)
-        tp = time.perf_counter()
-        for k in range(args.steps):
-            pstep(k)
-        fence()
-        p_elapsed = time.perf_counter() - tp
-        if world > 1:
-            t = torch.tensor([p_elapsed], dtype=torch.float64, device=cdev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            p_elapsed = float(t.item())
-        for t_ in trs:
-            t_.synchronize()
-        p_fallback = sum(int(t_.stats().fallback_frames) for t_ in trs) - fb0
-        p_ok = None
-        if rank == 0:
-            p_ok = all(bool(torch.equal(f.view(torch.int32), reference_frame.view(torch.int32))) for f in frames_f)
-        pipelined = {"frames_in_flight": F, "value": round(W * H * args.steps / p_elapsed / 1e6, 3), "unit": "Mpixels/s",
-                     "ms_per_step": round(p_elapsed / args.steps * 1e3, 4), "frames_match_one_at_a_time": p_ok,
-                     "fallback_frames": p_fallback,
-                     "note": "the same K steps with frame k on context / stream k % F; every frame complete inside the timed region"}
-        del trs[1:], packs[1:], gaths[1:]
+            for k in range(max(args.warmup, 2 * F)):
+                pstep(k)
+            fence()
+            for t_ in trs:
+                t_.synchronize()
+            fb0 = sum(int(t_.stats().fallback_frames) for t_ in trs)
+            tp = time.perf_counter()
+            for k in range(args.steps):
+                pstep(k)
+            fence()
+            p_elapsed = time.perf_counter() - tp
+            if world > 1:
+                t = torch.tensor([p_elapsed], dtype=torch.float64, device=cdev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                p_elapsed = float(t.item())
+            for t_ in trs:
+                t_.synchronize()
+            p_fallback = sum(int(t_.stats().fallback_frames) for t_ in trs) - fb0
+            p_ok = None
+            if rank == 0:
+                p_ok = all(bool(torch.equal(f.view(torch.int32), reference_frame.view(torch.int32))) for f in frames_f)
+            pipelined = {"frames_in_flight": F, "value": round(W * H * args.steps / p_elapsed / 1e6, 3), "unit": "Mpixels/s",
+                         "ms_per_step": round(p_elapsed / args.steps * 1e3, 4), "frames_match_one_at_a_time": p_ok,
+                         "fallback_frames": p_fallback,
+                         "note": "the same K steps with frame k on context / stream k % F; every frame complete inside the timed region"}
+            del trs[1:], packs[1:], gaths[1:]
+        except Exception as e:
+            pipelined = {"frames_in_flight": F, "error": repr(e)}
 
     # every rank's production tiles matched its counting build's?  (and, for N > 1, does the gathered frame equal
     # a single-rank render of the whole frame on rank 0?)
@@ -470,12 +485,17 @@ def main():
         out["fallback_frames_before_timing"] = fallback_before  # start-up frames redone while the queue capacities settled
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(sc, args.scene, depth, W, H)
+                out["cpu_baseline"] = cpu_baseline(sc, args.scene, depth, W, H, gpu_frame=host_frame)
             except Exception as e:  # the baseline is a reported extra; never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
-        if pipelined and pipelined["frames_match_one_at_a_time"] is False:
+        cb = out.get("cpu_baseline") or {}
+        if cb.get("frame_matches_gpu") is False:
+            print("bench.py: FAILED self-check: the GPU frame differs from the reference's own frame in %d floats"
+                  % cb.get("differing_floats", -1), file=sys.stderr, flush=True)
+            failed = True
+        if pipelined and pipelined.get("frames_match_one_at_a_time") is False:
             print("bench.py: FAILED self-check: a frame of the pipelined run differs from the one-at-a-time frame", file=sys.stderr, flush=True)
             failed = True
         if not frame_ok or gathered_ok is False or fallback:

@@ -39,6 +39,7 @@
 #include <vector>
 
 #include "../../include/crt_hip.h"
+#include "crt_bvh.h"
 #include "glibc_powf.h"
 
 namespace {
@@ -48,6 +49,7 @@ namespace {
 #include "kernel_stream.h"
 #include "kernel_heavy.h"
 #include "kernel_plan.h"
+#include "kernel_bvh.h"
 
 // scatter gathered packed tiles into the row-major frame
 __global__ void unpack_kernel(const float *packed, uint32_t n_parts, uint64_t part_stride, float *frame, uint32_t width,
@@ -161,6 +163,8 @@ struct crt_ctx {
     uint64_t overflows = 0;           // frames redone by the fallback (diagnostic)
     uint32_t n_lights = 0;
     crt_tuning tuning{};
+    std::string bvh_note;             // why this scene has no candidate filter (empty: it has one)
+    std::string bvh_stats;            // ... and what it consists of
     unsigned long long *d_counters = nullptr;
     float *d_frames = nullptr;
     size_t frames_floats = 0;
@@ -362,6 +366,7 @@ extern "C" void crt_tuning_defaults(crt_tuning *t) {
     t->step_budget = 384; t->shadow_budget = 4096; t->level0_budget = 0;
     t->heavy_level = 100000; t->side_blocks = 3;
     t->node_cap = t->ray_cap = t->shadow_cap = 0;
+    t->bvh = 1;
 }
 
 extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) { return crt_create_tuned(s, device, nullptr, out); }
@@ -501,6 +506,7 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
     }
     std::vector<HeavyMesh> hmesh_host;  // filled with the leaf sequences below, read again for the single-leaf mesh table
     std::vector<bool> is_top(s->n_nodes, false);
+    bool top_is_range = false;  // the top-level tree's nodes are ONE index range [top_first, top_first + top_count)
     {
         // the top-level tree's nodes: reachable from top_root (links point forward, so the walk is finite)
         std::vector<uint32_t> stack{s->top_root};
@@ -518,7 +524,8 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
         uint32_t lo = UINT32_MAX, hi = 0, cnt = 0;
         for (uint32_t i = 0; i < s->n_nodes; i++)
             if (is_top[i]) { lo = i < lo ? i : lo; hi = i > hi ? i : hi; cnt++; }
-        A.top_fast = (cnt > 0 && hi - lo + 1 == cnt && cnt <= 64u && s->n_leaf_meshes <= 128u && s->n_meshes <= 64u) ? 1u : 0u;
+        top_is_range = cnt > 0 && hi - lo + 1 == cnt;
+        A.top_fast = (top_is_range && cnt <= 64u && s->n_leaf_meshes <= 128u && s->n_meshes <= 64u) ? 1u : 0u;
         A.top_first = cnt ? lo : 0u;
         A.top_count = cnt;
         A.top_leaf_entries = s->n_leaf_meshes;
@@ -675,7 +682,9 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
         std::vector<uint32_t> bit_of(s->n_meshes, MAX_BITS), bit_of_all(s->n_meshes, MAX_BITS);
         for (size_t b = 0; b < order.size() && b < MAX_BITS; b++) bit_of[order[b]] = (uint32_t)b;
         for (size_t b = 0; b < order_all.size() && b < MAX_BITS; b++) bit_of_all[order_all[b]] = (uint32_t)b;
-        const bool contiguous = A.top_count > 0 && A.nested_boxes;  // (top_first / top_count: the top-level nodes are one index range)
+        // the plan reads the top-level leaves off the index range [top_first, top_first + top_count): a scene whose top-level nodes are
+        // interleaved with mesh-tree nodes (forward links allow it) has no plan and stays on the faithful kernels
+        const bool contiguous = top_is_range && A.nested_boxes;
         uint32_t n_leaves = 0;
         std::vector<float4> groups;
         for (uint32_t i = A.top_first; contiguous && i < A.top_first + A.top_count; i++) {
@@ -729,6 +738,38 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
         A.plan_shadow_bits_all = (uint32_t)std::min<size_t>(order_all.size(), A.plan_ok ? 64u : MAX_BITS);
         if (upload(ctx, boxes_all.data(), boxes_all.size(), &A.plan_boxes_all)) return fail(CRT_ERR_HIP);
         if (upload(ctx, order_all.data(), order_all.size(), &A.plan_shadow_mesh_all)) return fail(CRT_ERR_HIP);
+    }
+    {
+        // The candidate filter (crt_bvh.h): built on the host, once; a scene it cannot be built for renders on the reference-order kernels
+        BvhHost bvh;
+        bvh_build(s, A.nested_boxes != 0, bvh);
+        if (bvh.ok && !A.plan_compact) { bvh.ok = false; bvh.why = "no compact leaf links"; }  // (kernel_bvh.h: bvh_leaf_walk reads them)
+        ctx->bvh_note = bvh.ok ? "" : bvh.why;
+        if (bvh.ok) {
+            char note[160];
+            snprintf(note, sizeof(note), "nodes:%zu,entries:%zu,depth:%u,walk_triangles:%u,max_margin:%.3g", bvh.nodes.size(), bvh.ids.size(),
+                     bvh.max_depth, bvh.walk_triangles, bvh.max_margin);
+            ctx->bvh_stats = note;
+        }
+        // the leaf sequences of the wave-per-ray kernels were read off index ranges [root, next root): a description whose trees are
+        // interleaved (forward links allow it) is walked by the faithful kernels, which only follow links
+        if (!bvh.trees_are_ranges) ctx->step_budget = 0;
+        A.bvh_ok = bvh.ok ? 1u : 0u;
+        A.bvh_extent = bvh.extent;
+        A.bvh_overlap_eps = bvh.overlap_eps;
+        A.n_bvh_nodes = (uint32_t)bvh.nodes.size(); A.n_bvh_entries = (uint32_t)bvh.ids.size(); A.n_triangles = s->n_triangles; A.n_nodes = s->n_nodes;
+        A.n_leaf_tris = (uint32_t)s->n_leaf_triangles; A.n_tri_leaf_entries = (uint32_t)(bvh.tri_leaf_list.size() / 8);
+        A.n_mesh_top_entries = (uint32_t)(bvh.mesh_top_list.size() / 8); A.n_meshes = s->n_meshes;
+        if (!bvh.ok) bvh = BvhHost{};
+        static_assert(sizeof(BvhNode) == 8 * sizeof(float4), "BvhNode = 8 x float4");
+        if (upload(ctx, (const float4 *)bvh.nodes.data(), bvh.nodes.size() * 8, &A.bvh_nodes)) return fail(CRT_ERR_HIP);
+        if (upload(ctx, (const float4 *)bvh.tris.data(), bvh.tris.size() / 4, &A.bvh_tris)) return fail(CRT_ERR_HIP);
+        if (upload(ctx, bvh.ids.data(), bvh.ids.size(), &A.bvh_ids)) return fail(CRT_ERR_HIP);
+        if (upload(ctx, bvh.tri_mesh.data(), bvh.tri_mesh.size(), &A.tri_mesh)) return fail(CRT_ERR_HIP);
+        if (upload(ctx, bvh.tri_leaf_first.data(), bvh.tri_leaf_first.size(), &A.tri_leaf_first)) return fail(CRT_ERR_HIP);
+        if (upload(ctx, (const float4 *)bvh.tri_leaf_list.data(), bvh.tri_leaf_list.size() / 4, &A.tri_leaf_list)) return fail(CRT_ERR_HIP);
+        if (upload(ctx, bvh.mesh_top_first.data(), bvh.mesh_top_first.size(), &A.mesh_top_first)) return fail(CRT_ERR_HIP);
+        if (upload(ctx, (const float4 *)bvh.mesh_top_list.data(), bvh.mesh_top_list.size() / 4, &A.mesh_top_list)) return fail(CRT_ERR_HIP);
     }
     A.bgx = s->background[0]; A.bgy = s->background[1]; A.bgz = s->background[2];
     A.width = s->width; A.height = s->height; A.tiles_x = ctx->tiles_x;
@@ -1023,6 +1064,7 @@ struct FramePlan {
     uint32_t lane_blocks;         // grid of the kernels that take one ray (or pixel) per lane
     bool gi, count, exec_count;   // GI mode; counting build; production kernels tallying the tests they execute
     bool heavy, lean, wide;       // wave-per-ray kernels on; plan kernels; the wide plan
+    bool bvh;                     // the filter kernels (kernel_bvh.h) walk the rays; the kernels above take what they hand over
     uint32_t level_budget;        // steps after which a deeper level's per-lane walk is evicted
     const uint32_t *prev;         // counters of a completed frame of this size and kind, or null
     bool last_resort;             // render_lanes behind the stream pass
@@ -1080,7 +1122,8 @@ static int launch_stream_levels(crt_ctx *ctx, const crt_options *o, FramePlan &P
             const uint32_t want = was < ctx->frame.heavy_level_threshold ? 64u : std::max<uint32_t>((uint32_t)ctx->num_cus, (was + was / 2u + BLOCK - 1) / BLOCK);
             level_blocks = std::min(P.lane_blocks, want);
         }
-        if (P.count) { if (P.gi) launch(stream_trace_shade<true, true>, P.lane_blocks, stream, A, g); else launch(stream_trace_shade<true>, P.lane_blocks, stream, A, g); }
+        if (P.bvh) launch(P.exec_count ? bvh_trace_shade_tally : ctx->tuning.bvh == 2 ? bvh_trace_shade_checked : bvh_trace_shade, g == 0 ? P.lane_blocks : level_blocks, stream, A, g);
+        else if (P.count) { if (P.gi) launch(stream_trace_shade<true, true>, P.lane_blocks, stream, A, g); else launch(stream_trace_shade<true>, P.lane_blocks, stream, A, g); }
         else if (P.lean && P.gi) {
             // the GI mode: the walk alone, then the level's shading -- sample directions, gi_samples child rays -- with every lane busy
             // (kernel_plan.h, SPLIT; tools/gi_time.py hw14 960x540 d3 n2 r2: 42.3 ms on the device against 44.0 with the shading inside the walk)
@@ -1107,7 +1150,12 @@ static int launch_stream_levels(crt_ctx *ctx, const crt_options *o, FramePlan &P
             CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s0[P.slot], where));
             // (beside the levels its persistent waves must leave wave slots on every CU for the level kernels)
             const uint32_t blocks0 = side_per_cu ? (uint32_t)ctx->num_cus * side_per_cu : ctx->grid_blocks;
-            if (P.count) launch(stream_trace_shadow<true>, blocks0, where, S, 0u);
+            if (P.bvh) {
+                if (P.exec_count) launch(bvh_trace_shadow<0, BVH_TALLY>, blocks0, where, S);
+                else if (ctx->tuning.bvh == 2) launch(bvh_trace_shadow<0, BVH_CHECKED>, blocks0, where, S);
+                else launch(bvh_trace_shadow<0, BVH_PLAIN>, blocks0, where, S);
+            }
+            else if (P.count) launch(stream_trace_shadow<true>, blocks0, where, S, 0u);
             else if (P.wide) launch(stream_trace_shadow_plan_wide<0>, blocks0, where, S);
             else if (P.lean) launch(stream_trace_shadow_plan<0>, blocks0, where, S);
             else launch(stream_trace_shadow<false>, blocks0, where, S, 0u);
@@ -1143,7 +1191,12 @@ static int launch_stream_tail(crt_ctx *ctx, FramePlan &P, KernelArgs &A, hipStre
         const uint32_t cap1 = std::max(level_budget, ctx->tuning.shadow_budget);
         S1.step_budget = P.heavy ? (est1 >= cap1 ? cap1 : (est1 < 64u ? 64u : (uint32_t)est1)) : 0u;
     }
-    if (P.count) launch(stream_trace_shadow<true>, P.lane_blocks, stream, S1, 1u);
+    if (P.bvh) {
+        if (P.exec_count) launch(bvh_trace_shadow<1, BVH_TALLY>, P.lane_blocks, stream, S1);
+        else if (ctx->tuning.bvh == 2) launch(bvh_trace_shadow<1, BVH_CHECKED>, P.lane_blocks, stream, S1);
+        else launch(bvh_trace_shadow<1, BVH_PLAIN>, P.lane_blocks, stream, S1);
+    }
+    else if (P.count) launch(stream_trace_shadow<true>, P.lane_blocks, stream, S1, 1u);
     else if (P.wide) launch(stream_trace_shadow_plan_wide<1>, P.lane_blocks, stream, S1);
     else if (P.lean) launch(stream_trace_shadow_plan<1>, P.lane_blocks, stream, S1);
     else launch(stream_trace_shadow<false>, P.lane_blocks, stream, S1, 1u);
@@ -1242,10 +1295,12 @@ static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, fl
     // the plan kernels (kernel_plan.h): a small top-level tree (its leaves as a plan), 32-bit offsets, compact leaf links
     const bool lean = heavy && ctx->lean_ok && (SC.plan_ok || SC.plan_wide);
     const bool wide = lean && !SC.plan_ok;  // the wide plan (kernel_plan.h): more than 64 top-level leaves or meshes
+    // the filter kernels (kernel_bvh.h) hand rays without a verified finite hit to the wave-per-ray kernels: they need those
+    const bool bvh = heavy && SC.bvh_ok && ctx->tuning.bvh && !gi;
     if (stream_mode) {
         rc = ensure_stream(ctx, vitems);
         if (rc) return rc;
-        F.heavy_level_threshold = lean ? ctx->tuning.heavy_level : 0u;
+        F.heavy_level_threshold = (lean && !bvh) ? ctx->tuning.heavy_level : 0u;  // (filter frames: the wave-per-ray kernel takes the evicted rays only)
         // level 0 owns the first n_items * 64 * n_lights slots of the shadow queue; the deeper levels append
         F.fixed0 = (uint64_t)vitems * 64u * ctx->n_lights <= F.s_shadow_cap ? 1u : 0u;
     }
@@ -1256,7 +1311,7 @@ static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, fl
     A.s = (scene_args_p)ctx->d_scene;
     A.f = (frame_args_p)(ctx->d_frame_ring + slot);
     A.counters = ctx->d_counters;
-    FramePlan P{slot, n_items, vitems, lane_blocks, gi, count, exec_count, heavy, lean, wide, 0u, nullptr, last_resort};
+    FramePlan P{slot, n_items, vitems, lane_blocks, gi, count, exec_count, heavy, lean, wide, bvh, 0u, nullptr, last_resort};
     rc = stream_mode ? launch_stream_levels(ctx, o, P, A, stream) : launch_lanes_pass(ctx, P, A, stream);
     if (rc == CRT_OK && stream_mode) rc = launch_stream_tail(ctx, P, A, stream);
     if (rc) return rc;
@@ -1614,10 +1669,13 @@ extern "C" int crt_describe_kernels(const crt_ctx *ctx, char *out, size_t size) 
         const bool heavy = ctx->step_budget && A.nested_boxes && (A.top_fast || A.plan_seq);
         const bool lean = heavy && ctx->lean_ok && (A.plan_ok || A.plan_wide);
         const bool wide = lean && !A.plan_ok;
-        d = std::string("level0=") + (!lean ? "stream_trace_shade<false>" : wide ? "stream_trace_shade_plan_wide" : "stream_trace_shade_plan");
-        d += std::string(";shadow0=") + (!lean ? "stream_trace_shadow<false>" : wide ? "stream_trace_shadow_plan_wide<0u>" : "stream_trace_shadow_plan<0u>");
-        d += std::string(";levels=") + (!heavy ? "stream_trace_shade<false>" : "heavy_trace_closest");
+        const bool bvh = heavy && A.bvh_ok && ctx->tuning.bvh;
+        if (bvh) d = "level0=bvh_trace_shade;shadow0=bvh_trace_shadow<0u, 0>;levels=bvh_trace_shade";
+        else d = std::string("level0=") + (!lean ? "stream_trace_shade<false>" : wide ? "stream_trace_shade_plan_wide" : "stream_trace_shade_plan");
+        if (!bvh) d += std::string(";shadow0=") + (!lean ? "stream_trace_shadow<false>" : wide ? "stream_trace_shadow_plan_wide<0u>" : "stream_trace_shadow_plan<0u>");
+        if (!bvh) d += std::string(";levels=") + (!heavy ? "stream_trace_shade<false>" : "heavy_trace_closest");
     }
+    d += std::string(";filter=") + (A.bvh_ok ? ctx->bvh_stats : "none (" + ctx->bvh_note + ")");
     snprintf(out, size, "%s", d.c_str());
     return CRT_OK;
 }

@@ -1,0 +1,384 @@
+// kernel_bvh.h -- the production walk kernels: candidates from the filter hierarchy (crt_bvh.h), the reference's exact triangle
+// test on them, and the verification of every accepted candidate against the reference's own trees.
+//
+// What has to hold for the frame to be the reference's, float for float (crt_bvh.h has the argument for the candidates):
+//   * bvh_child_test can only err towards "pass": the boxes hold every triangle grown by its acceptance margin; a ray is given a
+//     slack rho = 2^-16 (largest box coordinate + largest origin coordinate) -- 256 unit roundoffs of the magnitudes involved, where
+//     the analysis needs about 20 (hit point o + d t rounded per component; the plane residual of a computed t, 6 u t + 4 sqrt(3) u
+//     (2 |o| + |v|)) -- the interval ends are widened by 2^-20 of themselves (their own rounding: ~4 u), and a NaN anywhere passes;
+//   * the triangle test is kernel_plan.h's, expression for expression (Ray.cpp:9-31, Triangle.cpp:37-57);
+//   * bvh_verify: the reference tests triangle T of mesh M for this ray exactly when it reaches a top-level leaf listing M and a leaf
+//     of M's tree listing T, and it reaches a leaf exactly when the leaf's own box passes the exact slab test (nested boxes, monotone
+//     test: kernel_heavy.h).  Both lists are walked in visit order up to the first box that passes, whose entry position is the place
+//     where the reference first COLLECTS the hit: ties in distance go to the smallest (mesh entry, triangle entry) -- KDTree.cpp:75-86,
+//     156-167 take the first collected hit and replace it only by a strictly smaller distance;
+//   * shadow rays: occluded == some accepted hit with a finite distance lies within the light's distance (kernel_walk.h), whatever
+//     the order; hits beyond the light cannot count, so the walk ends at distance * (1 + 2^-16) (|d| = 1 up to 2 u);
+//   * closest-hit rays WITHOUT a verified finite hit (and walks the fixed-size stack cannot hold, and rays with non-finite
+//     coordinates) go to the reference-order kernels through the eviction list: an accepted hit with an infinite or NaN distance --
+//     invisible to any filter -- only matters for them (KDTree.cpp:75-86: a finite distance always replaces it).
+#pragma once
+
+#include "crt_bvh.h"
+#include "kernel_common.h"
+#include "kernel_stream.h"
+#include "kernel_walk.h"
+
+constexpr uint32_t BVH_STACK = 32;   // entries per lane (LDS, one column per thread); a deeper walk is evicted
+constexpr float BVH_WIDEN = 0x1p-20f;
+constexpr uint32_t BVH_REFILL = 40;  // a wave hands out new rays when at most this many of its lanes still walk
+constexpr int BVH_STEPS = 4;         // walk steps between two looks at the lanes' states
+
+// Builds of the kernels: plain; tallying the tests they execute (crt_options::collect_counters == 2); bounds-checked (crt_tuning::bvh
+// == 2: every index is compared with its array's size first; a violation is recorded in the frame's counter block -- word
+// SC_BVH_DIAG + 2 code, the index beside it -- and index 0 is read instead: a development build that cannot fault)
+enum : int { BVH_PLAIN = 0, BVH_TALLY = 1, BVH_CHECKED = 2 };
+constexpr int SC_BVH_DIAG = SC_HEAVY_DIAG + 16;
+template <int MODE>
+__device__ __forceinline__ uint32_t bvh_at(const KernelArgs &A, const uint32_t i, const uint32_t n, const uint32_t code) {
+    if (MODE == BVH_CHECKED && i >= n) { A.f->s_counts[SC_BVH_DIAG + 2 * code] = 1u; A.f->s_counts[SC_BVH_DIAG + 2 * code + 1] = i; return 0u; }
+    return i;
+}
+
+struct BvhRay { float ix, iy, iz, cpx, cpy, cpz, cmx, cmy, cmz; };
+
+// false: the ray has non-finite coordinates (the filter would pass everything: let the reference-order kernels take it)
+__device__ __forceinline__ bool bvh_ray_setup(const KernelArgs &A, const Ray &R, BvhRay &B) {
+    const float rho = (A.s->bvh_extent + fmaxf(fmaxf(fabsf(R.ox), fabsf(R.oy)), fabsf(R.oz))) * 0x1p-16f;
+    B.ix = R.ix; B.iy = R.iy; B.iz = R.iz;
+    B.cpx = -((R.ox + rho) * R.ix); B.cmx = -((R.ox - rho) * R.ix);
+    B.cpy = -((R.oy + rho) * R.iy); B.cmy = -((R.oy - rho) * R.iy);
+    B.cpz = -((R.oz + rho) * R.iz); B.cmz = -((R.oz - rho) * R.iz);
+    const float s = (R.ox + R.oy + R.oz) + (R.dx + R.dy + R.dz);
+    return fabsf(s) < INFINITY && fabsf(R.ox) < INFINITY && fabsf(R.oy) < INFINITY && fabsf(R.oz) < INFINITY;  // (NaN: false)
+}
+
+// Does the ray come within rho of the box somewhere in [0, tmax]?  May say yes when it does not, never no when it does.
+__device__ __forceinline__ bool bvh_child_test(const BvhRay &B, const float lox, const float loy, const float loz, const float hix,
+                                               const float hiy, const float hiz, const float tmax, float &tnear) {
+    const float ax = __builtin_fmaf(lox, B.ix, B.cpx), bx = __builtin_fmaf(hix, B.ix, B.cmx);
+    const float ay = __builtin_fmaf(loy, B.iy, B.cpy), by = __builtin_fmaf(hiy, B.iy, B.cmy);
+    const float az = __builtin_fmaf(loz, B.iz, B.cpz), bz = __builtin_fmaf(hiz, B.iz, B.cmz);
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    tnear = tn;
+    return !(__builtin_fmaf(-fabsf(tn), BVH_WIDEN, tn) > __builtin_fmaf(fabsf(tf), BVH_WIDEN, tf));
+}
+
+// The leaves of `mesh`'s tree that list triangle `tri` (vertices a, b, c), for a triangle listed by too many of them for a list
+// (BVH_TRI_WALK): the reference's own walk of the tree (KDTree.cpp:53-74: the threaded nodes, the exact slab test), pruned to the
+// nodes whose box overlaps the triangle's -- every leaf that lists it does (checked by bvh_build), and so does every ancestor of
+// such a leaf (nested boxes) -- and stopped at the first leaf that passes and lists it: the first in visit order.  A leaf's entries
+// ascend (checked by bvh_build) and its compact link says how many there are: the triangle is looked up by bisection.
+template <int MODE>
+__device__ __forceinline__ bool bvh_leaf_walk(const KernelArgs &A, const Ray &R, const uint32_t tri, const uint32_t mesh, const float4 &a,
+                                              const float4 &b, const float4 &c, uint32_t &k3, uint32_t &nbox) {
+    const float eps = A.s->bvh_overlap_eps;
+    const float tlx = fminf(fminf(a.x, b.x), c.x) - eps, thx = fmaxf(fmaxf(a.x, b.x), c.x) + eps;
+    const float tly = fminf(fminf(a.y, b.y), c.y) - eps, thy = fmaxf(fmaxf(a.y, b.y), c.y) + eps;
+    const float tlz = fminf(fminf(a.z, b.z), c.z) - eps, thz = fmaxf(fmaxf(a.z, b.z), c.z) + eps;
+    uint32_t wn = A.s->meshes[bvh_at<MODE>(A, mesh, A.s->n_meshes, 0)].root;
+    uint32_t trips = 0;
+    while (wn != END) {   // (links point forward: the walk is finite)
+        if (MODE == BVH_CHECKED && ++trips > (1u << 22)) { bvh_at<MODE>(A, trips, 0u, 14); break; }
+        wn = bvh_at<MODE>(A, wn, A.s->n_nodes, 1);
+        const float4 q0 = A.s->pnodes[2 * (size_t)wn], q1 = A.s->pnodes[2 * (size_t)wn + 1];
+        const uint32_t miss = __float_as_uint(q0.w), link = __float_as_uint(q1.w);
+        if (MODE == BVH_TALLY) nbox++;
+        const bool overlap = tlx <= q1.x && thx >= q0.x && tly <= q1.y && thy >= q0.y && tlz <= q1.z && thz >= q0.z;
+        const bool hit = overlap && slab_test(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z);
+        if (hit && is_leaf_link(link)) {
+            uint32_t lo = link & 0x00FFFFFFu, hi = lo + ((link >> 24) & 0x7Fu);  // entries [lo, hi], ascending
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if ((A.s->leaf_tris[bvh_at<MODE>(A, mid, A.s->n_leaf_tris, 2)] & ~LAST) < tri) lo = mid + 1u; else hi = mid;
+            }
+            if ((A.s->leaf_tris[bvh_at<MODE>(A, lo, A.s->n_leaf_tris, 3)] & ~LAST) == tri) { k3 = lo; return true; }
+            wn = miss;
+        } else wn = (hit && link != END) ? link : miss;
+    }
+    return false;
+}
+
+// The first box of the list [j, e) -- 2 x float4 per entry: {lo, entry position} {hi, -} -- the ray passes (exact slab test), two
+// entries per round trip; NONE: it passes none of them.
+template <int MODE>
+__device__ __forceinline__ uint32_t bvh_first_passing(const KernelArgs &A, const Ray &R, const float4 *list, const uint32_t size, uint32_t j,
+                                                   uint32_t e, uint32_t &nbox) {
+    if (MODE == BVH_CHECKED && (e > size || j > e)) { bvh_at<MODE>(A, e, size, 4); bvh_at<MODE>(A, j, e + 1u, 5); e = j; }
+    for (; j < e; j += 2u) {
+        const uint32_t j1 = j + 1u < e ? j + 1u : j;
+        const float4 p0 = list[2 * (size_t)j], p1 = list[2 * (size_t)j + 1], q0 = list[2 * (size_t)j1], q1 = list[2 * (size_t)j1 + 1];
+        if (MODE == BVH_TALLY) nbox += j1 != j ? 2u : 1u;
+        if (slab_test(R, p0.x, p0.y, p0.z, p1.x, p1.y, p1.z)) return __float_as_uint(p0.w);
+        if (slab_test(R, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z)) return __float_as_uint(q0.w);   // (j1 == j: the same verdict again)
+    }
+    return NONE;
+}
+
+// Would the reference have tested triangle `tri` (vertices a, b, c) for this ray?  k2 / k3: where it first collects the mesh's / the
+// triangle's hit.  (cache_mesh, cache_k2): the last mesh looked up for this ray and its answer (a ray's candidates mostly share a mesh).
+template <int MODE>
+__device__ __forceinline__ bool bvh_verify(const KernelArgs &A, const Ray &R, const uint32_t tri, const float4 &a, const float4 &b,
+                                           const float4 &c, uint32_t &mesh, uint32_t &cache_mesh, uint32_t &cache_k2, uint32_t &k2,
+                                           uint32_t &k3, uint32_t &nbox) {
+    const uint32_t tm = A.s->tri_mesh[bvh_at<MODE>(A, tri, A.s->n_triangles, 6)];
+    mesh = bvh_at<MODE>(A, tm & ~BVH_TRI_WALK, A.s->n_meshes, 7);
+    if (mesh != cache_mesh) {
+        cache_mesh = mesh;
+        cache_k2 = bvh_first_passing<MODE>(A, R, A.s->mesh_top_list, A.s->n_mesh_top_entries, A.s->mesh_top_first[mesh], A.s->mesh_top_first[mesh + 1], nbox);
+    }
+    k2 = cache_k2;
+    if (k2 == NONE) return false;
+    if (tm & BVH_TRI_WALK) return bvh_leaf_walk<MODE>(A, R, tri, mesh, a, b, c, k3, nbox);
+    k3 = bvh_first_passing<MODE>(A, R, A.s->tri_leaf_list, A.s->n_tri_leaf_entries, A.s->tri_leaf_first[tri], A.s->tri_leaf_first[tri + 1], nbox);
+    return k3 != NONE;
+}
+
+// the reference's triangle test (kernel_plan.h's expressions; the plane offset is recomputed: -(v0 . n), checked against the stored
+// one bit for bit when the filter is built)
+__device__ __forceinline__ bool bvh_triangle(const Ray &R, const bool primary, const float4 &a, const float4 &b, const float4 &c, float &t,
+                                             float &px, float &py, float &pz) {
+    const float nx = a.w, ny = b.w, nz = c.w;
+    const float nd = dot3(R.dx, R.dy, R.dz, nx, ny, nz);
+    const float plane = -dot3(a.x, a.y, a.z, nx, ny, nz);  // distanceToPlane, Ray.cpp:17
+    t = -(dot3(nx, ny, nz, R.ox, R.oy, R.oz) + plane) / nd;
+    px = R.ox + R.dx * t; py = R.oy + R.dy * t; pz = R.oz + R.dz * t;
+    float s0, s1, s2;
+    {
+        const float ex = b.x - a.x, ey = b.y - a.y, ez = b.z - a.z, cx = px - a.x, cy = py - a.y, cz = pz - a.z;
+        s0 = dot3(nx, ny, nz, ey * cz - ez * cy, ez * cx - ex * cz, ex * cy - ey * cx);
+    }
+    {
+        const float ex = c.x - b.x, ey = c.y - b.y, ez = c.z - b.z, cx = px - b.x, cy = py - b.y, cz = pz - b.z;
+        s1 = dot3(nx, ny, nz, ey * cz - ez * cy, ez * cx - ex * cz, ex * cy - ey * cx);
+    }
+    {
+        const float ex = a.x - c.x, ey = a.y - c.y, ez = a.z - c.z, cx = px - c.x, cy = py - c.y, cz = pz - c.z;
+        s2 = dot3(nx, ny, nz, ey * cz - ez * cy, ez * cx - ex * cz, ex * cy - ey * cx);
+    }
+    return !(primary && nd >= 0) && !(t < 0) && !(s0 < -FLT_EPSILON) && !(s1 < -FLT_EPSILON) && !(s2 < -FLT_EPSILON);
+}
+
+// What a lane carries through a walk.  `cur`: the node or (rest of a) leaf to look at next, BVH_EMPTY: take one off the stack.
+struct BvhWalk {
+    BvhRay B;
+    uint32_t cur, sp;
+    float best;                 // closest hit: distance of the best verified hit so far; shadow: the end of the segment
+    uint32_t bk2, bk3, btri, bmesh, cache_mesh, cache_k2;
+    bool have, give_up;
+};
+__device__ __forceinline__ void bvh_walk_begin(BvhWalk &W, const float tmax) {
+    W.cur = 0; W.sp = 0;  // the root is node 0
+    W.best = tmax;
+    W.bk2 = W.bk3 = NONE; W.btri = 0; W.bmesh = 0; W.cache_mesh = NONE; W.cache_k2 = NONE;
+    W.have = false; W.give_up = false;
+}
+
+// One step of a lane's walk: an inner node (its four children tested, the nearest taken, the others pushed) or two triangles of a
+// leaf.  false: the walk is over -- nothing left, the stack too small (give_up), or (SHADOW) an occluder found (have).
+template <bool SHADOW, int MODE>
+__device__ __forceinline__ bool bvh_step(const KernelArgs &A, const Ray &R, const bool primary, const float light_dist, const bool every_mesh,
+                                         BvhWalk &W, uint32_t *stack, uint32_t &nbox, uint32_t &ntri) {
+    if (W.cur == BVH_EMPTY) {
+        if (W.sp == 0) return false;
+        W.sp--;
+        W.cur = stack[bvh_at<MODE>(A, W.sp, BVH_STACK, 8) * BLOCK];
+    }
+    if (!(W.cur & BVH_LEAF)) {
+        const float4 *N = A.s->bvh_nodes + 8 * (size_t)bvh_at<MODE>(A, W.cur, A.s->n_bvh_nodes, 9);
+        const float4 lx = N[0], ly = N[1], lz = N[2], hx = N[3], hy = N[4], hz = N[5];
+        const float4 ch = N[6];
+        if (MODE == BVH_TALLY) nbox += 4;
+        uint32_t c0 = __float_as_uint(ch.x), c1 = __float_as_uint(ch.y), c2 = __float_as_uint(ch.z), c3 = __float_as_uint(ch.w);
+        float t0, t1, t2, t3;
+        const bool h0 = bvh_child_test(W.B, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, W.best, t0) && c0 != BVH_EMPTY;
+        const bool h1 = bvh_child_test(W.B, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, W.best, t1) && c1 != BVH_EMPTY;
+        const bool h2 = bvh_child_test(W.B, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, W.best, t2) && c2 != BVH_EMPTY;
+        const bool h3 = bvh_child_test(W.B, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, W.best, t3) && c3 != BVH_EMPTY;
+        // nearest first: sort the four (entry distance, child) pairs, misses last (a NaN distance sorts anywhere: order is only speed)
+        t0 = h0 ? t0 : INFINITY; t1 = h1 ? t1 : INFINITY; t2 = h2 ? t2 : INFINITY; t3 = h3 ? t3 : INFINITY;
+        c0 = h0 ? c0 : BVH_EMPTY; c1 = h1 ? c1 : BVH_EMPTY; c2 = h2 ? c2 : BVH_EMPTY; c3 = h3 ? c3 : BVH_EMPTY;
+#define BVH_CSWAP(ta, ca, tb, cb) { const bool sw = tb < ta; const float tt = sw ? tb : ta; tb = sw ? ta : tb; ta = tt; const uint32_t cc = sw ? cb : ca; cb = sw ? ca : cb; ca = cc; }
+        BVH_CSWAP(t0, c0, t1, c1) BVH_CSWAP(t2, c2, t3, c3) BVH_CSWAP(t0, c0, t2, c2) BVH_CSWAP(t1, c1, t3, c3) BVH_CSWAP(t1, c1, t2, c2)
+#undef BVH_CSWAP
+        const uint32_t n_push = (c1 != BVH_EMPTY ? 1u : 0u) + (c2 != BVH_EMPTY ? 1u : 0u) + (c3 != BVH_EMPTY ? 1u : 0u);
+        if (W.sp + n_push > BVH_STACK) { W.give_up = true; return false; }
+        if (c3 != BVH_EMPTY) stack[(W.sp++) * BLOCK] = c3;
+        if (c2 != BVH_EMPTY) stack[(W.sp++) * BLOCK] = c2;
+        if (c1 != BVH_EMPTY) stack[(W.sp++) * BLOCK] = c1;
+        W.cur = c0;  // (BVH_EMPTY when the nearest slot holds a miss -- nothing passed, or a NaN distance out of order: the next step pops)
+    } else {
+        // two triangles of the leaf per step, both fetched before either is tested; what is left of the leaf stays in `cur`
+        const uint32_t left = (W.cur >> 24) & 0x7Fu;  // `left` more after the first
+        const uint32_t first = bvh_at<MODE>(A, W.cur & 0x00FFFFFFu, A.s->n_bvh_entries - (left ? 1u : 0u), 10);
+        const uint32_t second = first + (left ? 1u : 0u);
+        const float4 *T0 = A.s->bvh_tris + 3 * (size_t)first, *T1 = A.s->bvh_tris + 3 * (size_t)second;
+        const float4 a0 = T0[0], b0 = T0[1], c0 = T0[2], a1 = T1[0], b1 = T1[1], c1 = T1[2];
+        const uint32_t id0 = A.s->bvh_ids[first], id1 = A.s->bvh_ids[second];
+        W.cur = left >= 2u ? (BVH_LEAF | ((left - 2u) << 24) | (first + 2u)) : BVH_EMPTY;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            if (k == 1 && !left) break;
+            const float4 &a = k ? a1 : a0, &b = k ? b1 : b0, &c = k ? c1 : c0;
+            const uint32_t id = k ? id1 : id0;
+            if (SHADOW && (id & BVH_ID_REFRACTIVE) && !every_mesh) continue;  // AccelerationStructure.cpp:66-71 (not in the GI mode)
+            float t, px, py, pz;
+            if (MODE == BVH_TALLY) ntri++;
+            const bool ok = bvh_triangle(R, primary, a, b, c, t, px, py, pz);
+            if (!(ok && t < INFINITY)) continue;
+            uint32_t mesh, k2, k3 = NONE;
+            if (SHADOW) {
+                if (shadow_hit_occludes(R, px, py, pz, light_dist) &&
+                    bvh_verify<MODE>(A, R, id & ~BVH_ID_REFRACTIVE, a, b, c, mesh, W.cache_mesh, W.cache_k2, k2, k3, nbox)) { W.have = true; return false; }
+            } else if (t <= W.best) {
+                const uint32_t tri = id & ~BVH_ID_REFRACTIVE;
+                if (bvh_verify<MODE>(A, R, tri, a, b, c, mesh, W.cache_mesh, W.cache_k2, k2, k3, nbox) &&
+                    (t < W.best || k2 < W.bk2 || (k2 == W.bk2 && k3 < W.bk3))) {
+                    W.best = t; W.bk2 = k2; W.bk3 = k3; W.btri = tri; W.bmesh = mesh; W.have = true;
+                }
+            }
+        }
+    }
+    return true;
+}
+
+enum : int { BVH_FETCH = 0, BVH_WALK = 1, BVH_OUT = 2, BVH_FINISHED = 3 };  // a lane: wants a ray, walks, nothing left to fetch, its walk has ended
+
+// Every ray of recursion level `gen`, persistent waves: a lane walks its ray through the filter; when enough lanes of the wave have
+// finished, they shade their hits together -- shootRay's material dispatch (kernel_stream.h: shade_and_emit); rays without a verified
+// finite hit are queued for heavy_trace_closest(gen) + stream_shade_evicted(gen) -- and take the next rays of the level (consecutive
+// ones: at level 0 neighbouring pixels of a tile).
+template <int MODE>
+__device__ __forceinline__ void bvh_shade_level(const KernelArgs &A, const uint32_t gen, uint32_t *stack_lds) {
+    if (A.wave_prio) __builtin_amdgcn_s_setprio(3);
+    const uint32_t lane = threadIdx.x & 63u;
+    if (A.f->s_counts[SC_OVERFLOW]) return;
+    const uint32_t count = stream_level_count(A, gen);
+    const uint32_t node_base = stream_level_base(A, gen);
+    const uint32_t child_base = node_base + count;
+    const float4 *in_q = A.f->s_rayq[gen & 1u];
+    uint32_t *stack = stack_lds + threadIdx.x;
+    const bool primary = gen == 0;
+    uint32_t nbox = 0, ntri = 0;
+    Ray R;
+    R.ox = R.oy = R.oz = R.dx = R.dy = R.dz = R.ix = R.iy = R.iz = 0; R.parmask = 0;
+    BvhWalk W;
+    bvh_walk_begin(W, INFINITY);
+    int state = BVH_FETCH;
+    uint32_t r = 0, spins = 0;
+    for (;;) {
+        if (MODE == BVH_CHECKED && ++spins > (1u << 22)) { bvh_at<MODE>(A, spins, 0u, 15); break; }   // (a loop that does not end: say so and leave)
+        if (__ballot(state == BVH_FETCH || state == BVH_FINISHED) && (uint32_t)__popcll(__ballot(state == BVH_WALK)) <= BVH_REFILL) {
+            if (state == BVH_FINISHED) {
+                if (W.have && !W.give_up) shade_and_emit<false, false>(A, gen, r, node_base, child_base, R, true, W.best, W.btri, W.bmesh, nullptr, lane);
+                else if (!evict_ray(A.f->s_heavy, A.f->s_heavy_cap, A.f->s_counts + SC_HEAVY + gen, r, lane)) A.f->s_counts[SC_OVERFLOW] = 1;
+                state = BVH_FETCH;
+            }
+            while (state == BVH_FETCH) {
+                r = wave_fetch(A.f->s_counts + SC_FETCH + gen, lane);
+                if (r >= count) { state = BVH_OUT; break; }
+                if (gen == 0) {
+                    const Level0Ray P = level0_decode<false>(A, r);
+                    if (!P.covered) {
+                        reinterpret_cast<uint32_t *>(A.f->s_nodes + 2 * (size_t)r)[3] = TN_SKIP;
+                        level0_release_shadow_slots(A, r);
+                        continue;
+                    }
+                    level0_ray<false>(A, P, R);
+                } else {
+                    const float4 q0 = in_q[2 * (size_t)r], q1 = in_q[2 * (size_t)r + 1];
+                    R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
+                    R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;
+                    normalize3(R.dx, R.dy, R.dz);  // shootRay entry (RayTracer.cpp:420)
+                    ray_prepare(R);
+                }
+                bvh_walk_begin(W, INFINITY);
+                if (!bvh_ray_setup(A, R, W.B)) {
+                    if (!evict_ray(A.f->s_heavy, A.f->s_heavy_cap, A.f->s_counts + SC_HEAVY + gen, r, lane)) A.f->s_counts[SC_OVERFLOW] = 1;
+                    continue;
+                }
+                state = BVH_WALK;
+            }
+        }
+        if (!__ballot(state != BVH_OUT)) break;
+        if (state == BVH_WALK) {
+            for (int it = 0; it < BVH_STEPS; ++it)
+                if (!bvh_step<false, MODE>(A, R, primary, 0.0f, false, W, stack, nbox, ntri)) { state = BVH_FINISHED; break; }
+        }
+    }
+    exec_counters_flush(A, nbox, ntri, lane);
+}
+__global__ __launch_bounds__(BLOCK) void bvh_trace_shade(const KernelArgs A, const uint32_t gen) {
+    __shared__ uint32_t stack_lds[BVH_STACK * BLOCK];
+    bvh_shade_level<BVH_PLAIN>(A, gen, stack_lds);
+}
+__global__ __launch_bounds__(BLOCK) void bvh_trace_shade_tally(const KernelArgs A, const uint32_t gen) {
+    __shared__ uint32_t stack_lds[BVH_STACK * BLOCK];
+    bvh_shade_level<BVH_TALLY>(A, gen, stack_lds);
+}
+__global__ __launch_bounds__(BLOCK) void bvh_trace_shade_checked(const KernelArgs A, const uint32_t gen) {
+    __shared__ uint32_t stack_lds[BVH_STACK * BLOCK];
+    bvh_shade_level<BVH_CHECKED>(A, gen, stack_lds);
+}
+
+// The shadow rays [first, first + total) of the queue (pass 0: level 0's fixed slots; pass 1: the deeper levels'); `cursor` hands them
+// out, consecutive slots to the lanes that refill together: one tile's rays towards one light (kernel_stream.h: level0_shadow_place).
+template <int MODE>
+__device__ __forceinline__ void bvh_shadow_rays(const KernelArgs &A, const uint32_t first, const uint32_t total, uint32_t *cursor, uint32_t *stack_lds) {
+    const uint32_t lane = threadIdx.x & 63u;
+    if (A.f->s_counts[SC_OVERFLOW]) return;
+    uint32_t *stack = stack_lds + threadIdx.x;
+    const bool every_mesh = A.f->use_gi != 0;
+    uint32_t nbox = 0, ntri = 0;
+    Ray R;
+    R.ox = R.oy = R.oz = R.dx = R.dy = R.dz = R.ix = R.iy = R.iz = 0; R.parmask = 0;
+    BvhWalk W;
+    bvh_walk_begin(W, INFINITY);
+    float light_dist = 0;
+    int state = BVH_FETCH;
+    uint32_t r = 0, spins = 0;
+    for (;;) {
+        if (MODE == BVH_CHECKED && ++spins > (1u << 22)) { bvh_at<MODE>(A, spins, 0u, 15); break; }   // (a loop that does not end: say so and leave)
+        if (__ballot(state == BVH_FETCH || state == BVH_FINISHED) && (uint32_t)__popcll(__ballot(state == BVH_WALK)) <= BVH_REFILL) {
+            if (state == BVH_FINISHED) {
+                if (W.give_up) { if (!evict_ray(A.f->s_sheavy, A.f->s_heavy_cap, A.f->s_counts + SC_SHEAVY, r, lane)) A.f->s_counts[SC_OVERFLOW] = 1; }
+                else A.f->s_occluded[r] = W.have ? 1 : 0;
+                state = BVH_FETCH;
+            }
+            while (state == BVH_FETCH) {
+                r = wave_fetch(cursor, lane);
+                if (r >= total) { state = BVH_OUT; break; }
+                r += first;
+                const float4 q0 = A.f->s_shadowq[2 * (size_t)r], q1 = A.f->s_shadowq[2 * (size_t)r + 1];
+                if (__float_as_uint(q0.w) == SHADOW_SLOT_UNUSED) continue;  // a level-0 pixel without a diffuse hit
+                // a light behind the surface contributes +-0 times the albedo: no walk (kernel_plan.h has the argument)
+                if (q1.w == 0.0f) { A.f->s_occluded[r] = 0; continue; }
+                R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
+                R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;  // already normalised once; shadow rays skip shootRay (RayTracer.cpp:313-317)
+                ray_prepare(R);
+                light_dist = q0.w;
+                // an occluding hit has length(o + d t - o) <= light_dist with |d| = 1 up to two unit roundoffs: t <= light_dist (1 + 2^-16) (NaN: no bound)
+                bvh_walk_begin(W, light_dist * (1.0f + 0x1p-16f));
+                if (!bvh_ray_setup(A, R, W.B)) {
+                    if (!evict_ray(A.f->s_sheavy, A.f->s_heavy_cap, A.f->s_counts + SC_SHEAVY, r, lane)) A.f->s_counts[SC_OVERFLOW] = 1;
+                    continue;
+                }
+                state = BVH_WALK;
+            }
+        }
+        if (!__ballot(state != BVH_OUT)) break;
+        if (state == BVH_WALK) {
+            for (int it = 0; it < BVH_STEPS; ++it)
+                if (!bvh_step<true, MODE>(A, R, false, light_dist, every_mesh, W, stack, nbox, ntri)) { state = BVH_FINISHED; break; }
+        }
+    }
+    exec_counters_flush(A, nbox, ntri, lane);
+}
+template <uint32_t pass, int MODE>  // (the passes are kernels of their own in a profile)
+__global__ __launch_bounds__(BLOCK) void bvh_trace_shadow(const KernelArgs A) {
+    __shared__ uint32_t stack_lds[BVH_STACK * BLOCK];
+    const uint32_t split = A.f->s_counts[SC_SHADOW_SPLIT];
+    bvh_shadow_rays<MODE>(A, pass == 0 ? 0u : split, pass == 0 ? split : A.f->s_counts[SC_SHADOW] - split,
+                          A.f->s_counts + (pass == 0 ? SC_SHADOW_FETCH : SC_SHADOW_FETCH2), stack_lds);
+}

@@ -100,6 +100,21 @@ struct SceneArgs {
     const float4 *ptris;
     const float4 *pnodes;
     uint32_t plan_list_words;     // LDS words per lane of a closest-hit ray's mesh list: ceil(meshes / 4), at most 32 (wide plan: a longer list sends the ray to heavy_trace_closest)
+    // The candidate filter (crt_bvh.h, kernel_bvh.h): a 4-wide hierarchy over the triangles grown by their acceptance margins, and the
+    // inverse maps its hits are verified with against the reference's trees
+    uint32_t bvh_ok;              // the filter exists (crt_create: every triangle's margin is bounded, the reference's boxes are nested)
+    float bvh_extent;             // largest absolute coordinate of any of its boxes
+    float bvh_overlap_eps;        // slack of the box-overlap predicate of bvh_leaf_walk (kernel_bvh.h)
+    const float4 *bvh_nodes;      // 8 x float4 per node: child boxes lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4], children[4], pad
+    const float4 *bvh_tris;       // 3 x float4 per filter entry {v0,nx} {v1,ny} {v2,nz}, in the filter's leaf order
+    const uint32_t *bvh_ids;      // per filter entry: triangle | BVH_ID_REFRACTIVE
+    const uint32_t *tri_mesh;     // per triangle: its mesh | BVH_TRI_WALK (listed by too many leaves for a list: verified by the pruned tree walk)
+    const uint32_t *tri_leaf_first;  // CSR per triangle: the reference leaves listing it, in visit order,
+    const float4 *tri_leaf_list;     //   2 x float4 each: {box lo, entry position in leaf_triangles} {box hi, -}
+    const uint32_t *mesh_top_first;  // CSR per mesh: the top-level leaves listing it, in visit order,
+    const float4 *mesh_top_list;     //   the same form with the entry position in leaf_meshes
+    // sizes of the arrays above, for the bounds-checked build of the filter kernels (crt_tuning::bvh = 2)
+    uint32_t n_bvh_nodes, n_bvh_entries, n_triangles, n_nodes, n_leaf_tris, n_tri_leaf_entries, n_mesh_top_entries, n_meshes;
 };
 
 struct FrameArgs {

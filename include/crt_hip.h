@@ -191,6 +191,8 @@ typedef struct crt_tuning {
     uint32_t side_blocks;     /* 3: workgroups per CU of the bulk shadow pass on the side stream; 0 = no side stream */
     uint32_t node_cap, ray_cap, shadow_cap; /* 0 = the queues follow the frames; explicit values make
                                              * queue overflow -- and the fallback -- reachable in tests */
+    uint32_t bvh;             /* 1: rays are walked through the candidate filter (csrc/crt_bvh.h, csrc/kernel_bvh.h) where the scene has one;
+                               * 0: by the reference-order kernels alone */
 } crt_tuning;
 void crt_tuning_defaults(crt_tuning *tuning);
 

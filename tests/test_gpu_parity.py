@@ -493,3 +493,67 @@ def test_async_frames_equal_synchronous_ones(pkg, scenes, oracle):
         want, _ = o.render(depth)
         assert_same_floats(bufs[j % 2][0], want, "async frame %d" % j)
     assert ring[0].stats().pixels == H * W and ring[0].stats().kernel_ms > 0
+
+
+def test_top_level_nodes_interleaved_with_a_mesh_tree(pkg, scenes, oracle):
+    """crt_scene_desc only asks for forward links: the top-level tree's nodes need not be one index range.  With a mesh tree spliced
+    into the middle of them there is no plan table (it is read off that range) -- the frame must come from the faithful kernels
+    and still be the oracle's, and the counters the oracle's."""
+    import ctypes as C
+    scene, depth, _ = small_case(scenes, "hw11")
+    hs = pkg.Scene(json_text=scenes.to_json(scene))
+    d = hs.desc
+    n = d.n_nodes
+    nodes = [d.nodes[i] for i in range(n)]
+    roots = sorted([d.meshes[m].root for m in range(d.n_meshes)] + [d.top_root, n])
+    top_lo, top_hi = d.top_root, roots[roots.index(d.top_root) + 1]          # the top-level tree's range
+    assert top_hi - top_lo >= 3
+    m0 = min(range(d.n_meshes), key=lambda m: d.meshes[m].root if d.meshes[m].root >= top_hi else 1 << 40)
+    m_lo = d.meshes[m0].root
+    m_hi = roots[roots.index(m_lo) + 1]
+    assert m_lo >= top_hi                                                     # (the host stores the top-level tree first)
+    cut = top_lo + 2
+    order = list(range(0, cut)) + list(range(m_lo, m_hi)) + list(range(cut, m_lo)) + list(range(m_hi, n))
+    assert sorted(order) == list(range(n))
+    new_of = {old: new for new, old in enumerate(order)}
+    END, LEAF = 0xFFFFFFFF, 0x80000000
+
+    def remap(link, is_link):
+        if link == END or (is_link and (link & LEAF)):
+            return link
+        return new_of[link]
+
+    arr = (pkg.Node * n)()
+    for new, old in enumerate(order):
+        src = nodes[old]
+        arr[new].lo[:] = src.lo[:]
+        arr[new].hi[:] = src.hi[:]
+        arr[new].miss = remap(src.miss, False)
+        arr[new].link = remap(src.link, True)
+    meshes = (pkg.MeshRec * d.n_meshes)()
+    for m in range(d.n_meshes):
+        meshes[m].root, meshes[m].material, meshes[m].flags, meshes[m].pad = new_of[d.meshes[m].root], d.meshes[m].material, d.meshes[m].flags, 0
+    d2 = pkg.SceneDesc()
+    C.memmove(C.byref(d2), C.byref(d), C.sizeof(d2))
+    d2.nodes = C.cast(arr, C.POINTER(pkg.Node))
+    d2.meshes = C.cast(meshes, C.POINTER(pkg.MeshRec))
+    d2.top_root = new_of[d.top_root]
+    L = pkg.lib()
+    ctx = C.c_void_p()
+    rc = L.crt_create(C.byref(d2), 0, C.byref(ctx))
+    assert rc == 0, L.crt_last_error(None)
+    try:
+        pos, mat = hs.camera()
+        assert L.crt_set_camera(ctx, pos.ctypes.data_as(C.c_void_p), mat.ctypes.data_as(C.c_void_p)) == 0
+        want, counters = oracle.OracleScene(scenes.to_blob(scene)).render(depth)
+        rect = pkg.Rect(0, 0, hs.width, hs.height)
+        for counting in (False, True):
+            got = np.zeros((hs.height, hs.width, 3), dtype=np.float32)
+            o = pkg.make_options(depth, counters=counting)
+            assert L.crt_render(ctx, C.byref(o), C.byref(rect), 1, got.ctypes.data_as(C.c_void_p)) == 0, L.crt_last_error(ctx)
+            assert_same_floats(got, want, "interleaved layout, counting=%r" % counting)
+        st = pkg.Stats()
+        assert L.crt_get_stats(ctx, C.byref(st)) == 0
+        assert st.counters() == counters
+    finally:
+        L.crt_destroy(ctx)

@@ -16,9 +16,13 @@ def _have(oracle, textured):
     ("hw11", 128, 72, 0.2, 5),
     ("hw14", 112, 63, 0.03, 8),
     ("hw12", 96, 54, 0.06, 3),
+    # the benchmark scenes at FULL detail (the deep-tree paths: depth-25 cut-off, 8.6x leaf duplication, KDTree.cpp:10-46)
+    ("hw14", 160, 90, 1.0, 8),     # 207,954 triangles
+    ("hw12", 160, 90, 1.0, 8),     # 60,156 triangles, 1024x1024 bitmap
+    ("hw11", 160, 90, 1.0, 8),
 ])
 def test_restatement_is_bit_exact(oracle, scenes, name, w, h, detail, depth):
-    kw = {"bitmap_size": 32} if name == "hw12" else {}
+    kw = {"bitmap_size": 32} if name == "hw12" and detail < 1.0 else {}
     scene = scenes.make(name, width=w, height=h, detail=detail, **kw)
     if not _have(oracle, bool(scene.get("textures"))):
         pytest.skip("oracle/_ref not built here")
