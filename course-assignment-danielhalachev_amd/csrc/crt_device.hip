@@ -1048,9 +1048,13 @@ static uint32_t frame_config_of(const crt_options *o) {
     return (o->use_gi ? 0x80000000u : 0u) | ((o->use_gi ? o->gi_sample_size & 0x7Fu : 0u) << 24) | (o->max_depth & 0xFFFFFFu);
 }
 
+static int g_debug_sync = 0;   // development (crt_tuning::bvh == 3): announce every launch of launch() on stderr and wait for it
 template <typename K, typename... Args>
 static void launch(K kernel, uint32_t blocks, hipStream_t stream, Args... args) {
+    static int serial = 0;
+    if (g_debug_sync) { fprintf(stderr, "[launch %d] kernel %p blocks %u ...", serial, (void *)kernel, blocks); fflush(stderr); }
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK), 0, stream, args...);
+    if (g_debug_sync) { hipError_t e = hipDeviceSynchronize(); fprintf(stderr, " done (%s)\n", hipGetErrorString(e)); fflush(stderr); serial++; }
 }
 template <typename K, typename... Args>
 static void launch_lds(K kernel, uint32_t blocks, uint32_t lds_bytes, hipStream_t stream, Args... args) {
@@ -1134,7 +1138,7 @@ static int launch_stream_levels(crt_ctx *ctx, const crt_options *o, FramePlan &P
         else if (P.lean) launch_lds(stream_trace_shade_plan, level_blocks, plds, stream, A, g);
         else if (P.gi) launch(stream_trace_shade<false, true>, P.lane_blocks, stream, A, g);
         else launch(stream_trace_shade<false>, P.lane_blocks, stream, A, g);
-        if (P.heavy) {
+        if (P.heavy && !P.bvh) {   // (the filter kernels walk what they cannot decide themselves, in the reference's order: nothing is handed over)
             launch(P.gi ? heavy_trace_closest_gi : P.exec_count ? heavy_trace_closest_tally : heavy_trace_closest, HEAVY_BLOCKS, stream, A, g);
             if (P.gi) launch(stream_shade_evicted<false, true>, 256u, stream, A, g);
             else launch(stream_shade_evicted<false>, 256u, stream, A, g);
@@ -1161,9 +1165,9 @@ static int launch_stream_levels(crt_ctx *ctx, const crt_options *o, FramePlan &P
             else launch(stream_trace_shadow<false>, blocks0, where, S, 0u);
             // ... and behind it the walks it gave up, still beside the levels; the mark comes before the event the
             // caller's stream waits for, so nothing the later pass appends is below it
-            if (P.heavy) hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, where, S, (uint32_t)SC_SHEAVY_SPLIT, (uint32_t)SC_SHEAVY);
+            if (P.heavy && !P.bvh) hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, where, S, (uint32_t)SC_SHEAVY_SPLIT, (uint32_t)SC_SHEAVY);
             CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s1[P.slot], where));
-            if (P.heavy) launch(P.exec_count ? heavy_trace_shadow_tally : heavy_trace_shadow, HEAVY_BLOCKS, where, S, 0u);
+            if (P.heavy && !P.bvh) launch(P.exec_count ? heavy_trace_shadow_tally : heavy_trace_shadow, HEAVY_BLOCKS, where, S, 0u);
             CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s2[P.slot], where));
         }
     }
@@ -1201,7 +1205,7 @@ static int launch_stream_tail(crt_ctx *ctx, FramePlan &P, KernelArgs &A, hipStre
     else if (P.lean) launch(stream_trace_shadow_plan<1>, P.lane_blocks, stream, S1);
     else launch(stream_trace_shadow<false>, P.lane_blocks, stream, S1, 1u);
     if (side_per_cu) CRT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_s2[P.slot], 0));
-    if (P.heavy) launch(P.exec_count ? heavy_trace_shadow_tally : heavy_trace_shadow, HEAVY_BLOCKS, stream, S1, 1u);
+    if (P.heavy && !P.bvh) launch(P.exec_count ? heavy_trace_shadow_tally : heavy_trace_shadow, HEAVY_BLOCKS, stream, S1, 1u);
     CRT_HIP_CHECK(ctx, hipGetLastError());
     CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev2[P.slot], stream));
     A.counters = ctx->d_counters + 2 * C_N;
@@ -1295,8 +1299,12 @@ static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, fl
     // the plan kernels (kernel_plan.h): a small top-level tree (its leaves as a plan), 32-bit offsets, compact leaf links
     const bool lean = heavy && ctx->lean_ok && (SC.plan_ok || SC.plan_wide);
     const bool wide = lean && !SC.plan_ok;  // the wide plan (kernel_plan.h): more than 64 top-level leaves or meshes
-    // the filter kernels (kernel_bvh.h) hand rays without a verified finite hit to the wave-per-ray kernels: they need those
-    const bool bvh = heavy && SC.bvh_ok && ctx->tuning.bvh && !gi;
+    // the filter kernels (kernel_bvh.h): whenever the scene has a filter -- they need nothing of the plan or of the wave-per-ray kernels
+    const bool bvh = stream_mode && SC.bvh_ok && ctx->tuning.bvh && !gi && !count;
+    g_debug_sync = ctx->tuning.bvh == 3 ? 1 : 0;
+    if (g_debug_sync) fprintf(stderr, "[frame] bvh_trace_shade %p tally %p checked %p shadow0 %p shadow1 %p heavy_closest %p shade_evicted %p resolve %p heavy_shadow %p\n",
+                              (void *)bvh_trace_shade, (void *)bvh_trace_shade_tally, (void *)bvh_trace_shade_checked, (void *)bvh_trace_shadow<0, BVH_PLAIN>,
+                              (void *)bvh_trace_shadow<1, BVH_PLAIN>, (void *)heavy_trace_closest, (void *)stream_shade_evicted<false>, (void *)stream_resolve<false>, (void *)heavy_trace_shadow);
     if (stream_mode) {
         rc = ensure_stream(ctx, vitems);
         if (rc) return rc;
@@ -1669,7 +1677,7 @@ extern "C" int crt_describe_kernels(const crt_ctx *ctx, char *out, size_t size) 
         const bool heavy = ctx->step_budget && A.nested_boxes && (A.top_fast || A.plan_seq);
         const bool lean = heavy && ctx->lean_ok && (A.plan_ok || A.plan_wide);
         const bool wide = lean && !A.plan_ok;
-        const bool bvh = heavy && A.bvh_ok && ctx->tuning.bvh;
+        const bool bvh = A.bvh_ok && ctx->tuning.bvh;
         if (bvh) d = "level0=bvh_trace_shade;shadow0=bvh_trace_shadow<0u, 0>;levels=bvh_trace_shade";
         else d = std::string("level0=") + (!lean ? "stream_trace_shade<false>" : wide ? "stream_trace_shade_plan_wide" : "stream_trace_shade_plan");
         if (!bvh) d += std::string(";shadow0=") + (!lean ? "stream_trace_shadow<false>" : wide ? "stream_trace_shadow_plan_wide<0u>" : "stream_trace_shadow_plan<0u>");

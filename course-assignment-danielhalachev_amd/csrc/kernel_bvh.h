@@ -24,7 +24,8 @@
 #include "kernel_stream.h"
 #include "kernel_walk.h"
 
-constexpr uint32_t BVH_STACK = 32;   // entries per lane (LDS, one column per thread); a deeper walk is evicted
+constexpr uint32_t BVH_STACK = 32;   // entries per lane (LDS, one column per thread); a deeper walk is evicted.  A power of two: indices are masked
+static_assert((BVH_STACK & (BVH_STACK - 1u)) == 0, "BVH_STACK must be a power of two");
 constexpr float BVH_WIDEN = 0x1p-20f;
 constexpr uint32_t BVH_REFILL = 40;  // a wave hands out new rays when at most this many of its lanes still walk
 constexpr int BVH_STEPS = 4;         // walk steps between two looks at the lanes' states
@@ -37,7 +38,7 @@ constexpr int SC_BVH_DIAG = SC_HEAVY_DIAG + 16;
 template <int MODE>
 __device__ __forceinline__ uint32_t bvh_at(const KernelArgs &A, const uint32_t i, const uint32_t n, const uint32_t code) {
     if (MODE == BVH_CHECKED && i >= n) { A.f->s_counts[SC_BVH_DIAG + 2 * code] = 1u; A.f->s_counts[SC_BVH_DIAG + 2 * code + 1] = i; return 0u; }
-    return i;
+    return i < n ? i : 0u;   // (every build keeps its indices inside their arrays, whatever a walk's state says)
 }
 
 struct BvhRay { float ix, iy, iz, cpx, cpy, cpz, cmx, cmy, cmz; };
@@ -45,10 +46,16 @@ struct BvhRay { float ix, iy, iz, cpx, cpy, cpz, cmx, cmy, cmz; };
 // false: the ray has non-finite coordinates (the filter would pass everything: let the reference-order kernels take it)
 __device__ __forceinline__ bool bvh_ray_setup(const KernelArgs &A, const Ray &R, BvhRay &B) {
     const float rho = (A.s->bvh_extent + fmaxf(fmaxf(fabsf(R.ox), fabsf(R.oy)), fabsf(R.oz))) * 0x1p-16f;
-    B.ix = R.ix; B.iy = R.iy; B.iz = R.iz;
-    B.cpx = -((R.ox + rho) * R.ix); B.cmx = -((R.ox - rho) * R.ix);
-    B.cpy = -((R.oy + rho) * R.iy); B.cmy = -((R.oy - rho) * R.iy);
-    B.cpz = -((R.oz + rho) * R.iz); B.cmz = -((R.oz - rho) * R.iz);
+    // A direction component of (nearly) zero -- a light straight above its surface point -- would make 1/d infinite and every product
+    // with it a NaN, which passes: such a ray would walk half the hierarchy.  The filter walks the ray with that component moved to
+    // +-1e-12 instead: over any distance a hit can have (the scene's extent, < 1e7 here or rho is no longer small against it) the two
+    // rays are less than 1e-5 rho apart, which the slack covers many times over.
+    const float dx = fabsf(R.dx) < 1e-12f ? copysignf(1e-12f, R.dx) : R.dx, dy = fabsf(R.dy) < 1e-12f ? copysignf(1e-12f, R.dy) : R.dy,
+                dz = fabsf(R.dz) < 1e-12f ? copysignf(1e-12f, R.dz) : R.dz;
+    B.ix = 1.0f / dx; B.iy = 1.0f / dy; B.iz = 1.0f / dz;
+    B.cpx = -((R.ox + rho) * B.ix); B.cmx = -((R.ox - rho) * B.ix);
+    B.cpy = -((R.oy + rho) * B.iy); B.cmy = -((R.oy - rho) * B.iy);
+    B.cpz = -((R.oz + rho) * B.iz); B.cmz = -((R.oz - rho) * B.iz);
     const float s = (R.ox + R.oy + R.oz) + (R.dx + R.dy + R.dz);
     return fabsf(s) < INFINITY && fabsf(R.ox) < INFINITY && fabsf(R.oy) < INFINITY && fabsf(R.oz) < INFINITY;  // (NaN: false)
 }
@@ -167,12 +174,13 @@ struct BvhWalk {
     float best;                 // closest hit: distance of the best verified hit so far; shadow: the end of the segment
     uint32_t bk2, bk3, btri, bmesh, cache_mesh, cache_k2;
     bool have, give_up;
+    uint32_t steps;             // BVH_TALLY: steps of this walk (diagnostics)
 };
 __device__ __forceinline__ void bvh_walk_begin(BvhWalk &W, const float tmax) {
     W.cur = 0; W.sp = 0;  // the root is node 0
     W.best = tmax;
     W.bk2 = W.bk3 = NONE; W.btri = 0; W.bmesh = 0; W.cache_mesh = NONE; W.cache_k2 = NONE;
-    W.have = false; W.give_up = false;
+    W.have = false; W.give_up = false; W.steps = 0;
 }
 
 // One step of a lane's walk: an inner node (its four children tested, the nearest taken, the others pushed) or two triangles of a
@@ -180,10 +188,11 @@ __device__ __forceinline__ void bvh_walk_begin(BvhWalk &W, const float tmax) {
 template <bool SHADOW, int MODE>
 __device__ __forceinline__ bool bvh_step(const KernelArgs &A, const Ray &R, const bool primary, const float light_dist, const bool every_mesh,
                                          BvhWalk &W, uint32_t *stack, uint32_t &nbox, uint32_t &ntri) {
+    if (MODE == BVH_TALLY) W.steps++;
     if (W.cur == BVH_EMPTY) {
         if (W.sp == 0) return false;
         W.sp--;
-        W.cur = stack[bvh_at<MODE>(A, W.sp, BVH_STACK, 8) * BLOCK];
+        W.cur = stack[(bvh_at<MODE>(A, W.sp, BVH_STACK, 8) & (BVH_STACK - 1u)) * BLOCK];
     }
     if (!(W.cur & BVH_LEAF)) {
         const float4 *N = A.s->bvh_nodes + 8 * (size_t)bvh_at<MODE>(A, W.cur, A.s->n_bvh_nodes, 9);
@@ -204,9 +213,9 @@ __device__ __forceinline__ bool bvh_step(const KernelArgs &A, const Ray &R, cons
 #undef BVH_CSWAP
         const uint32_t n_push = (c1 != BVH_EMPTY ? 1u : 0u) + (c2 != BVH_EMPTY ? 1u : 0u) + (c3 != BVH_EMPTY ? 1u : 0u);
         if (W.sp + n_push > BVH_STACK) { W.give_up = true; return false; }
-        if (c3 != BVH_EMPTY) stack[(W.sp++) * BLOCK] = c3;
-        if (c2 != BVH_EMPTY) stack[(W.sp++) * BLOCK] = c2;
-        if (c1 != BVH_EMPTY) stack[(W.sp++) * BLOCK] = c1;
+        if (c3 != BVH_EMPTY) stack[((W.sp++) & (BVH_STACK - 1u)) * BLOCK] = c3;
+        if (c2 != BVH_EMPTY) stack[((W.sp++) & (BVH_STACK - 1u)) * BLOCK] = c2;
+        if (c1 != BVH_EMPTY) stack[((W.sp++) & (BVH_STACK - 1u)) * BLOCK] = c1;
         W.cur = c0;  // (BVH_EMPTY when the nearest slot holds a miss -- nothing passed, or a NaN distance out of order: the next step pops)
     } else {
         // two triangles of the leaf per step, both fetched before either is tested; what is left of the leaf stays in `cur`
@@ -243,12 +252,15 @@ __device__ __forceinline__ bool bvh_step(const KernelArgs &A, const Ray &R, cons
     return true;
 }
 
-enum : int { BVH_FETCH = 0, BVH_WALK = 1, BVH_OUT = 2, BVH_FINISHED = 3 };  // a lane: wants a ray, walks, nothing left to fetch, its walk has ended
+// a lane: wants a ray; walks it through the filter; nothing left to fetch; its walk has ended; walks it in the reference's own order
+enum : int { BVH_FETCH = 0, BVH_WALK = 1, BVH_OUT = 2, BVH_FINISHED = 3, BVH_EXACT = 4 };
 
-// Every ray of recursion level `gen`, persistent waves: a lane walks its ray through the filter; when enough lanes of the wave have
-// finished, they shade their hits together -- shootRay's material dispatch (kernel_stream.h: shade_and_emit); rays without a verified
-// finite hit are queued for heavy_trace_closest(gen) + stream_shade_evicted(gen) -- and take the next rays of the level (consecutive
-// ones: at level 0 neighbouring pixels of a tile).
+// Every ray of recursion level `gen`, persistent waves: a lane walks its ray through the filter; a ray WITHOUT a verified finite hit
+// (and one the filter gave up on) is then walked by the same lane in the reference's own order (kernel_lane.h: traversal_step, the
+// walk of the faithful kernels) -- only that walk sees an accepted hit with an infinite or NaN distance, which is the ray's hit when
+// there is no finite one (KDTree.cpp:75-86).  When enough lanes of the wave have finished, they shade together -- shootRay's
+// material dispatch (kernel_stream.h: shade_and_emit) -- and take the next rays of the level (consecutive ones: at level 0
+// neighbouring pixels of a tile).
 template <int MODE>
 __device__ __forceinline__ void bvh_shade_level(const KernelArgs &A, const uint32_t gen, uint32_t *stack_lds) {
     if (A.wave_prio) __builtin_amdgcn_s_setprio(3);
@@ -265,46 +277,62 @@ __device__ __forceinline__ void bvh_shade_level(const KernelArgs &A, const uint3
     R.ox = R.oy = R.oz = R.dx = R.dy = R.dz = R.ix = R.iy = R.iz = 0; R.parmask = 0;
     BvhWalk W;
     bvh_walk_begin(W, INFINITY);
+    LaneWalk L;
+    traversal_begin(L, A.s->top_root);
+    L.rtype = primary ? RAY_PRIMARY : RAY_REFLECTION;   // (reflection and refraction rays behave alike in the walk)
+    L.bt = 0; L.btri = 0; L.bmesh = 0; L.mt = 0; L.mtri = 0; L.light_dist = 0;
     int state = BVH_FETCH;
     uint32_t r = 0, spins = 0;
     for (;;) {
         if (MODE == BVH_CHECKED && ++spins > (1u << 22)) { bvh_at<MODE>(A, spins, 0u, 15); break; }   // (a loop that does not end: say so and leave)
-        if (__ballot(state == BVH_FETCH || state == BVH_FINISHED) && (uint32_t)__popcll(__ballot(state == BVH_WALK)) <= BVH_REFILL) {
+        if (__ballot(state == BVH_FETCH || state == BVH_FINISHED) && (uint32_t)__popcll(__ballot(state == BVH_WALK || state == BVH_EXACT)) <= BVH_REFILL) {
             if (state == BVH_FINISHED) {
-                if (W.have && !W.give_up) shade_and_emit<false, false>(A, gen, r, node_base, child_base, R, true, W.best, W.btri, W.bmesh, nullptr, lane);
-                else if (!evict_ray(A.f->s_heavy, A.f->s_heavy_cap, A.f->s_counts + SC_HEAVY + gen, r, lane)) A.f->s_counts[SC_OVERFLOW] = 1;
+                shade_and_emit<false, false>(A, gen, r, node_base, child_base, R, W.have, W.best, W.btri, W.bmesh, nullptr, lane);
                 state = BVH_FETCH;
             }
-            while (state == BVH_FETCH) {
+            // one fetch per free lane and round (a lane whose ray needs no walk here -- an uncovered pixel -- asks again next round): no
+            // inner loop, no `continue` (compiler notes)
+            if (state == BVH_FETCH) {
                 r = wave_fetch(A.f->s_counts + SC_FETCH + gen, lane);
-                if (r >= count) { state = BVH_OUT; break; }
-                if (gen == 0) {
-                    const Level0Ray P = level0_decode<false>(A, r);
-                    if (!P.covered) {
-                        reinterpret_cast<uint32_t *>(A.f->s_nodes + 2 * (size_t)r)[3] = TN_SKIP;
-                        level0_release_shadow_slots(A, r);
-                        continue;
+                if (r >= count) state = BVH_OUT;
+                else {
+                    bool walk = true;
+                    if (gen == 0) {
+                        const Level0Ray P = level0_decode<false>(A, r);
+                        if (!P.covered) {
+                            reinterpret_cast<uint32_t *>(A.f->s_nodes + 2 * (size_t)r)[3] = TN_SKIP;
+                            level0_release_shadow_slots(A, r);
+                            walk = false;
+                        } else level0_ray<false>(A, P, R);
+                    } else {
+                        const float4 q0 = in_q[2 * (size_t)r], q1 = in_q[2 * (size_t)r + 1];
+                        R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
+                        R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;
+                        normalize3(R.dx, R.dy, R.dz);  // shootRay entry (RayTracer.cpp:420)
+                        ray_prepare(R);
                     }
-                    level0_ray<false>(A, P, R);
-                } else {
-                    const float4 q0 = in_q[2 * (size_t)r], q1 = in_q[2 * (size_t)r + 1];
-                    R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
-                    R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;
-                    normalize3(R.dx, R.dy, R.dz);  // shootRay entry (RayTracer.cpp:420)
-                    ray_prepare(R);
+                    if (walk) {
+                        bvh_walk_begin(W, INFINITY);
+                        if (bvh_ray_setup(A, R, W.B)) state = BVH_WALK;
+                        else { traversal_begin(L, A.s->top_root); state = BVH_EXACT; }
+                    }
                 }
-                bvh_walk_begin(W, INFINITY);
-                if (!bvh_ray_setup(A, R, W.B)) {
-                    if (!evict_ray(A.f->s_heavy, A.f->s_heavy_cap, A.f->s_counts + SC_HEAVY + gen, r, lane)) A.f->s_counts[SC_OVERFLOW] = 1;
-                    continue;
-                }
-                state = BVH_WALK;
             }
         }
         if (!__ballot(state != BVH_OUT)) break;
         if (state == BVH_WALK) {
             for (int it = 0; it < BVH_STEPS; ++it)
-                if (!bvh_step<false, MODE>(A, R, primary, 0.0f, false, W, stack, nbox, ntri)) { state = BVH_FINISHED; break; }
+                if (state == BVH_WALK && !bvh_step<false, MODE>(A, R, primary, 0.0f, false, W, stack, nbox, ntri)) {
+                    if (W.have && !W.give_up) state = BVH_FINISHED;
+                    else { traversal_begin(L, A.s->top_root); state = BVH_EXACT; }
+                }
+        }
+        if (state == BVH_EXACT) {
+            for (int it = 0; it < 2 * BVH_STEPS; ++it)
+                if (state == BVH_EXACT && !traversal_step<false>(L, R, A, nullptr)) {
+                    W.have = L.have; W.best = L.bt; W.btri = L.btri; W.bmesh = L.bmesh;
+                    state = BVH_FINISHED;
+                }
         }
     }
     exec_counters_flush(A, nbox, ntri, lane);
@@ -335,42 +363,60 @@ __device__ __forceinline__ void bvh_shadow_rays(const KernelArgs &A, const uint3
     R.ox = R.oy = R.oz = R.dx = R.dy = R.dz = R.ix = R.iy = R.iz = 0; R.parmask = 0;
     BvhWalk W;
     bvh_walk_begin(W, INFINITY);
+    LaneWalk L;   // (a walk the filter gave up on is redone in the reference's order, as in bvh_shade_level)
+    traversal_begin(L, A.s->top_root);
+    L.rtype = RAY_SHADOW;
+    L.bt = 0; L.btri = 0; L.bmesh = 0; L.mt = 0; L.mtri = 0; L.light_dist = 0;
     float light_dist = 0;
     int state = BVH_FETCH;
     uint32_t r = 0, spins = 0;
     for (;;) {
         if (MODE == BVH_CHECKED && ++spins > (1u << 22)) { bvh_at<MODE>(A, spins, 0u, 15); break; }   // (a loop that does not end: say so and leave)
-        if (__ballot(state == BVH_FETCH || state == BVH_FINISHED) && (uint32_t)__popcll(__ballot(state == BVH_WALK)) <= BVH_REFILL) {
+        if (__ballot(state == BVH_FETCH || state == BVH_FINISHED) && (uint32_t)__popcll(__ballot(state == BVH_WALK || state == BVH_EXACT)) <= BVH_REFILL) {
             if (state == BVH_FINISHED) {
-                if (W.give_up) { if (!evict_ray(A.f->s_sheavy, A.f->s_heavy_cap, A.f->s_counts + SC_SHEAVY, r, lane)) A.f->s_counts[SC_OVERFLOW] = 1; }
-                else A.f->s_occluded[r] = W.have ? 1 : 0;
+                if (MODE == BVH_TALLY) {   // diagnostics: the longest walk of the pass, which ray it was, all steps, walks of 1024 steps and more
+                    uint32_t *dg = A.f->s_counts + SC_BVH_DIAG + 40;
+                    if (atomicMax(dg + 0, W.steps) < W.steps) dg[1] = r;
+                    atomicAdd(dg + 2, W.steps >> 4);
+                    if (W.steps >= 1024u) atomicAdd(dg + 3, 1u);
+                }
+                A.f->s_occluded[r] = W.have ? 1 : 0;
                 state = BVH_FETCH;
             }
-            while (state == BVH_FETCH) {
+            if (state == BVH_FETCH) {   // (one fetch per free lane and round, as in bvh_shade_level)
                 r = wave_fetch(cursor, lane);
-                if (r >= total) { state = BVH_OUT; break; }
-                r += first;
-                const float4 q0 = A.f->s_shadowq[2 * (size_t)r], q1 = A.f->s_shadowq[2 * (size_t)r + 1];
-                if (__float_as_uint(q0.w) == SHADOW_SLOT_UNUSED) continue;  // a level-0 pixel without a diffuse hit
-                // a light behind the surface contributes +-0 times the albedo: no walk (kernel_plan.h has the argument)
-                if (q1.w == 0.0f) { A.f->s_occluded[r] = 0; continue; }
-                R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
-                R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;  // already normalised once; shadow rays skip shootRay (RayTracer.cpp:313-317)
-                ray_prepare(R);
-                light_dist = q0.w;
-                // an occluding hit has length(o + d t - o) <= light_dist with |d| = 1 up to two unit roundoffs: t <= light_dist (1 + 2^-16) (NaN: no bound)
-                bvh_walk_begin(W, light_dist * (1.0f + 0x1p-16f));
-                if (!bvh_ray_setup(A, R, W.B)) {
-                    if (!evict_ray(A.f->s_sheavy, A.f->s_heavy_cap, A.f->s_counts + SC_SHEAVY, r, lane)) A.f->s_counts[SC_OVERFLOW] = 1;
-                    continue;
+                if (r >= total) state = BVH_OUT;
+                else {
+                    r += first;
+                    const float4 q0 = A.f->s_shadowq[2 * (size_t)r], q1 = A.f->s_shadowq[2 * (size_t)r + 1];
+                    // an unused slot (a level-0 pixel without a diffuse hit) needs nothing.  A light behind the surface contributes +-0
+                    // times the albedo: no walk (kernel_plan.h has the argument)
+                    if (__float_as_uint(q0.w) == SHADOW_SLOT_UNUSED) {}
+                    else if (q1.w == 0.0f) A.f->s_occluded[r] = 0;
+                    else {
+                        R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
+                        R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;  // already normalised once; shadow rays skip shootRay (RayTracer.cpp:313-317)
+                        ray_prepare(R);
+                        light_dist = q0.w;
+                        // an occluding hit has length(o + d t - o) <= light_dist with |d| = 1 up to two unit roundoffs: t <= light_dist (1 + 2^-16) (NaN: no bound)
+                        bvh_walk_begin(W, light_dist * (1.0f + 0x1p-16f));
+                        if (bvh_ray_setup(A, R, W.B)) state = BVH_WALK;
+                        else { traversal_begin(L, A.s->top_root); L.light_dist = light_dist; state = BVH_EXACT; }
+                    }
                 }
-                state = BVH_WALK;
             }
         }
         if (!__ballot(state != BVH_OUT)) break;
         if (state == BVH_WALK) {
             for (int it = 0; it < BVH_STEPS; ++it)
-                if (!bvh_step<true, MODE>(A, R, false, light_dist, every_mesh, W, stack, nbox, ntri)) { state = BVH_FINISHED; break; }
+                if (state == BVH_WALK && !bvh_step<true, MODE>(A, R, false, light_dist, every_mesh, W, stack, nbox, ntri)) {
+                    if (!W.give_up) state = BVH_FINISHED;
+                    else { traversal_begin(L, A.s->top_root); L.light_dist = light_dist; state = BVH_EXACT; }
+                }
+        }
+        if (state == BVH_EXACT) {
+            for (int it = 0; it < 2 * BVH_STEPS; ++it)
+                if (state == BVH_EXACT && !traversal_step<false>(L, R, A, nullptr)) { W.have = L.occluded; state = BVH_FINISHED; }
         }
     }
     exec_counters_flush(A, nbox, ntri, lane);

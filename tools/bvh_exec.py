@@ -14,4 +14,5 @@ for bvh in (0, 1):
     e = tr.executed_counters()
     c = tr.stream_counts()
     rays0 = int(c[327]); 
+    c2 = tr.stream_counts(); print('  shadow walks: longest', int(c2[440]), 'steps (ray', int(c2[441]), ') total/16', int(c2[442]), 'walks >= 1024 steps', int(c2[443]))
     print(name, 'bvh', bvh, e, 'pass-0 slots', rays0, 'per slot: box %.1f tri %.2f' % (e['shadow_pass0_box_tests'] / max(rays0, 1), e['shadow_pass0_tri_tests'] / max(rays0, 1)), 'phase ms', tr.kernel_times_ms(1), flush=True)
