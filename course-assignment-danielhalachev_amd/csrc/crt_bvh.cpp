@@ -283,7 +283,7 @@ void bvh_build(const crt_scene_desc *s, bool nested_boxes, BvhHost &out) {
         for (size_t j = 0; j < mesh_tops[m].size() / 2; j++) push_box_entry(out.mesh_top_list, s->nodes[mesh_tops[m][2 * j]], mesh_tops[m][2 * j + 1]);
     }
     // ---- the triangles a ray can be tested against at all, each in a box grown by its margin
-    std::vector<Box> pbox(s->n_triangles);
+    std::vector<Box> pbox(s->n_triangles), vbox(s->n_triangles);
     Builder B(pbox);
     for (uint32_t t = 0; t < s->n_triangles; t++) {
         if (out.tri_mesh[t] == NONE) continue;             // no leaf lists it: the reference never tests it
@@ -304,6 +304,14 @@ void bvh_build(const crt_scene_desc *s, bool nested_boxes, BvhHost &out) {
             b.hi[a] = std::nextafter((float)hi, FLT_MAX);
             if (!std::isfinite(b.lo[a]) || !std::isfinite(b.hi[a])) return no("coordinates out of range");
         }
+        // ... and, for the miss check, the box of everything the reference can reach this triangle through: the leaves listing it
+        Box &v = vbox[t];
+        v = b;
+        for (size_t j = 0; j < tri_leaves[t].size(); j += 2) {
+            const crt_node &nd = s->nodes[tri_leaves[t][j]];
+            for (int a = 0; a < 3; a++) { v.lo[a] = std::min(v.lo[a], nd.lo[a]); v.hi[a] = std::max(v.hi[a], nd.hi[a]); }
+        }
+        for (int a = 0; a < 3; a++) if (!std::isfinite(v.lo[a]) || !std::isfinite(v.hi[a])) return no("coordinates out of range");
         B.prims.push_back(t);
     }
     if (B.prims.size() >= (1u << 24)) return no("too many triangles for the leaf links");
@@ -317,9 +325,57 @@ void bvh_build(const crt_scene_desc *s, bool nested_boxes, BvhHost &out) {
         }
         return N;
     };
-    if (B.prims.empty()) { out.nodes.push_back(empty_node()); out.ok = true; return; }
+    if (B.prims.empty()) {
+        out.nodes.push_back(empty_node()); out.wide_depth = 1;
+        out.vnodes.assign(24, 0.0f); out.cones.assign(16, 0.0f);
+        out.ok = true;
+        return;
+    }
     const int32_t root = B.build(0, (uint32_t)B.prims.size(), 0);
     out.max_depth = B.max_depth;
+    // ---- what the miss check reads: per node of the binary build, the box of its triangles' leaf unions and a cone around their normals
+    struct Agg { Box v; double ax[3]; double theta; };   // theta: half-angle (pi: no bound)
+    std::vector<Agg> agg(B.nodes.size());
+    {
+        constexpr double PI = 3.14159265358979323846;
+        auto angle = [](const double a[3], const double b[3]) {
+            const double d = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+            return std::acos(std::max(-1.0, std::min(1.0, d)));
+        };
+        // post-order without recursion: children have larger indices than their parent (Builder::build), so a reverse sweep does it
+        for (size_t i = B.nodes.size(); i-- > 0;) {
+            const BinNode &n = B.nodes[i];
+            Agg &g = agg[i];
+            box_empty(g.v);
+            double sum[3] = {0, 0, 0};
+            if (n.left < 0) {
+                for (uint32_t k = n.first; k < n.first + n.count; k++) {
+                    const crt_triangle &T = s->triangles[B.prims[k]];
+                    box_add(g.v, vbox[B.prims[k]]);
+                    sum[0] += T.nx; sum[1] += T.ny; sum[2] += T.nz;
+                }
+            } else {
+                box_add(g.v, agg[n.left].v); box_add(g.v, agg[n.right].v);
+                for (int a = 0; a < 3; a++) sum[a] = agg[n.left].ax[a] + agg[n.right].ax[a];
+            }
+            const double len = std::sqrt(sum[0] * sum[0] + sum[1] * sum[1] + sum[2] * sum[2]);
+            if (!(len > 1e-9)) { g.ax[0] = 1; g.ax[1] = 0; g.ax[2] = 0; g.theta = PI; continue; }
+            for (int a = 0; a < 3; a++) g.ax[a] = sum[a] / len;
+            g.theta = 0;
+            if (n.left < 0) {
+                for (uint32_t k = n.first; k < n.first + n.count; k++) {
+                    const crt_triangle &T = s->triangles[B.prims[k]];
+                    const double nn[3] = {T.nx, T.ny, T.nz};   // (a unit vector to 1e-3: triangle_margin; the angle does not care)
+                    const double l = std::sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+                    const double u[3] = {nn[0] / l, nn[1] / l, nn[2] / l};
+                    g.theta = std::max(g.theta, angle(g.ax, u));
+                }
+            } else {
+                for (int32_t c : {n.left, n.right}) g.theta = std::max(g.theta, std::min(PI, angle(g.ax, agg[c].ax) + agg[c].theta));
+            }
+            g.theta = std::min(PI, g.theta + 1e-6);
+        }
+    }
     // ---- collapse to four children per node; leaves' triangles in leaf order
     auto emit_leaf = [&](const BinNode &n) -> uint32_t {
         const uint32_t first = (uint32_t)out.ids.size();
@@ -332,13 +388,14 @@ void bvh_build(const crt_scene_desc *s, bool nested_boxes, BvhHost &out) {
         }
         return BVH_LEAF | ((n.count - 1u) << 24) | first;
     };
-    struct Work { int32_t bin; uint32_t node; };
+    struct Work { int32_t bin; uint32_t node; uint32_t depth; };
     std::vector<Work> todo;
     out.nodes.push_back(empty_node());
-    todo.push_back({root, 0});
+    todo.push_back({root, 0, 1});
     for (size_t w = 0; w < todo.size(); w++) {   // breadth-first: the top of the tree in consecutive lines
         const int32_t bin = todo[w].bin;
-        const uint32_t at = todo[w].node;
+        const uint32_t at = todo[w].node, depth = todo[w].depth;
+        out.wide_depth = std::max(out.wide_depth, depth);
         int32_t kids[4];
         int nk = 0;
         if (B.nodes[bin].left < 0) kids[nk++] = bin;   // (only the root can be a leaf here)
@@ -354,8 +411,22 @@ void bvh_build(const crt_scene_desc *s, bool nested_boxes, BvhHost &out) {
             kids[nk++] = B.nodes[k0].right;
         }
         BvhNode N = empty_node();
+        float V[24], C[16];
+        for (int k = 0; k < 4; k++) {
+            V[k] = V[4 + k] = V[8 + k] = FLT_MAX; V[12 + k] = V[16 + k] = V[20 + k] = -FLT_MAX;
+            C[k] = 1.0f; C[4 + k] = C[8 + k] = 0.0f; C[12 + k] = 2.0f;
+        }
         for (int k = 0; k < nk; k++) {
             const BinNode &c = B.nodes[kids[k]];
+            const Agg &g = agg[kids[k]];
+            for (int a = 0; a < 3; a++) {
+                V[4 * a + k] = g.v.lo[a]; V[12 + 4 * a + k] = g.v.hi[a];
+                C[4 * a + k] = (float)g.ax[a];
+                out.extent = std::max({out.extent, std::fabs(g.v.lo[a]), std::fabs(g.v.hi[a])});
+            }
+            // skip the child when |d . axis| > sin(theta + 1e-4): then no normal of the cone is within 1e-4 rad of perpendicular to d
+            const double bound = g.theta + 1e-4;
+            C[12 + k] = bound >= 1.5707 ? 2.0f : std::nextafter((float)std::sin(bound), 4.0f);
             N.lox[k] = c.box.lo[0]; N.loy[k] = c.box.lo[1]; N.loz[k] = c.box.lo[2];
             N.hix[k] = c.box.hi[0]; N.hiy[k] = c.box.hi[1]; N.hiz[k] = c.box.hi[2];
             for (int a = 0; a < 3; a++) out.extent = std::max({out.extent, std::fabs(c.box.lo[a]), std::fabs(c.box.hi[a])});  // (the margins on top)
@@ -363,11 +434,16 @@ void bvh_build(const crt_scene_desc *s, bool nested_boxes, BvhHost &out) {
             else {
                 N.child[k] = (uint32_t)out.nodes.size();
                 out.nodes.push_back(empty_node());
-                todo.push_back({kids[k], N.child[k]});
+                todo.push_back({kids[k], N.child[k], depth + 1});
             }
         }
         out.nodes[at] = N;
+        if (out.vnodes.size() < out.nodes.size() * 24) { out.vnodes.resize(out.nodes.size() * 24, 0.0f); out.cones.resize(out.nodes.size() * 16, 0.0f); }
+        std::copy(V, V + 24, out.vnodes.begin() + (size_t)at * 24);
+        std::copy(C, C + 16, out.cones.begin() + (size_t)at * 16);
     }
+    out.vnodes.resize(out.nodes.size() * 24, 0.0f);
+    out.cones.resize(out.nodes.size() * 16, 0.0f);
     if (out.nodes.size() >= (1u << 31)) return no("too many nodes");
     out.ok = true;
 }

@@ -57,8 +57,15 @@ struct BvhHost {
     // CSR: the top-level leaves listing mesh m, in visit order, the same form with the entry position in leaf_meshes
     std::vector<uint32_t> mesh_top_first;
     std::vector<float> mesh_top_list;
+    // The same hierarchy as the MISS CHECK reads it (kernel_bvh.h: bvh_miss_step): per node, per child,
+    //   vnodes  the box of everything the reference could reach the child's triangles THROUGH: the union of the boxes of the
+    //           reference leaves listing them (and of the triangles themselves) -- 24 floats lo.x[4] .. hi.z[4];
+    //   cones   a cone around the child's triangle normals -- axis x[4] y[4] z[4] and k[4] = sin(half-angle + 1e-4): a direction d
+    //           with |d . axis| > k is more than 1e-4 rad away from being parallel to any of those triangles' planes.
+    std::vector<float> vnodes, cones;
     float extent = 0;                // largest absolute coordinate of any box
-    uint32_t max_depth = 0;
+    uint32_t max_depth = 0;          // of the binary build
+    uint32_t wide_depth = 0;         // inner nodes on the longest root-to-leaf path of the 4-wide hierarchy
     double max_margin = 0;
     uint32_t walk_triangles = 0;     // triangles verified by the pruned tree walk
 };

@@ -135,6 +135,9 @@ struct crt_ctx {
     uint32_t *d_sheavy = nullptr;     // evicted shadow ray ids
     float4 *d_hits = nullptr;         // their closest hits
     float4 *d_hits_all = nullptr;     // a level's closest hits by ray index (kernel_plan.h: the walk-only builds)
+    unsigned long long *d_lq = nullptr;   // kernel_bvh.h: the level queue (one entry per ray-tree node at most), 8 granules per ray
+    uint32_t *d_lq_words = nullptr;       // ... and its counters (kernel_stream.h: LQ_*)
+    uint32_t *d_bvh_spill = nullptr;  // kernel_bvh.h: the walks' stacks beyond their LDS part: one region for the caller's stream, one for the side stream
     hipStream_t side = nullptr;       // shadow pass 0 overlaps the deeper recursion levels on this stream
     // What a finished frame tells the next ones (queue sizing, launch sizes, fallback count): every frame copies its counter
     // block and the fallback total to ITS slot of this pinned ring, and the host reads a slot only once that frame's last
@@ -364,9 +367,10 @@ extern "C" void crt_tuning_defaults(crt_tuning *t) {
     t->size = (uint32_t)sizeof(*t);
     t->mode = CRT_MODE_STREAM;
     t->step_budget = 384; t->shadow_budget = 4096; t->level0_budget = 0;
-    t->heavy_level = 100000; t->side_blocks = 3;
+    t->heavy_level = 100000; t->side_blocks = 2;
     t->node_cap = t->ray_cap = t->shadow_cap = 0;
     t->bvh = 1;
+    t->level_queue = 2;
 }
 
 extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) { return crt_create_tuned(s, device, nullptr, out); }
@@ -744,11 +748,13 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
         BvhHost bvh;
         bvh_build(s, A.nested_boxes != 0, bvh);
         if (bvh.ok && !A.plan_compact) { bvh.ok = false; bvh.why = "no compact leaf links"; }  // (kernel_bvh.h: bvh_leaf_walk reads them)
+        A.bvh_stack = 3u * bvh.wide_depth + 1u;   // what a walk can push: three children per inner node of a path
+        if (bvh.ok && A.bvh_stack > 1024u) { bvh.ok = false; bvh.why = "hierarchy too deep"; }
         ctx->bvh_note = bvh.ok ? "" : bvh.why;
         if (bvh.ok) {
             char note[160];
-            snprintf(note, sizeof(note), "nodes:%zu,entries:%zu,depth:%u,walk_triangles:%u,max_margin:%.3g", bvh.nodes.size(), bvh.ids.size(),
-                     bvh.max_depth, bvh.walk_triangles, bvh.max_margin);
+            snprintf(note, sizeof(note), "nodes:%zu,entries:%zu,depth:%u/%u,walk_triangles:%u,max_margin:%.3g", bvh.nodes.size(), bvh.ids.size(),
+                     bvh.max_depth, bvh.wide_depth, bvh.walk_triangles, bvh.max_margin);
             ctx->bvh_stats = note;
         }
         // the leaf sequences of the wave-per-ray kernels were read off index ranges [root, next root): a description whose trees are
@@ -763,6 +769,8 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
         if (!bvh.ok) bvh = BvhHost{};
         static_assert(sizeof(BvhNode) == 8 * sizeof(float4), "BvhNode = 8 x float4");
         if (upload(ctx, (const float4 *)bvh.nodes.data(), bvh.nodes.size() * 8, &A.bvh_nodes)) return fail(CRT_ERR_HIP);
+        if (upload(ctx, (const float4 *)bvh.vnodes.data(), bvh.vnodes.size() / 4, &A.bvh_vnodes)) return fail(CRT_ERR_HIP);
+        if (upload(ctx, (const float4 *)bvh.cones.data(), bvh.cones.size() / 4, &A.bvh_cones)) return fail(CRT_ERR_HIP);
         if (upload(ctx, (const float4 *)bvh.tris.data(), bvh.tris.size() / 4, &A.bvh_tris)) return fail(CRT_ERR_HIP);
         if (upload(ctx, bvh.ids.data(), bvh.ids.size(), &A.bvh_ids)) return fail(CRT_ERR_HIP);
         if (upload(ctx, bvh.tri_mesh.data(), bvh.tri_mesh.size(), &A.tri_mesh)) return fail(CRT_ERR_HIP);
@@ -786,6 +794,8 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
     ctx->mode = tune.mode == CRT_MODE_LANES ? crt_ctx::MODE_LANES : crt_ctx::MODE_STREAM;
     if (ctx->step_budget) ctx->step_budget = tune.step_budget;  // (0: a mesh with too many leaves switched the wave-per-ray path off)
     ctx->lean_ok = s->n_nodes < (1u << 27) && s->n_leaf_triangles < (1ull << 26);
+    CK(hipMalloc((void **)&ctx->d_lq_words, LQ_WORDS * sizeof(uint32_t)));
+    CK(hipMemset(ctx->d_lq_words, 0, LQ_WORDS * sizeof(uint32_t)));
     CK(hipMalloc((void **)&ctx->d_exec, 6 * sizeof(unsigned long long)));
     CK(hipMemset(ctx->d_exec, 0, 6 * sizeof(unsigned long long)));
     CK(hipMalloc((void **)&ctx->d_scounts, SC_ALLOC_WORDS * sizeof(uint32_t)));
@@ -800,6 +810,8 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
     CK(hipMalloc((void **)&ctx->d_counters, 3 * C_N * sizeof(unsigned long long)));  // [levels | shadow pass 0 | the rest]
     // persistent grid: 8 blocks of 256 threads per CU gives every CU its 32 waves if registers allow
     ctx->grid_blocks = (uint32_t)ctx->num_cus * 8u;
+    if (ctx->scene.bvh_ok && ctx->scene.bvh_stack > BVH_LDS_STACK)
+        CK(hipMalloc((void **)&ctx->d_bvh_spill, 2u * (size_t)ctx->grid_blocks * BLOCK * (ctx->scene.bvh_stack - BVH_LDS_STACK) * sizeof(uint32_t)));
     // the argument blocks (kernel_common.h): the scene's once, a slot per frame in flight for the frames'
     CK(hipMalloc((void **)&ctx->d_scene, sizeof(SceneArgs)));
     CK(hipMemcpy(ctx->d_scene, &ctx->scene, sizeof(SceneArgs), hipMemcpyHostToDevice));
@@ -828,6 +840,9 @@ extern "C" void crt_destroy(crt_ctx *ctx) {
     if (ctx->d_sheavy) (void)hipFree(ctx->d_sheavy);
     if (ctx->d_hits) (void)hipFree(ctx->d_hits);
     if (ctx->d_hits_all) (void)hipFree(ctx->d_hits_all);
+    if (ctx->d_bvh_spill) (void)hipFree(ctx->d_bvh_spill);
+    if (ctx->d_lq) (void)hipFree(ctx->d_lq);
+    if (ctx->d_lq_words) (void)hipFree(ctx->d_lq_words);
     if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
     if (ctx->h_frame_ring) (void)hipHostFree(ctx->h_frame_ring);
     if (ctx->d_frame_ring) (void)hipFree(ctx->d_frame_ring);
@@ -1013,7 +1028,8 @@ static int ensure_stream(crt_ctx *ctx, uint32_t n_items) {
             shadow_cap = std::max<uint64_t>(shadow_cap, A.s_shadow_cap);
         }
         void **bufs[] = {(void **)&ctx->d_rayq[0], (void **)&ctx->d_rayq[1], (void **)&ctx->d_shadowq, (void **)&ctx->d_occluded,
-                         (void **)&ctx->d_nodes, (void **)&ctx->d_heavy, (void **)&ctx->d_sheavy, (void **)&ctx->d_hits, (void **)&ctx->d_hits_all};
+                         (void **)&ctx->d_nodes, (void **)&ctx->d_heavy, (void **)&ctx->d_sheavy, (void **)&ctx->d_hits, (void **)&ctx->d_hits_all,
+                         (void **)&ctx->d_lq};
         for (void **b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
         ctx->stream_items = 0;
         A.s_node_cap = A.s_ray_cap = A.s_shadow_cap = 0;
@@ -1027,13 +1043,19 @@ static int ensure_stream(crt_ctx *ctx, uint32_t n_items) {
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_sheavy, (size_t)ctx->heavy_cap * sizeof(uint32_t) + 64));
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_hits, (size_t)ctx->heavy_cap * sizeof(float4)));
         CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_hits_all, (size_t)std::max<uint64_t>(ray_cap, px) * sizeof(float4)));  // (level 0 holds px rays, a deeper level at most ray_cap)
+        if (ctx->scene.bvh_ok && ctx->tuning.bvh && ctx->tuning.level_queue) {
+            // the level queue: every ray below level 0 owns a node, so node_cap entries always do; its tags start as "no frame's"
+            CRT_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_lq, node_cap * 8 * sizeof(unsigned long long)));
+            CRT_HIP_CHECK(ctx, hipMemset(ctx->d_lq, 0, node_cap * 8 * sizeof(unsigned long long)));
+        }
         A.s_ray_cap = (uint32_t)ray_cap; A.s_shadow_cap = (uint32_t)shadow_cap; A.s_node_cap = (uint32_t)node_cap;
         ctx->stream_items = n_items;
-        ctx->queue_bytes = ray_cap * 64 + shadow_cap * 33 + node_cap * 32 + (size_t)ctx->heavy_cap * 24 + std::max<uint64_t>(ray_cap, px) * 16;
+        ctx->queue_bytes = ray_cap * 64 + shadow_cap * 33 + node_cap * 32 + (size_t)ctx->heavy_cap * 24 + std::max<uint64_t>(ray_cap, px) * 16 + (ctx->d_lq ? node_cap * 64 : 0);
     }
     A.s_rayq[0] = ctx->d_rayq[0]; A.s_rayq[1] = ctx->d_rayq[1];
     A.s_shadowq = ctx->d_shadowq; A.s_occluded = ctx->d_occluded; A.s_nodes = ctx->d_nodes;
     A.s_heavy = ctx->d_heavy; A.s_sheavy = ctx->d_sheavy; A.s_hits = ctx->d_hits; A.s_hits_all = ctx->d_hits_all; A.s_heavy_cap = ctx->heavy_cap;
+    A.s_lq = ctx->d_lq; A.s_lq_cap = ctx->d_lq ? A.s_node_cap : 0u;
     return CRT_OK;
 }
 
@@ -1068,7 +1090,8 @@ struct FramePlan {
     uint32_t lane_blocks;         // grid of the kernels that take one ray (or pixel) per lane
     bool gi, count, exec_count;   // GI mode; counting build; production kernels tallying the tests they execute
     bool heavy, lean, wide;       // wave-per-ray kernels on; plan kernels; the wide plan
-    bool bvh;                     // the filter kernels (kernel_bvh.h) walk the rays; the kernels above take what they hand over
+    bool bvh;                     // the filter kernels (kernel_bvh.h) walk the rays
+    bool queue;                   // ... and every level below level 0 is one launch (bvh_trace_queue)
     uint32_t level_budget;        // steps after which a deeper level's per-lane walk is evicted
     const uint32_t *prev;         // counters of a completed frame of this size and kind, or null
     bool last_resort;             // render_lanes behind the stream pass
@@ -1077,6 +1100,7 @@ struct FramePlan {
 // Levels 0 .. MAX_DEPTH on `stream`; after level 0 the bulk shadow pass (and the walks it gives up) on the side stream.
 static int launch_stream_levels(crt_ctx *ctx, const crt_options *o, FramePlan &P, KernelArgs &A, hipStream_t stream) {
     CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_scounts, 0, SC_ALLOC_WORDS * sizeof(uint32_t), stream));
+    if (P.queue) for (int w : {LQ_TAIL, LQ_HEAD, LQ_DONE, LQ_ABORT}) CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_lq_words + w, 0, 16, stream));
     const uint32_t side_per_cu = ctx->tuning.side_blocks;  // workgroups per CU of the bulk shadow pass beside the levels
     A.exec_count = P.exec_count ? 1u : 0u;
     A.exec_counters = ctx->d_exec;
@@ -1126,7 +1150,12 @@ static int launch_stream_levels(crt_ctx *ctx, const crt_options *o, FramePlan &P
             const uint32_t want = was < ctx->frame.heavy_level_threshold ? 64u : std::max<uint32_t>((uint32_t)ctx->num_cus, (was + was / 2u + BLOCK - 1) / BLOCK);
             level_blocks = std::min(P.lane_blocks, want);
         }
-        if (P.bvh) launch(P.exec_count ? bvh_trace_shade_tally : ctx->tuning.bvh == 2 ? bvh_trace_shade_checked : bvh_trace_shade, g == 0 ? P.lane_blocks : level_blocks, stream, A, g);
+        if (P.queue && g == 0) {
+            if (P.exec_count) launch(bvh_trace_level0<BVH_TALLY>, P.lane_blocks, stream, A);
+            else if (ctx->tuning.bvh == 2) launch(bvh_trace_level0<BVH_CHECKED>, P.lane_blocks, stream, A);
+            else launch(bvh_trace_level0<BVH_PLAIN>, P.lane_blocks, stream, A);
+        }
+        else if (P.bvh) launch(P.exec_count ? bvh_trace_shade_tally : ctx->tuning.bvh == 2 ? bvh_trace_shade_checked : bvh_trace_shade, g == 0 ? P.lane_blocks : level_blocks, stream, A, g);
         else if (P.count) { if (P.gi) launch(stream_trace_shade<true, true>, P.lane_blocks, stream, A, g); else launch(stream_trace_shade<true>, P.lane_blocks, stream, A, g); }
         else if (P.lean && P.gi) {
             // the GI mode: the walk alone, then the level's shading -- sample directions, gi_samples child rays -- with every lane busy
@@ -1169,6 +1198,18 @@ static int launch_stream_levels(crt_ctx *ctx, const crt_options *o, FramePlan &P
             CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s1[P.slot], where));
             if (P.heavy && !P.bvh) launch(P.exec_count ? heavy_trace_shadow_tally : heavy_trace_shadow, HEAVY_BLOCKS, where, S, 0u);
             CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s2[P.slot], where));
+        }
+        if (P.queue) {
+            // every level below level 0: one launch that feeds itself (kernel_bvh.h); two workgroups per CU hold more lanes than the
+            // widest level of a frame of this size has rays
+            const uint32_t qblocks = std::min(P.lane_blocks, (uint32_t)ctx->num_cus * std::max(1u, ctx->tuning.level_queue));
+            if (o->max_depth >= 1) {
+                A.bundle = ctx->tuning.level0_budget ? ctx->tuning.level0_budget - 1u : 15u;   // (development: turns between two housekeeping rounds, as a mask)
+                if (P.exec_count) launch(bvh_trace_queue<BVH_TALLY>, qblocks, stream, A);
+                else if (ctx->tuning.bvh == 2) launch(bvh_trace_queue<BVH_CHECKED>, qblocks, stream, A);
+                else launch(bvh_trace_queue<BVH_PLAIN>, qblocks, stream, A);
+            }
+            break;
         }
     }
     return CRT_OK;
@@ -1272,6 +1313,10 @@ static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, fl
     F.packed = packed;
     F.s_counts = ctx->d_scounts;
     F.fallback_total = ctx->d_fallback_total;
+    F.s_lq_words = ctx->d_lq_words;
+    F.lq_epoch = (uint32_t)(ctx->launches & 0x7FFFFFFFull) + 1u;   // the level queue's tag of this frame (this context's buffer has never seen it: tags only grow)
+    F.bvh_spill = ctx->d_bvh_spill;
+    F.bvh_spill_side = ctx->d_bvh_spill ? ctx->d_bvh_spill + (size_t)ctx->grid_blocks * BLOCK * (ctx->scene.bvh_stack - BVH_LDS_STACK) : nullptr;
     const bool count = o->collect_counters == 1;       // the counting build: every ray walked the reference's way
     const bool exec_count = o->collect_counters == 2;  // the production kernels, tallying the tests they execute
     CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_sync, 0, 4 * sizeof(uint32_t), stream));
@@ -1301,6 +1346,7 @@ static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, fl
     const bool wide = lean && !SC.plan_ok;  // the wide plan (kernel_plan.h): more than 64 top-level leaves or meshes
     // the filter kernels (kernel_bvh.h): whenever the scene has a filter -- they need nothing of the plan or of the wave-per-ray kernels
     const bool bvh = stream_mode && SC.bvh_ok && ctx->tuning.bvh && !gi && !count;
+    const bool queue = bvh && ctx->tuning.level_queue;
     g_debug_sync = ctx->tuning.bvh == 3 ? 1 : 0;
     if (g_debug_sync) fprintf(stderr, "[frame] bvh_trace_shade %p tally %p checked %p shadow0 %p shadow1 %p heavy_closest %p shade_evicted %p resolve %p heavy_shadow %p\n",
                               (void *)bvh_trace_shade, (void *)bvh_trace_shade_tally, (void *)bvh_trace_shade_checked, (void *)bvh_trace_shadow<0, BVH_PLAIN>,
@@ -1319,7 +1365,7 @@ static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, fl
     A.s = (scene_args_p)ctx->d_scene;
     A.f = (frame_args_p)(ctx->d_frame_ring + slot);
     A.counters = ctx->d_counters;
-    FramePlan P{slot, n_items, vitems, lane_blocks, gi, count, exec_count, heavy, lean, wide, bvh, 0u, nullptr, last_resort};
+    FramePlan P{slot, n_items, vitems, lane_blocks, gi, count, exec_count, heavy, lean, wide, bvh, queue, 0u, nullptr, last_resort};
     rc = stream_mode ? launch_stream_levels(ctx, o, P, A, stream) : launch_lanes_pass(ctx, P, A, stream);
     if (rc == CRT_OK && stream_mode) rc = launch_stream_tail(ctx, P, A, stream);
     if (rc) return rc;
@@ -1678,7 +1724,8 @@ extern "C" int crt_describe_kernels(const crt_ctx *ctx, char *out, size_t size) 
         const bool lean = heavy && ctx->lean_ok && (A.plan_ok || A.plan_wide);
         const bool wide = lean && !A.plan_ok;
         const bool bvh = A.bvh_ok && ctx->tuning.bvh;
-        if (bvh) d = "level0=bvh_trace_shade;shadow0=bvh_trace_shadow<0u, 0>;levels=bvh_trace_shade";
+        if (bvh && ctx->tuning.level_queue) d = "level0=bvh_trace_level0<0>;shadow0=bvh_trace_shadow<0u, 0>;levels=bvh_trace_queue<0>";
+        else if (bvh) d = "level0=bvh_trace_shade;shadow0=bvh_trace_shadow<0u, 0>;levels=bvh_trace_shade";
         else d = std::string("level0=") + (!lean ? "stream_trace_shade<false>" : wide ? "stream_trace_shade_plan_wide" : "stream_trace_shade_plan");
         if (!bvh) d += std::string(";shadow0=") + (!lean ? "stream_trace_shadow<false>" : wide ? "stream_trace_shadow_plan_wide<0u>" : "stream_trace_shadow_plan<0u>");
         if (!bvh) d += std::string(";levels=") + (!heavy ? "stream_trace_shade<false>" : "heavy_trace_closest");

@@ -14,9 +14,16 @@
 //     156-167 take the first collected hit and replace it only by a strictly smaller distance;
 //   * shadow rays: occluded == some accepted hit with a finite distance lies within the light's distance (kernel_walk.h), whatever
 //     the order; hits beyond the light cannot count, so the walk ends at distance * (1 + 2^-16) (|d| = 1 up to 2 u);
-//   * closest-hit rays WITHOUT a verified finite hit (and walks the fixed-size stack cannot hold, and rays with non-finite
-//     coordinates) go to the reference-order kernels through the eviction list: an accepted hit with an infinite or NaN distance --
-//     invisible to any filter -- only matters for them (KDTree.cpp:75-86: a finite distance always replaces it).
+//   * a closest-hit ray WITHOUT a verified finite hit: the reference still gives it a hit if some triangle it tests is accepted with
+//     an infinite or NaN distance (KDTree.cpp:75-86: only a finite distance replaces the first collected hit).  Such a distance needs
+//     a computed d . n of zero (or so small that the quotient overflows): |d . n| < 4 u.  THE MISS CHECK (bvh_miss_step) looks for
+//     exactly those triangles: the same hierarchy, read through the boxes of everything the reference can reach a child's triangles
+//     through (the LINE of the ray against them: the reference's slab test knows no t >= 0) and through cones around the children's
+//     normals (a child none of whose normals is within 1e-4 rad of perpendicular to d is skipped); what is left is tested with
+//     the reference's triangle test and verified like any candidate.  Nothing found -- the all but certain outcome --: the ray is a
+//     miss.  Something found: the frame's overflow word is raised (with the guard word: larger queues would not help) and the
+//     queue-less reference-order kernel redoes the frame (crt_stats::fallback_frames), the same last resort as a queue overflow;
+//   * a ray with non-finite coordinates (the filter would pass everything) condemns the frame the same way.
 #pragma once
 
 #include "crt_bvh.h"
@@ -24,10 +31,32 @@
 #include "kernel_stream.h"
 #include "kernel_walk.h"
 
-constexpr uint32_t BVH_STACK = 32;   // entries per lane (LDS, one column per thread); a deeper walk is evicted.  A power of two: indices are masked
-static_assert((BVH_STACK & (BVH_STACK - 1u)) == 0, "BVH_STACK must be a power of two");
+// The walk's stack: the first BVH_LDS_STACK entries of a lane in LDS (one column per thread: 16 KB per workgroup, so that the level
+// kernels and the bulk shadow pass fit on a CU together), the rest -- rarely reached -- in a device buffer (FrameArgs::bvh_spill, one
+// column per thread of the largest grid).  SceneArgs::bvh_stack entries in all, sized by crt_create from the hierarchy's depth -- three
+// entries per inner node on a path is all a walk can push -- so that no walk outgrows it.
+constexpr uint32_t BVH_LDS_STACK = 16;
+struct BvhStack { uint32_t *lds; uint32_t *spill; uint32_t stride; };   // lds + threadIdx.x; spill + global thread; threads of the grid
+__device__ __forceinline__ void bvh_push(const BvhStack &S, uint32_t &sp, const uint32_t v) {
+    if (sp < BVH_LDS_STACK) S.lds[sp * BLOCK] = v;
+    else S.spill[(size_t)(sp - BVH_LDS_STACK) * S.stride] = v;
+    sp++;
+}
+__device__ __forceinline__ uint32_t bvh_pop(const BvhStack &S, uint32_t &sp) {
+    sp--;
+    return sp < BVH_LDS_STACK ? S.lds[sp * BLOCK] : S.spill[(size_t)(sp - BVH_LDS_STACK) * S.stride];
+}
+__device__ __forceinline__ BvhStack bvh_stack_of(const KernelArgs &A, uint32_t *stack_lds, const bool side) {
+    BvhStack S;
+    S.lds = stack_lds + threadIdx.x;
+    S.stride = gridDim.x * BLOCK;
+    S.spill = (side ? A.f->bvh_spill_side : A.f->bvh_spill) + (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    return S;
+}
 constexpr float BVH_WIDEN = 0x1p-20f;
-constexpr uint32_t BVH_REFILL = 40;  // a wave hands out new rays when at most this many of its lanes still walk
+// A wave looks after its free lanes -- output of the finished walks, new rays -- when BVH_BATCH of them have gathered (or none walks
+// any more): every such round costs the lanes that still walk a shading's worth of time, so the rounds must be few.
+constexpr uint32_t BVH_BATCH = 24;
 constexpr int BVH_STEPS = 4;         // walk steps between two looks at the lanes' states
 
 // Builds of the kernels: plain; tallying the tests they execute (crt_options::collect_counters == 2); bounds-checked (crt_tuning::bvh
@@ -187,12 +216,12 @@ __device__ __forceinline__ void bvh_walk_begin(BvhWalk &W, const float tmax) {
 // leaf.  false: the walk is over -- nothing left, the stack too small (give_up), or (SHADOW) an occluder found (have).
 template <bool SHADOW, int MODE>
 __device__ __forceinline__ bool bvh_step(const KernelArgs &A, const Ray &R, const bool primary, const float light_dist, const bool every_mesh,
-                                         BvhWalk &W, uint32_t *stack, uint32_t &nbox, uint32_t &ntri) {
+                                         BvhWalk &W, const BvhStack &stack, uint32_t &nbox, uint32_t &ntri) {
     if (MODE == BVH_TALLY) W.steps++;
     if (W.cur == BVH_EMPTY) {
         if (W.sp == 0) return false;
-        W.sp--;
-        W.cur = stack[(bvh_at<MODE>(A, W.sp, BVH_STACK, 8) & (BVH_STACK - 1u)) * BLOCK];
+        bvh_at<MODE>(A, W.sp - 1u, A.s->bvh_stack, 8);
+        W.cur = bvh_pop(stack, W.sp);
     }
     if (!(W.cur & BVH_LEAF)) {
         const float4 *N = A.s->bvh_nodes + 8 * (size_t)bvh_at<MODE>(A, W.cur, A.s->n_bvh_nodes, 9);
@@ -212,25 +241,32 @@ __device__ __forceinline__ bool bvh_step(const KernelArgs &A, const Ray &R, cons
         BVH_CSWAP(t0, c0, t1, c1) BVH_CSWAP(t2, c2, t3, c3) BVH_CSWAP(t0, c0, t2, c2) BVH_CSWAP(t1, c1, t3, c3) BVH_CSWAP(t1, c1, t2, c2)
 #undef BVH_CSWAP
         const uint32_t n_push = (c1 != BVH_EMPTY ? 1u : 0u) + (c2 != BVH_EMPTY ? 1u : 0u) + (c3 != BVH_EMPTY ? 1u : 0u);
-        if (W.sp + n_push > BVH_STACK) { W.give_up = true; return false; }
-        if (c3 != BVH_EMPTY) stack[((W.sp++) & (BVH_STACK - 1u)) * BLOCK] = c3;
-        if (c2 != BVH_EMPTY) stack[((W.sp++) & (BVH_STACK - 1u)) * BLOCK] = c2;
-        if (c1 != BVH_EMPTY) stack[((W.sp++) & (BVH_STACK - 1u)) * BLOCK] = c1;
+        if (W.sp + n_push > A.s->bvh_stack) { W.give_up = true; return false; }   // (cannot happen: the stack is sized by the depth)
+        if (c3 != BVH_EMPTY) bvh_push(stack, W.sp, c3);
+        if (c2 != BVH_EMPTY) bvh_push(stack, W.sp, c2);
+        if (c1 != BVH_EMPTY) bvh_push(stack, W.sp, c1);
         W.cur = c0;  // (BVH_EMPTY when the nearest slot holds a miss -- nothing passed, or a NaN distance out of order: the next step pops)
     } else {
-        // two triangles of the leaf per step, both fetched before either is tested; what is left of the leaf stays in `cur`
+        // up to TPS triangles of the leaf per step, all fetched before any is tested (one round trip); what is left of the leaf stays in `cur`
+        constexpr uint32_t TPS = 2u;   // (four per step for the closest-hit walks: measured, no faster, 30 registers more)
         const uint32_t left = (W.cur >> 24) & 0x7Fu;  // `left` more after the first
-        const uint32_t first = bvh_at<MODE>(A, W.cur & 0x00FFFFFFu, A.s->n_bvh_entries - (left ? 1u : 0u), 10);
-        const uint32_t second = first + (left ? 1u : 0u);
-        const float4 *T0 = A.s->bvh_tris + 3 * (size_t)first, *T1 = A.s->bvh_tris + 3 * (size_t)second;
-        const float4 a0 = T0[0], b0 = T0[1], c0 = T0[2], a1 = T1[0], b1 = T1[1], c1 = T1[2];
-        const uint32_t id0 = A.s->bvh_ids[first], id1 = A.s->bvh_ids[second];
-        W.cur = left >= 2u ? (BVH_LEAF | ((left - 2u) << 24) | (first + 2u)) : BVH_EMPTY;
+        const uint32_t n_here = left + 1u < TPS ? left + 1u : TPS;
+        const uint32_t first = bvh_at<MODE>(A, W.cur & 0x00FFFFFFu, A.s->n_bvh_entries - (n_here - 1u), 10);
+        float4 ta[TPS], tb[TPS], tc[TPS];
+        uint32_t tid[TPS];
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            if (k == 1 && !left) break;
-            const float4 &a = k ? a1 : a0, &b = k ? b1 : b0, &c = k ? c1 : c0;
-            const uint32_t id = k ? id1 : id0;
+        for (uint32_t k = 0; k < TPS; k++) {
+            const uint32_t e = first + (k < n_here ? k : n_here - 1u);   // (beyond the leaf: its last triangle again, not tested)
+            const float4 *T = A.s->bvh_tris + 3 * (size_t)e;
+            ta[k] = T[0]; tb[k] = T[1]; tc[k] = T[2];
+            tid[k] = A.s->bvh_ids[e];
+        }
+        W.cur = left >= TPS ? (BVH_LEAF | ((left - TPS) << 24) | (first + TPS)) : BVH_EMPTY;
+#pragma unroll
+        for (uint32_t k = 0; k < TPS; k++) {
+            if (k >= n_here) break;
+            const float4 &a = ta[k], &b = tb[k], &c = tc[k];
+            const uint32_t id = tid[k];
             if (SHADOW && (id & BVH_ID_REFRACTIVE) && !every_mesh) continue;  // AccelerationStructure.cpp:66-71 (not in the GI mode)
             float t, px, py, pz;
             if (MODE == BVH_TALLY) ntri++;
@@ -252,16 +288,90 @@ __device__ __forceinline__ bool bvh_step(const KernelArgs &A, const Ray &R, cons
     return true;
 }
 
-// a lane: wants a ray; walks it through the filter; nothing left to fetch; its walk has ended; walks it in the reference's own order
-enum : int { BVH_FETCH = 0, BVH_WALK = 1, BVH_OUT = 2, BVH_FINISHED = 3, BVH_EXACT = 4 };
+// a lane: wants a ray; walks it through the filter; nothing left to fetch; its walk has ended; checks the miss its walk ended with
+enum : int { BVH_FETCH = 0, BVH_WALK = 1, BVH_OUT = 2, BVH_FINISHED = 3, BVH_MISS_CHECK = 4, BVH_WAIT = 5 };   // (WAIT: for the record of the ray it has claimed, bvh_trace_queue)
 
-// Every ray of recursion level `gen`, persistent waves: a lane walks its ray through the filter; a ray WITHOUT a verified finite hit
-// (and one the filter gave up on) is then walked by the same lane in the reference's own order (kernel_lane.h: traversal_step, the
-// walk of the faithful kernels) -- only that walk sees an accepted hit with an infinite or NaN distance, which is the ray's hit when
-// there is no finite one (KDTree.cpp:75-86).  When enough lanes of the wave have finished, they shade together -- shootRay's
-// material dispatch (kernel_stream.h: shade_and_emit) -- and take the next rays of the level (consecutive ones: at level 0
-// neighbouring pixels of a tile).
+// The miss check's view of the ray: its whole LINE (the reference's slab test has no t >= 0, BoundingBox.h:85-108), with the reference's
+// notion of a parallel axis -- |d| < FLT_EPSILON is a containment test there (BoundingBox.h:90-93) -- kept as a superset: such a
+// component becomes +-1e-30, whose slab interval holds every moderate t exactly when the origin lies in the (slackened) slab.
+__device__ __forceinline__ void bvh_line_setup(const KernelArgs &A, const Ray &R, BvhRay &B) {
+    const float rho = (A.s->bvh_extent + fmaxf(fmaxf(fabsf(R.ox), fabsf(R.oy)), fabsf(R.oz))) * 0x1p-16f;
+    const float dx = fabsf(R.dx) < 2.0f * FLT_EPSILON ? copysignf(1e-30f, R.dx) : R.dx, dy = fabsf(R.dy) < 2.0f * FLT_EPSILON ? copysignf(1e-30f, R.dy) : R.dy,
+                dz = fabsf(R.dz) < 2.0f * FLT_EPSILON ? copysignf(1e-30f, R.dz) : R.dz;
+    B.ix = 1.0f / dx; B.iy = 1.0f / dy; B.iz = 1.0f / dz;
+    B.cpx = -((R.ox + rho) * B.ix); B.cmx = -((R.ox - rho) * B.ix);
+    B.cpy = -((R.oy + rho) * B.iy); B.cmy = -((R.oy - rho) * B.iy);
+    B.cpz = -((R.oz + rho) * B.iz); B.cmz = -((R.oz - rho) * B.iz);
+}
+// Does the line come within rho of the box?  (May say yes when it does not, never no when the reference's slab test passes.)
+__device__ __forceinline__ bool bvh_line_test(const BvhRay &B, const float lox, const float loy, const float loz, const float hix,
+                                              const float hiy, const float hiz) {
+    const float ax = __builtin_fmaf(lox, B.ix, B.cpx), bx = __builtin_fmaf(hix, B.ix, B.cmx);
+    const float ay = __builtin_fmaf(loy, B.iy, B.cpy), by = __builtin_fmaf(hiy, B.iy, B.cmy);
+    const float az = __builtin_fmaf(loz, B.iz, B.cpz), bz = __builtin_fmaf(hiz, B.iz, B.cmz);
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    return !(__builtin_fmaf(-fabsf(tn), BVH_WIDEN, tn) > __builtin_fmaf(fabsf(tf), BVH_WIDEN, tf));
+}
+
+// One step of the miss check (W.B holds the line): an inner node -- the children whose reach box the line passes and whose normal
+// cone comes within 1e-4 rad of perpendicular to d are kept -- or two triangles of a leaf: one that the reference's test accepts,
+// whatever its distance, and that the reference would have tested (bvh_verify) refutes the miss: W.give_up.  false: the check is over.
 template <int MODE>
+__device__ __forceinline__ bool bvh_miss_step(const KernelArgs &A, const Ray &R, const bool primary, BvhWalk &W, const BvhStack &stack, uint32_t &nbox,
+                                              uint32_t &ntri) {
+    if (MODE == BVH_TALLY) W.steps++;
+    if (W.cur == BVH_EMPTY) {
+        if (W.sp == 0) return false;
+        bvh_at<MODE>(A, W.sp - 1u, A.s->bvh_stack, 8);
+        W.cur = bvh_pop(stack, W.sp);
+    }
+    if (!(W.cur & BVH_LEAF)) {
+        const uint32_t node = bvh_at<MODE>(A, W.cur, A.s->n_bvh_nodes, 9);
+        const float4 *V = A.s->bvh_vnodes + 6 * (size_t)node, *C = A.s->bvh_cones + 4 * (size_t)node;
+        const float4 lx = V[0], ly = V[1], lz = V[2], hx = V[3], hy = V[4], hz = V[5];
+        const float4 cx = C[0], cy = C[1], cz = C[2], ck = C[3];
+        const float4 ch = A.s->bvh_nodes[8 * (size_t)node + 6];
+        if (MODE == BVH_TALLY) nbox += 4;
+        const uint32_t c0 = __float_as_uint(ch.x), c1 = __float_as_uint(ch.y), c2 = __float_as_uint(ch.z), c3 = __float_as_uint(ch.w);
+        const bool h0 = c0 != BVH_EMPTY && !(fabsf(__builtin_fmaf(cx.x, R.dx, __builtin_fmaf(cy.x, R.dy, cz.x * R.dz))) > ck.x) && bvh_line_test(W.B, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x);
+        const bool h1 = c1 != BVH_EMPTY && !(fabsf(__builtin_fmaf(cx.y, R.dx, __builtin_fmaf(cy.y, R.dy, cz.y * R.dz))) > ck.y) && bvh_line_test(W.B, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y);
+        const bool h2 = c2 != BVH_EMPTY && !(fabsf(__builtin_fmaf(cx.z, R.dx, __builtin_fmaf(cy.z, R.dy, cz.z * R.dz))) > ck.z) && bvh_line_test(W.B, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z);
+        const bool h3 = c3 != BVH_EMPTY && !(fabsf(__builtin_fmaf(cx.w, R.dx, __builtin_fmaf(cy.w, R.dy, cz.w * R.dz))) > ck.w) && bvh_line_test(W.B, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w);
+        const uint32_t n_hit = (h0 ? 1u : 0u) + (h1 ? 1u : 0u) + (h2 ? 1u : 0u) + (h3 ? 1u : 0u);
+        if (W.sp + n_hit > A.s->bvh_stack) { W.give_up = true; return false; }   // (cannot happen: the stack is sized by the depth)
+        W.cur = BVH_EMPTY;
+        if (h0) { W.cur = c0; }
+        if (h1) { if (W.cur != BVH_EMPTY) bvh_push(stack, W.sp, W.cur); W.cur = c1; }
+        if (h2) { if (W.cur != BVH_EMPTY) bvh_push(stack, W.sp, W.cur); W.cur = c2; }
+        if (h3) { if (W.cur != BVH_EMPTY) bvh_push(stack, W.sp, W.cur); W.cur = c3; }
+    } else {
+        const uint32_t left = (W.cur >> 24) & 0x7Fu;
+        const uint32_t first = bvh_at<MODE>(A, W.cur & 0x00FFFFFFu, A.s->n_bvh_entries - (left ? 1u : 0u), 10);
+        const uint32_t second = first + (left ? 1u : 0u);
+        const float4 *T0 = A.s->bvh_tris + 3 * (size_t)first, *T1 = A.s->bvh_tris + 3 * (size_t)second;
+        const float4 a0 = T0[0], b0 = T0[1], c0 = T0[2], a1 = T1[0], b1 = T1[1], c1 = T1[2];
+        const uint32_t id0 = A.s->bvh_ids[first], id1 = A.s->bvh_ids[second];
+        W.cur = left >= 2u ? (BVH_LEAF | ((left - 2u) << 24) | (first + 2u)) : BVH_EMPTY;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            if (k == 1 && !left) break;
+            const float4 &a = k ? a1 : a0, &b = k ? b1 : b0, &c = k ? c1 : c0;
+            float t, px, py, pz;
+            if (MODE == BVH_TALLY) ntri++;
+            if (!bvh_triangle(R, primary, a, b, c, t, px, py, pz)) continue;
+            uint32_t mesh, k2, k3 = NONE;
+            if (bvh_verify<MODE>(A, R, (k ? id1 : id0) & ~BVH_ID_REFRACTIVE, a, b, c, mesh, W.cache_mesh, W.cache_k2, k2, k3, nbox)) { W.give_up = true; return false; }
+        }
+    }
+    return true;
+}
+
+// Every ray of recursion level `gen`, persistent waves: a lane walks its ray through the filter; a ray that ends WITHOUT a verified
+// finite hit goes through the miss check (above) in the same lane.  When enough lanes of the wave have finished, they shade together
+// -- shootRay's material dispatch (kernel_stream.h: shade_and_emit) -- and take the next rays of the level (consecutive ones: at
+// level 0 neighbouring pixels of a tile).
+template <int MODE, bool LQ = false>   // LQ: level 0 of a frame whose deeper levels are bvh_trace_queue's: the children go to the level queue
 __device__ __forceinline__ void bvh_shade_level(const KernelArgs &A, const uint32_t gen, uint32_t *stack_lds) {
     if (A.wave_prio) __builtin_amdgcn_s_setprio(3);
     const uint32_t lane = threadIdx.x & 63u;
@@ -270,24 +380,26 @@ __device__ __forceinline__ void bvh_shade_level(const KernelArgs &A, const uint3
     const uint32_t node_base = stream_level_base(A, gen);
     const uint32_t child_base = node_base + count;
     const float4 *in_q = A.f->s_rayq[gen & 1u];
-    uint32_t *stack = stack_lds + threadIdx.x;
+    const BvhStack stack = bvh_stack_of(A, stack_lds, false);
     const bool primary = gen == 0;
     uint32_t nbox = 0, ntri = 0;
     Ray R;
     R.ox = R.oy = R.oz = R.dx = R.dy = R.dz = R.ix = R.iy = R.iz = 0; R.parmask = 0;
     BvhWalk W;
     bvh_walk_begin(W, INFINITY);
-    LaneWalk L;
-    traversal_begin(L, A.s->top_root);
-    L.rtype = primary ? RAY_PRIMARY : RAY_REFLECTION;   // (reflection and refraction rays behave alike in the walk)
-    L.bt = 0; L.btri = 0; L.bmesh = 0; L.mt = 0; L.mtri = 0; L.light_dist = 0;
     int state = BVH_FETCH;
     uint32_t r = 0, spins = 0;
     for (;;) {
         if (MODE == BVH_CHECKED && ++spins > (1u << 22)) { bvh_at<MODE>(A, spins, 0u, 15); break; }   // (a loop that does not end: say so and leave)
-        if (__ballot(state == BVH_FETCH || state == BVH_FINISHED) && (uint32_t)__popcll(__ballot(state == BVH_WALK || state == BVH_EXACT)) <= BVH_REFILL) {
+        const uint32_t n_free = (uint32_t)__popcll(__ballot(state == BVH_FETCH || state == BVH_FINISHED));
+        if (n_free >= BVH_BATCH || (n_free && !__ballot(state == BVH_WALK || state == BVH_MISS_CHECK))) {
             if (state == BVH_FINISHED) {
-                shade_and_emit<false, false>(A, gen, r, node_base, child_base, R, W.have, W.best, W.btri, W.bmesh, nullptr, lane);
+                if (MODE == BVH_TALLY && gen < 10u) {   // diagnostics per level: the longest walk, all steps / 16, walks
+                    uint32_t *dg = A.f->s_counts + SC_BVH_DIAG + 48 + 3 * gen;
+                    atomicMax(dg + 0, W.steps); atomicAdd(dg + 1, W.steps); atomicAdd(dg + 2, 1u);
+                }
+                if (W.give_up) { A.f->s_counts[SC_GUARD] = 1; A.f->s_counts[SC_OVERFLOW] = 1; }   // a ray the filter cannot take, a miss refuted: the frame goes to the last resort
+                shade_and_emit<false, false, LQ>(A, gen, r, node_base, child_base, R, W.have, W.best, W.btri, W.bmesh, nullptr, lane);
                 state = BVH_FETCH;
             }
             // one fetch per free lane and round (a lane whose ray needs no walk here -- an uncovered pixel -- asks again next round): no
@@ -314,7 +426,7 @@ __device__ __forceinline__ void bvh_shade_level(const KernelArgs &A, const uint3
                     if (walk) {
                         bvh_walk_begin(W, INFINITY);
                         if (bvh_ray_setup(A, R, W.B)) state = BVH_WALK;
-                        else { traversal_begin(L, A.s->top_root); state = BVH_EXACT; }
+                        else { W.give_up = true; state = BVH_FINISHED; }
                     }
                 }
             }
@@ -323,31 +435,153 @@ __device__ __forceinline__ void bvh_shade_level(const KernelArgs &A, const uint3
         if (state == BVH_WALK) {
             for (int it = 0; it < BVH_STEPS; ++it)
                 if (state == BVH_WALK && !bvh_step<false, MODE>(A, R, primary, 0.0f, false, W, stack, nbox, ntri)) {
-                    if (W.have && !W.give_up) state = BVH_FINISHED;
-                    else { traversal_begin(L, A.s->top_root); state = BVH_EXACT; }
+                    if (W.have || W.give_up) state = BVH_FINISHED;
+                    else { W.cur = 0; W.sp = 0; W.cache_mesh = NONE; W.cache_k2 = NONE; bvh_line_setup(A, R, W.B); state = BVH_MISS_CHECK; }
                 }
         }
-        if (state == BVH_EXACT) {
-            for (int it = 0; it < 2 * BVH_STEPS; ++it)
-                if (state == BVH_EXACT && !traversal_step<false>(L, R, A, nullptr)) {
-                    W.have = L.have; W.best = L.bt; W.btri = L.btri; W.bmesh = L.bmesh;
-                    state = BVH_FINISHED;
-                }
+        if (state == BVH_MISS_CHECK) {
+            for (int it = 0; it < BVH_STEPS; ++it)
+                if (state == BVH_MISS_CHECK && !bvh_miss_step<MODE>(A, R, primary, W, stack, nbox, ntri)) state = BVH_FINISHED;
         }
     }
     exec_counters_flush(A, nbox, ntri, lane);
 }
 __global__ __launch_bounds__(BLOCK) void bvh_trace_shade(const KernelArgs A, const uint32_t gen) {
-    __shared__ uint32_t stack_lds[BVH_STACK * BLOCK];
+    __shared__ uint32_t stack_lds[BVH_LDS_STACK * BLOCK];
     bvh_shade_level<BVH_PLAIN>(A, gen, stack_lds);
 }
 __global__ __launch_bounds__(BLOCK) void bvh_trace_shade_tally(const KernelArgs A, const uint32_t gen) {
-    __shared__ uint32_t stack_lds[BVH_STACK * BLOCK];
+    __shared__ uint32_t stack_lds[BVH_LDS_STACK * BLOCK];
     bvh_shade_level<BVH_TALLY>(A, gen, stack_lds);
 }
 __global__ __launch_bounds__(BLOCK) void bvh_trace_shade_checked(const KernelArgs A, const uint32_t gen) {
-    __shared__ uint32_t stack_lds[BVH_STACK * BLOCK];
+    __shared__ uint32_t stack_lds[BVH_LDS_STACK * BLOCK];
     bvh_shade_level<BVH_CHECKED>(A, gen, stack_lds);
+}
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void bvh_trace_level0(const KernelArgs A) {
+    __shared__ uint32_t stack_lds[BVH_LDS_STACK * BLOCK];
+    bvh_shade_level<MODE, true>(A, 0u, stack_lds);
+}
+
+// EVERY ray below level 0, in one launch (crt_tuning::level_queue).  Launched level by level a frame waits, at each of its levels,
+// for that level's longest walk -- eight times 0.2 - 0.3 ms on the benchmark frame for walks that average a tenth of it.  Here a lane
+// takes the next ray of the level queue (kernel_stream.h: lq_store_ray), walks it, shades it, appends its children to the same queue
+// and takes the next one: a pixel's chain of rays never waits for another pixel's.
+//   rays are RESERVED (SC_LQ_TAIL, when their parent is shaded), CLAIMED (SC_LQ_HEAD, by the lane that will walk them) and counted
+//   DONE (SC_LQ_DONE, after their own children are reserved); entry k owns ray-tree node count0 + k.
+//   A lane that has claimed an entry polls its record until every granule carries the frame's tag -- the record may be written by a
+//   workgroup on another XCD while this one runs: agent-scope stores and loads, no fence (Guideline 16, R2).
+//   The end: done == tail, read in that order (done never exceeds tail and both only grow: equal values read that way were equal at
+//   the second read, and once equal nothing is in flight that could reserve more).  Every wave reaches it: a wave only waits for
+//   records of rays reserved by waves that are running (a reserved ray's parent was walked by a resident wave, which writes the
+//   record before it does anything else), the overflow word ends every wait, and a loop that turns 2^20 times raises it.
+template <int MODE>
+__device__ __forceinline__ void bvh_queue_levels(const KernelArgs &A, uint32_t *stack_lds) {
+    if (A.wave_prio) __builtin_amdgcn_s_setprio(3);
+    const uint32_t lane = threadIdx.x & 63u;
+    if (A.f->s_counts[SC_OVERFLOW]) return;
+    typedef uint32_t __attribute__((address_space(1))) *gu32;
+    const gu32 tail_p = (gu32)(A.f->s_lq_words + LQ_TAIL), head_p = (gu32)(A.f->s_lq_words + LQ_HEAD), done_p = (gu32)(A.f->s_lq_words + LQ_DONE),
+               ovf_p = (gu32)(A.f->s_lq_words + LQ_ABORT);
+    const uint32_t count0 = stream_level_count(A, 0);
+    const BvhStack stack = bvh_stack_of(A, stack_lds, false);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t nbox = 0, ntri = 0;
+    Ray R;
+    R.ox = R.oy = R.oz = R.dx = R.dy = R.dz = R.ix = R.iy = R.iz = 0; R.parmask = 0;
+    BvhWalk W;
+    bvh_walk_begin(W, INFINITY);
+    int state = BVH_FETCH;
+    uint32_t r = 0, gen = 1, spins = 0, idle_polls = 0;
+    for (;;) {
+        if (++spins > (1u << 20)) { A.f->s_counts[SC_GUARD] = 1; A.f->s_counts[SC_OVERFLOW] = 1; __hip_atomic_store(ovf_p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        const unsigned long long fin = __ballot(state == BVH_FINISHED), idle = __ballot(state == BVH_FETCH);
+        const bool walking = __ballot(state == BVH_WALK || state == BVH_MISS_CHECK) != 0;
+        // a round of housekeeping -- shading, counting, claiming -- costs the lanes that walk two round trips to the queue's words: when
+        // enough walks have finished, when nothing (or little) walks, and otherwise, for the idle lanes' sake, every sixteenth turn
+        const uint32_t n_walk = (uint32_t)__popcll(__ballot(state == BVH_WALK || state == BVH_MISS_CHECK));
+        if ((uint32_t)__popcll(fin) >= BVH_BATCH || !walking || (fin && n_walk <= 8u) || ((fin | idle) && (spins & A.bundle) == 0u)) {
+            if (state == BVH_FINISHED) {
+                if (MODE == BVH_TALLY && gen < 10u) {
+                    uint32_t *dg = A.f->s_counts + SC_BVH_DIAG + 48 + 3 * gen;
+                    atomicMax(dg + 0, W.steps); atomicAdd(dg + 1, W.steps); atomicAdd(dg + 2, 1u);
+                }
+                if (W.give_up) { A.f->s_counts[SC_GUARD] = 1; A.f->s_counts[SC_OVERFLOW] = 1; __hip_atomic_store(ovf_p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                shade_and_emit<false, false, true>(A, gen, r, count0, count0, R, W.have, W.best, W.btri, W.bmesh, nullptr, lane);
+                state = BVH_FETCH;
+            }
+            // (the children's reservations above have returned: the finished rays may count as done)
+            uint32_t t = 0, h = 0;
+            if (lane == 0) {
+                if (fin) atomicAdd(A.f->s_lq_words + LQ_DONE, (uint32_t)__popcll(fin));
+                t = __hip_atomic_load(tail_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                h = __hip_atomic_load(head_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            t = __builtin_amdgcn_readfirstlane(t); h = __builtin_amdgcn_readfirstlane(h);
+            const unsigned long long want = __ballot(state == BVH_FETCH);
+            const uint32_t n_want = (uint32_t)__popcll(want), avail = t > h ? t - h : 0u;
+            const uint32_t take = n_want < avail ? n_want : avail;
+            if (take) {   // (wave-uniform)
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(A.f->s_lq_words + LQ_HEAD, take);
+                base = __builtin_amdgcn_readfirstlane(base);
+                const uint32_t rank = (uint32_t)__popcll(want & below);
+                if (state == BVH_FETCH && rank < take) { r = base + rank; state = BVH_WAIT; }
+                idle_polls = 0;
+            } else if (n_want || __ballot(state == BVH_WAIT)) {
+                // nothing to claim: is it the end?
+                uint32_t d = 0, t2 = 0, ovf = 0;
+                if (lane == 0) {
+                    d = __hip_atomic_load(done_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // done BEFORE tail (see above)
+                    t2 = __hip_atomic_load(tail_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ovf = __hip_atomic_load(ovf_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                d = __builtin_amdgcn_readfirstlane(d); t2 = __builtin_amdgcn_readfirstlane(t2); ovf = __builtin_amdgcn_readfirstlane(ovf);
+                // nothing is in flight and nothing can be reserved any more (or the frame is lost): whoever has no ray leaves
+                if ((ovf || d == t2) && (state == BVH_FETCH || ovf || (state == BVH_WAIT && r >= t2))) state = BVH_OUT;
+                // A wave without a single ray that keeps finding nothing to claim leaves too: the waves that hold the rays in flight
+                // claim what those rays reserve (a wave that has just reserved rays looks for work at once), and a frame's levels shrink:
+                // most waves are only needed for the first of them -- and every idle wave is one more poller of the queue's words.
+                if (!__ballot(state != BVH_FETCH && state != BVH_OUT) && ++idle_polls >= 4u) state = BVH_OUT;
+            }
+        }
+        if (state == BVH_WAIT) {   // is my ray there?
+            uint32_t level = 0;
+            if (lq_load_ray(A, r, R.ox, R.oy, R.oz, R.dx, R.dy, R.dz, level)) {
+                gen = level;
+                normalize3(R.dx, R.dy, R.dz);  // shootRay entry (RayTracer.cpp:420)
+                ray_prepare(R);
+                bvh_walk_begin(W, INFINITY);
+                if (bvh_ray_setup(A, R, W.B)) state = BVH_WALK;
+                else { W.give_up = true; state = BVH_FINISHED; }
+            }
+        }
+        if (!__ballot(state != BVH_OUT)) break;
+        if (!__ballot(state == BVH_WALK || state == BVH_MISS_CHECK || state == BVH_FINISHED)) {   // only waiting: poll gently, and ever more gently
+            __builtin_amdgcn_s_sleep(127);
+            if (idle_polls >= 1u) __builtin_amdgcn_s_sleep(127);
+            if (idle_polls >= 2u) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
+        }
+        if (state == BVH_WALK) {
+            for (int it = 0; it < BVH_STEPS; ++it)
+                if (state == BVH_WALK && !bvh_step<false, MODE>(A, R, false, 0.0f, false, W, stack, nbox, ntri)) {
+                    if (W.have || W.give_up) state = BVH_FINISHED;
+                    else { W.cur = 0; W.sp = 0; W.cache_mesh = NONE; W.cache_k2 = NONE; bvh_line_setup(A, R, W.B); state = BVH_MISS_CHECK; }
+                }
+        }
+        if (state == BVH_MISS_CHECK) {
+            for (int it = 0; it < BVH_STEPS; ++it)
+                if (state == BVH_MISS_CHECK && !bvh_miss_step<MODE>(A, R, false, W, stack, nbox, ntri)) state = BVH_FINISHED;
+        }
+    }
+    exec_counters_flush(A, nbox, ntri, lane);
+}
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void bvh_trace_queue(const KernelArgs A) {
+    __shared__ uint32_t stack_lds[BVH_LDS_STACK * BLOCK];
+    bvh_queue_levels<MODE>(A, stack_lds);
 }
 
 // The shadow rays [first, first + total) of the queue (pass 0: level 0's fixed slots; pass 1: the deeper levels'); `cursor` hands them
@@ -356,23 +590,20 @@ template <int MODE>
 __device__ __forceinline__ void bvh_shadow_rays(const KernelArgs &A, const uint32_t first, const uint32_t total, uint32_t *cursor, uint32_t *stack_lds) {
     const uint32_t lane = threadIdx.x & 63u;
     if (A.f->s_counts[SC_OVERFLOW]) return;
-    uint32_t *stack = stack_lds + threadIdx.x;
+    const BvhStack stack = bvh_stack_of(A, stack_lds, true);   // (the bulk pass runs beside the level kernels: a region of its own)
     const bool every_mesh = A.f->use_gi != 0;
     uint32_t nbox = 0, ntri = 0;
     Ray R;
     R.ox = R.oy = R.oz = R.dx = R.dy = R.dz = R.ix = R.iy = R.iz = 0; R.parmask = 0;
     BvhWalk W;
     bvh_walk_begin(W, INFINITY);
-    LaneWalk L;   // (a walk the filter gave up on is redone in the reference's order, as in bvh_shade_level)
-    traversal_begin(L, A.s->top_root);
-    L.rtype = RAY_SHADOW;
-    L.bt = 0; L.btri = 0; L.bmesh = 0; L.mt = 0; L.mtri = 0; L.light_dist = 0;
     float light_dist = 0;
     int state = BVH_FETCH;
     uint32_t r = 0, spins = 0;
     for (;;) {
         if (MODE == BVH_CHECKED && ++spins > (1u << 22)) { bvh_at<MODE>(A, spins, 0u, 15); break; }   // (a loop that does not end: say so and leave)
-        if (__ballot(state == BVH_FETCH || state == BVH_FINISHED) && (uint32_t)__popcll(__ballot(state == BVH_WALK || state == BVH_EXACT)) <= BVH_REFILL) {
+        const uint32_t n_free = (uint32_t)__popcll(__ballot(state == BVH_FETCH || state == BVH_FINISHED));
+        if (n_free >= BVH_BATCH || (n_free && !__ballot(state == BVH_WALK))) {
             if (state == BVH_FINISHED) {
                 if (MODE == BVH_TALLY) {   // diagnostics: the longest walk of the pass, which ray it was, all steps, walks of 1024 steps and more
                     uint32_t *dg = A.f->s_counts + SC_BVH_DIAG + 40;
@@ -380,6 +611,7 @@ __device__ __forceinline__ void bvh_shadow_rays(const KernelArgs &A, const uint3
                     atomicAdd(dg + 2, W.steps >> 4);
                     if (W.steps >= 1024u) atomicAdd(dg + 3, 1u);
                 }
+                if (W.give_up) { A.f->s_counts[SC_GUARD] = 1; A.f->s_counts[SC_OVERFLOW] = 1; }   // a ray the filter cannot take: the frame goes to the last resort
                 A.f->s_occluded[r] = W.have ? 1 : 0;
                 state = BVH_FETCH;
             }
@@ -401,7 +633,7 @@ __device__ __forceinline__ void bvh_shadow_rays(const KernelArgs &A, const uint3
                         // an occluding hit has length(o + d t - o) <= light_dist with |d| = 1 up to two unit roundoffs: t <= light_dist (1 + 2^-16) (NaN: no bound)
                         bvh_walk_begin(W, light_dist * (1.0f + 0x1p-16f));
                         if (bvh_ray_setup(A, R, W.B)) state = BVH_WALK;
-                        else { traversal_begin(L, A.s->top_root); L.light_dist = light_dist; state = BVH_EXACT; }
+                        else { W.give_up = true; state = BVH_FINISHED; }
                     }
                 }
             }
@@ -409,22 +641,16 @@ __device__ __forceinline__ void bvh_shadow_rays(const KernelArgs &A, const uint3
         if (!__ballot(state != BVH_OUT)) break;
         if (state == BVH_WALK) {
             for (int it = 0; it < BVH_STEPS; ++it)
-                if (state == BVH_WALK && !bvh_step<true, MODE>(A, R, false, light_dist, every_mesh, W, stack, nbox, ntri)) {
-                    if (!W.give_up) state = BVH_FINISHED;
-                    else { traversal_begin(L, A.s->top_root); L.light_dist = light_dist; state = BVH_EXACT; }
-                }
-        }
-        if (state == BVH_EXACT) {
-            for (int it = 0; it < 2 * BVH_STEPS; ++it)
-                if (state == BVH_EXACT && !traversal_step<false>(L, R, A, nullptr)) { W.have = L.occluded; state = BVH_FINISHED; }
+                if (state == BVH_WALK && !bvh_step<true, MODE>(A, R, false, light_dist, every_mesh, W, stack, nbox, ntri)) state = BVH_FINISHED;
         }
     }
     exec_counters_flush(A, nbox, ntri, lane);
 }
 template <uint32_t pass, int MODE>  // (the passes are kernels of their own in a profile)
 __global__ __launch_bounds__(BLOCK) void bvh_trace_shadow(const KernelArgs A) {
-    __shared__ uint32_t stack_lds[BVH_STACK * BLOCK];
+    __shared__ uint32_t stack_lds[BVH_LDS_STACK * BLOCK];
     const uint32_t split = A.f->s_counts[SC_SHADOW_SPLIT];
     bvh_shadow_rays<MODE>(A, pass == 0 ? 0u : split, pass == 0 ? split : A.f->s_counts[SC_SHADOW] - split,
                           A.f->s_counts + (pass == 0 ? SC_SHADOW_FETCH : SC_SHADOW_FETCH2), stack_lds);
 }
+

@@ -103,9 +103,12 @@ struct SceneArgs {
     // The candidate filter (crt_bvh.h, kernel_bvh.h): a 4-wide hierarchy over the triangles grown by their acceptance margins, and the
     // inverse maps its hits are verified with against the reference's trees
     uint32_t bvh_ok;              // the filter exists (crt_create: every triangle's margin is bounded, the reference's boxes are nested)
+    uint32_t bvh_stack;           // stack entries a walk can need: 3 x (inner nodes on the longest path) + 1
     float bvh_extent;             // largest absolute coordinate of any of its boxes
     float bvh_overlap_eps;        // slack of the box-overlap predicate of bvh_leaf_walk (kernel_bvh.h)
     const float4 *bvh_nodes;      // 8 x float4 per node: child boxes lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4], children[4], pad
+    const float4 *bvh_vnodes;     // 6 x float4 per node: the children's reach boxes (crt_bvh.h: vnodes), for the miss check
+    const float4 *bvh_cones;      // 4 x float4 per node: the children's normal cones (crt_bvh.h: cones)
     const float4 *bvh_tris;       // 3 x float4 per filter entry {v0,nx} {v1,ny} {v2,nz}, in the filter's leaf order
     const uint32_t *bvh_ids;      // per filter entry: triangle | BVH_ID_REFRACTIVE
     const uint32_t *tri_mesh;     // per triangle: its mesh | BVH_TRI_WALK (listed by too many leaves for a list: verified by the pruned tree walk)
@@ -143,6 +146,10 @@ struct FrameArgs {
     float4 *s_hits;               // closest-hit records of evicted rays: {t, triangle, mesh, have}
     float4 *s_hits_all;           // ... of every ray of the current level, by ray index, when the per-lane walk leaves the shading to stream_shade_all
                                   //     (w: 0 / 1 no hit / hit, 2 evicted -- stream_shade_evicted shades it --, 3 not a ray)
+    unsigned long long *s_lq;     // kernel_bvh.h / kernel_stream.h: the level queue, 8 granules per ray
+    uint32_t s_lq_cap, lq_epoch;  // its capacity in rays; this frame's tag (never 0, never a tag the buffer may still hold)
+    uint32_t *s_lq_words;         // its counters (kernel_stream.h: LQ_*), zeroed before every frame
+    uint32_t *bvh_spill, *bvh_spill_side;  // kernel_bvh.h: what a walk's stack holds beyond its LDS part, one column per thread of the largest grid (level kernels / shadow passes)
     uint32_t heavy_level_threshold; // a recursion level with fewer rays than this goes to heavy_trace whole
     uint32_t fixed0;              // level 0's shadow rays go to fixed, tile-ordered slots (kernel_stream.h: level0_shadow_place)
     uint32_t use_gi, gi_samples, rays_per_pixel, gi_seed;  // crt_options: the GI / multi-sample mode (kernel_stream.h, kernel_lane.h, gi_random.h)

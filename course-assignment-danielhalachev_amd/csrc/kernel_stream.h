@@ -45,6 +45,10 @@ enum : int { SC_COUNT = 0, SC_FETCH = MAX_GENERATIONS, SC_HEAVY = 2 * MAX_GENERA
              SC_WORDS,
              SC_HEAVY_DIAG = 384,  // diagnostics of a collect_counters == 2 render (kernel_heavy.h): 8 words closest-hit walks, 8 words shadow walks
              SC_ALLOC_WORDS = 512 };
+// kernel_bvh.h, the level queue's words (FrameArgs::s_lq_words): rays reserved / claimed / finished, and a copy of the overflow word for
+// the waves that wait -- 64 KB apart: hundreds of waves poll them, and words that share a memory channel share its request rate (with
+// each other and with the bulk shadow pass's cursor, were they in the counter block)
+enum : int { LQ_TAIL = 0, LQ_HEAD = 16384, LQ_DONE = 32768, LQ_ABORT = 49152, LQ_WORDS = 65536 };
 static_assert(SC_WORDS <= SC_HEAVY_DIAG, "counter block too small");
 
 static_assert(SC_OVERFLOW == SC_OVERFLOW_WORD, "kernel_common.h SC_OVERFLOW_WORD must match");
@@ -277,10 +281,41 @@ __device__ __forceinline__ void store_child_ray(float4 *q, const size_t index, c
     q[2 * index + 1] = make_float4(dx, dy, dz, __uint_as_float(node));
 }
 
+// The LEVEL QUEUE (kernel_bvh.h: bvh_trace_queue): every ray below level 0 in ONE queue, whatever its level; a ray is consumed by
+// another workgroup -- possibly on another XCD, whose L2 is not coherent with the producer's -- while the launch that produced it
+// still runs.  A record is therefore eight 8-byte granules {tag = the frame's epoch, value}, each ONE agent-scope (write-through)
+// store: the data is its own flag, a consumer re-reads a record with agent-scope loads until every tag is the frame's epoch
+// (/opt/skills/guides/cdna_hip_programming.md, Guideline 16, R2).  Values: origin x y z, level, direction x y z, spare.
+typedef unsigned long long __attribute__((address_space(1))) *lq_ptr;
+__device__ __forceinline__ void lq_store_ray(const KernelArgs &A, const uint32_t index, const float ox, const float oy, const float oz,
+                                             const float dx, const float dy, const float dz, const uint32_t level) {
+    lq_ptr g = (lq_ptr)(A.f->s_lq + 8 * (size_t)index);
+    const unsigned long long tag = (unsigned long long)A.f->lq_epoch << 32;
+    const uint32_t v[8] = {__float_as_uint(ox), __float_as_uint(oy), __float_as_uint(oz), level, __float_as_uint(dx), __float_as_uint(dy), __float_as_uint(dz), 0u};
+#pragma unroll
+    for (int k = 0; k < 8; k++) __hip_atomic_store(g + k, tag | v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// false: not (yet) there (one granule is looked at first: a lane that waits for its record asks for eight bytes per look, not sixty-four)
+__device__ __forceinline__ bool lq_load_ray(const KernelArgs &A, const uint32_t index, float &ox, float &oy, float &oz, float &dx, float &dy,
+                                            float &dz, uint32_t &level) {
+    lq_ptr g = (lq_ptr)(A.f->s_lq + 8 * (size_t)index);
+    if ((uint32_t)(__hip_atomic_load(g + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) != A.f->lq_epoch) return false;
+    unsigned long long x[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) x[k] = __hip_atomic_load(g + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 8; k++) ok = ok && (uint32_t)(x[k] >> 32) == A.f->lq_epoch;
+    ox = __uint_as_float((uint32_t)x[0]); oy = __uint_as_float((uint32_t)x[1]); oz = __uint_as_float((uint32_t)x[2]); level = (uint32_t)x[3];
+    dx = __uint_as_float((uint32_t)x[4]); dy = __uint_as_float((uint32_t)x[5]); dz = __uint_as_float((uint32_t)x[6]);
+    return ok;
+}
+
 // shade_hit + the per-level queues: ray `r` of level `gen` writes node node_base + r, its children are appended to the
 // queue of level gen+1 (child k of that queue owns node child_base + k).  Allocations are aggregated over the calling lanes:
 // the reflection rays, then the transmission rays, then -- GI mode -- gi_samples consecutive rays per diffuse hit.
-template <bool COUNT, bool GI>
+// LQ: the children go to the level queue instead (entry k of it owns node child_base + k, whatever its level).
+template <bool COUNT, bool GI, bool LQ = false>
 __device__ __forceinline__ void shade_and_emit(const KernelArgs &A, const uint32_t gen, const uint32_t r, const uint32_t node_base,
                                        const uint32_t child_base, const Ray &R, const bool have, const float bt,
                                        const uint32_t btri, const uint32_t bmesh, uint32_t *cnt, const uint32_t lane,
@@ -290,7 +325,8 @@ __device__ __forceinline__ void shade_and_emit(const KernelArgs &A, const uint32
     constexpr bool gi_mode = GI;
     if (E.reflect || (GI && E.gi)) {
         float4 *out_q = A.f->s_rayq[(gen + 1u) & 1u];
-        uint32_t *out_count = A.f->s_counts + SC_COUNT + gen + 1;
+        uint32_t *out_count = LQ ? A.f->s_lq_words + LQ_TAIL : A.f->s_counts + SC_COUNT + gen + 1;
+        const uint32_t out_cap = LQ ? A.f->s_lq_cap : A.f->s_ray_cap;
         // this invocation's key: the children's keys and the sample directions' random numbers derive from it
         uint32_t key = 0;
         if constexpr (GI) key = gen == 0 ? level0_key(A, level0_decode<true>(A, r)) : __float_as_uint(A.f->s_rayq[gen & 1u][2 * (size_t)r].w);
@@ -299,17 +335,24 @@ __device__ __forceinline__ void shade_and_emit(const KernelArgs &A, const uint32
         const unsigned long long below = (1ull << lane) - 1ull;
         const uint32_t n1 = (uint32_t)__popcll(m1), n2 = (uint32_t)__popcll(m2), n3 = GI ? (uint32_t)__popcll(m3) * A.f->gi_samples : 0u;
         uint32_t base = 0;
-        if ((m0 & below) == 0) base = atomicAdd(out_count, n1 + n2 + n3);
+        if ((m0 & below) == 0) {
+            base = atomicAdd(out_count, n1 + n2 + n3);
+            if (LQ) atomicAdd(A.f->s_counts + SC_COUNT + gen + 1, n1 + n2 + n3);   // (the levels' sizes: what the queues are sized by)
+        }
         base = __shfl(base, __ffsll((long long)m0) - 1);
-        if ((uint64_t)base + n1 + n2 + n3 > A.f->s_ray_cap || (uint64_t)child_base + base + n1 + n2 + n3 > A.f->s_node_cap) {
+        if ((uint64_t)base + n1 + n2 + n3 > out_cap || (uint64_t)child_base + base + n1 + n2 + n3 > A.f->s_node_cap) {
+            // (level queue: entries were reserved that will never be written; the waves waiting for them watch this word, from other XCDs too)
+            if (LQ) __hip_atomic_store((uint32_t __attribute__((address_space(1))) *)(A.f->s_lq_words + LQ_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             A.f->s_counts[SC_OVERFLOW] = 1;
         } else if (E.reflect) {
             const uint32_t i1 = base + (uint32_t)__popcll(m1 & below);
-            store_child_ray(out_q, i1, E.rox, E.roy, E.roz, E.rdx, E.rdy, E.rdz, gi_mode ? crt_gi_child_key(key, 0u) : gen + 1u, child_base + i1);
+            if constexpr (LQ) lq_store_ray(A, i1, E.rox, E.roy, E.roz, E.rdx, E.rdy, E.rdz, gen + 1u);
+            else store_child_ray(out_q, i1, E.rox, E.roy, E.roz, E.rdx, E.rdy, E.rdz, gi_mode ? crt_gi_child_key(key, 0u) : gen + 1u, child_base + i1);
             E.N.a = child_base + i1;
             if (E.transmit) {
                 const uint32_t i2 = base + n1 + (uint32_t)__popcll(m2 & below);
-                store_child_ray(out_q, i2, E.tox, E.toy, E.toz, E.tdx, E.tdy, E.tdz, gi_mode ? crt_gi_child_key(key, 1u) : gen + 1u, child_base + i2);
+                if constexpr (LQ) lq_store_ray(A, i2, E.tox, E.toy, E.toz, E.tdx, E.tdy, E.tdz, gen + 1u);
+                else store_child_ray(out_q, i2, E.tox, E.toy, E.toz, E.tdx, E.tdy, E.tdz, gi_mode ? crt_gi_child_key(key, 1u) : gen + 1u, child_base + i2);
                 E.N.b = child_base + i2;
             }
         } else if constexpr (GI) {

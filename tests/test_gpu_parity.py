@@ -53,17 +53,25 @@ def test_ppm_file_matches_reference_bytes(pkg, scenes, tmp_path):
     assert open(path, "rb").read() == g["ppm"]
 
 
-# kernel paths, selected through crt_tuning (include/crt_hip.h); mode: 1 = lanes
+# kernel paths, selected through crt_tuning (include/crt_hip.h); mode: 1 = lanes; bvh: 1 = the candidate-filter kernels (the default
+# where the scene has a filter), 0 = the reference-order kernels alone, 2 = the filter kernels' bounds-checked build
 KERNEL_PATHS = [
     dict(mode=1),                                                # recursive one-ray-per-lane kernel for every pixel (the queue-less fallback)
-    dict(step_budget=8, shadow_budget=8, level0_budget=8),       # nearly every walk through the wave-per-ray kernels
-    dict(step_budget=0),                                         # wave-per-ray kernels off: faithful stream kernels
-    dict(heavy_level=1000000),                                   # deeper levels entirely by the wave-per-ray kernel
-    dict(heavy_level=0),                                         # ... entirely by the per-lane kernel first
-    dict(heavy_level=3000),                                      # ... some levels straddle the threshold
-    dict(side_blocks=0),                                         # no side stream
-    dict(step_budget=100000, shadow_budget=100000, heavy_level=0),  # nothing evicted: per-lane kernels alone
-    dict(side_blocks=4),                                         # the bulk shadow pass on four workgroups per CU
+    dict(bvh=1),                                                 # the filter kernels (csrc/kernel_bvh.h), the levels below level 0 through the level queue
+    dict(bvh=1, side_blocks=0),                                  # ... without a side stream
+    dict(bvh=1, side_blocks=4, level_queue=1),                   # ... the bulk shadow pass on four workgroups per CU, the queue on one
+    dict(bvh=2),                                                 # ... their bounds-checked build
+    dict(bvh=1, level_queue=0),                                  # ... one launch per level
+    dict(bvh=2, level_queue=0, side_blocks=0),
+    dict(bvh=0),                                                 # the reference-order kernels: plan kernels + wave-per-ray kernels
+    dict(bvh=0, step_budget=8, shadow_budget=8, level0_budget=8),       # nearly every walk through the wave-per-ray kernels
+    dict(bvh=0, step_budget=0),                                         # wave-per-ray kernels off: faithful stream kernels
+    dict(bvh=0, heavy_level=1000000),                                   # deeper levels entirely by the wave-per-ray kernel
+    dict(bvh=0, heavy_level=0),                                         # ... entirely by the per-lane kernel first
+    dict(bvh=0, heavy_level=3000),                                      # ... some levels straddle the threshold
+    dict(bvh=0, side_blocks=0),                                         # no side stream
+    dict(bvh=0, step_budget=100000, shadow_budget=100000, heavy_level=0),  # nothing evicted: per-lane kernels alone
+    dict(bvh=0, side_blocks=4),                                         # the bulk shadow pass on four workgroups per CU
 ]
 
 
@@ -81,11 +89,11 @@ def test_every_kernel_path_gives_the_same_frame(pkg, scenes, oracle, name, tunin
     assert tracer.stats().fallback_frames == 0
 
 
-MANY_PATHS = [None, dict(step_budget=8, shadow_budget=8, level0_budget=8), dict(heavy_level=0),
-              dict(step_budget=100000, shadow_budget=100000, heavy_level=0), dict(step_budget=0), dict(mode=1)]
+MANY_PATHS = [dict(bvh=0), dict(bvh=0, step_budget=8, shadow_budget=8, level0_budget=8), dict(bvh=0, heavy_level=0),
+              dict(bvh=0, step_budget=100000, shadow_budget=100000, heavy_level=0), dict(bvh=0, step_budget=0), dict(mode=1), None, dict(bvh=2)]
 
 
-@pytest.mark.parametrize("n_meshes,tuning", [(100, t) for t in MANY_PATHS] + [(150, MANY_PATHS[k]) for k in (0, 1, 3)] + [(300, MANY_PATHS[k]) for k in (0, 1)],
+@pytest.mark.parametrize("n_meshes,tuning", [(100, t) for t in MANY_PATHS] + [(150, MANY_PATHS[k]) for k in (0, 1, 3, 6)] + [(300, MANY_PATHS[k]) for k in (0, 1, 6, 7)],
                          ids=lambda v: str(v) if isinstance(v, int) else ("defaults" if v is None else ",".join("%s=%s" % kv for kv in v.items())))
 def test_many_meshes_stay_on_the_plan_kernels(pkg, scenes, oracle, n_meshes, tuning):
     """A top-level tree with hundreds of leaves (the reference's scenes have a handful of meshes): up to 256 meshes the wide
@@ -94,8 +102,10 @@ def test_many_meshes_stay_on_the_plan_kernels(pkg, scenes, oracle, n_meshes, tun
     scene = scenes.scatter_meshes(scenes.make("hw11", width=192, height=108, detail=0.25), n_meshes)
     want, _ = oracle.OracleScene(scenes.to_blob(scene)).render(4)
     tracer = make_tracer(pkg, scenes, scene, tuning=tuning)
-    if tuning is None:
+    if tuning == dict(bvh=0):
         assert ("plan_wide" in tracer.kernels()["level0"]) == (n_meshes <= 256)
+    if tuning is None:
+        assert "bvh_trace_shade" in tracer.kernels()["level0"]   # the filter kernels take any number of meshes
     for frame in range(2):
         assert_same_floats(tracer.render(max_depth=4), want, "%d meshes %r frame %d" % (n_meshes, tuning, frame))
     assert tracer.stats().fallback_frames == 0
@@ -341,7 +351,7 @@ def test_more_meshes_than_the_seen_mask_holds(pkg, scenes, oracle, n_objects):
     assert tracer.stats().counters() == counters
     assert_same_floats(got, want, "%d meshes (counting build)" % n_objects)
     assert_same_floats(tracer.render(max_depth=4), want, "%d meshes (production kernels)" % n_objects)
-    heavy = make_tracer(pkg, scenes, scene, tuning=dict(step_budget=8, shadow_budget=8))   # nearly every walk by the wave-per-ray kernels
+    heavy = make_tracer(pkg, scenes, scene, tuning=dict(bvh=0, step_budget=8, shadow_budget=8))   # nearly every walk by the wave-per-ray kernels
     assert_same_floats(heavy.render(max_depth=4), want, "%d meshes (wave-per-ray kernels)" % n_objects)
 
 
@@ -453,14 +463,11 @@ def test_queue_capacities_follow_the_frames(pkg, scenes, oracle):
     fresh = make_tracer(pkg, scenes, big)
     fresh.render(max_depth=8)
     attempts = int(fresh.stats().queue_regrows) + 1
-    first = sum(t[0] for t in fresh.kernel_times_ms(attempts))
     for _ in range(4):
         fresh.render(max_depth=8)
-    settled = sum(t[0] for t in fresh.kernel_times_ms(3)) / 3.0
-    assert attempts == 2 and fresh.stats().fallback_frames == 0
-    # (measured 1.8 - 2.2 x: the failed attempt stops at the level that overflowed, the repeated one is the first to touch the new
-    #  queues; the bound only has to tell this from the queue-less redo, which costs 4.4 x a frame on top of the failed attempt)
-    assert first <= 3.0 * settled + 1.0, (first, settled, attempts)
+    # one failed attempt, one repeat, never the queue-less redo (what the first frame COSTS against a settled one is measured by
+    # tools/regrow_time.py, not asserted here: wall-clock bounds on a shared box are flaky)
+    assert attempts == 2 and fresh.stats().fallback_frames == 0 and int(fresh.stats().queue_regrows) == 1
 
 
 def test_async_frames_equal_synchronous_ones(pkg, scenes, oracle):

@@ -12,7 +12,7 @@ extra = os.environ.get('CRT_TUNING', '')
 
 def counts(tr, depth):
     c = tr.stream_counts()
-    return 'rays %s evicted %s shadow %d sheavy %d overflow %d' % ([int(c[g]) for g in range(depth + 1)], [int(c[128 + g]) for g in range(depth + 1)], int(c[320]), int(c[323]), int(c[322]))
+    return 'rays %s shadow %d misses %d miss_hit %d overflow %d' % ([int(c[g]) for g in range(depth + 1)], int(c[320]), int(c[330]), int(c[332]), int(c[322]))
 
 
 for name in ['hw07', 'hw08', 'hw11', 'hw14', 'hw12']:
