@@ -8,7 +8,7 @@
 One "step" = one full frame of the per-pixel hot path.  The scene and its flattened tree are resident in
 HBM before the timed region.  With N > 1 the frame's 8x8 tiles are dealt round-robin over the ranks (one
 process per GPU, scene replicated), each rank renders its tiles into a packed device buffer and one RCCL
-all_gather collects them; rank 0 scatters them into the row-major frame.  The timed region
+gather brings them to rank 0, which scatters them into the row-major frame.  The timed region
 is bracketed by barrier + torch.cuda.synchronize() on both sides, the MAX over ranks is taken, and rank 0
 prints ONE JSON line.  `value` is the whole job's Mpixels/s as SURVEY.md section 8(d) defines the metric -- the
 reference's timing window ends with the float frame in HOST memory (RayTracer.cpp:207,289-293) -- so every timed
@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--no-alone", action="store_true", help="skip roofline.alone (keeps a rocprofv3 --stats run of this command to the in-frame launches)")
     ap.add_argument("--tuning", default="", help="development: crt_tuning fields as 'name=value ...' (default: the library's defaults)")
     ap.add_argument("--force-dist", action="store_true",
-                    help="run the collective path (process group, all_gather_into_tensor) even with one rank: exercises the RCCL "
+                    help="run the collective path (process group, gather to rank 0) even with one rank: exercises the RCCL "
                          "branch on a one-GPU box (tests/test_gpu_cli.py)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="development only: N processes share GPU 0 and gather through gloo on host buffers "
@@ -168,6 +168,7 @@ def main():
     part_floats = per_rank * 64 * 3
     packed = torch.zeros(part_floats, dtype=torch.float32, device=dev)
     gathered = torch.zeros(part_floats * world, dtype=torch.float32, device=dev) if dist_on else packed
+    gather_parts = list(gathered.view(world, part_floats).unbind(0)) if dist_on and rank == 0 else None
     # rank 0 assembles the frame; two buffers, so that frame k's copy to the host can run beside frame k + 1's kernels
     frames2 = [torch.zeros(H * W * 3, dtype=torch.float32, device=dev) for _ in range(2)]
     frame = frames2[0]
@@ -191,7 +192,9 @@ def main():
             dist.all_gather(parts, packed.cpu())
             gathered.copy_(torch.cat(parts))
         elif dist_on:
-            dist.all_gather_into_tensor(gathered, packed)
+            # only rank 0 assembles the frame: a gather to it (point-to-point sends over xGMI), not an all-gather that would deliver the
+            # whole frame to every rank
+            dist.gather(packed, gather_parts if rank == 0 else None, dst=0)
         if rank == 0:
             if to_host:
                 stream.wait_event(ev_copied[k])       # (the copy of the frame that used this buffer two steps ago)
@@ -289,7 +292,7 @@ def main():
                         dist.all_gather(parts, packs[i].cpu())
                         gaths[i].copy_(torch.cat(parts))
                     elif dist_on:
-                        dist.all_gather_into_tensor(gaths[i], packs[i])
+                        dist.gather(packs[i], list(gaths[i].view(world, part_floats).unbind(0)) if rank == 0 else None, dst=0)
                     if rank == 0:
                         trs[i].unpack_tiles_device(gaths[i].data_ptr(), world, part_floats, frames_f[i].data_ptr(), strs[i].cuda_stream)
 
@@ -369,7 +372,7 @@ def main():
                 with open(tp) as f:
                     tj = json.load(f)
                 key = "%s_%dx%d_d%d_n%d" % (args.scene, W, H, depth, world)
-                if key in tj:
+                if key in tj and tj[key].get("csrc_sha256") == pkg.csrc_sha256():   # (counters of THESE kernels only)
                     traffic = tj[key]["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
@@ -400,38 +403,57 @@ def main():
                          "note": "the same launch with the chip to itself (crt_tuning side_blocks=0: after the recursion levels, on their stream)"}
         except Exception as e:
             alone = {"kernel_ms": None, "note": "not measured: %r" % (e,)}
-        # The roofs nearer to this kernel than HBM, from the counters of the committed PMC passes (profiles/r03_pmc.json: per-launch
-        # counts, which do not depend on timing) over the launch duration measured LIVE above: vector-instruction issue (2 cycles
-        # per wave64 instruction on a SIMD-32), lanes per vector instruction, vector-L1 line rate; and the cycle-counter ratios of
-        # the counted launch itself (texture-address unit busy, waves waiting).
-        binding = None
+        # The roofs nearer to these kernels than HBM, from the counters of the committed PMC passes (profiles/r04_pmc.json: per-launch
+        # COUNTS, which do not depend on timing) over the launch durations measured LIVE above.  The file records the SHA-256 of the
+        # kernel sources it was collected from (tools/collect_profiles.py); when that is not the running tree's, its counts describe
+        # other kernels and nothing of it is used: `binding` and `traffic` are null and say why.
+        binding, bound, bound_frac, evidence = None, "latency", None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r03_pmc.json")) as f:
-                pj = json.load(f).get("%s_%dx%d_d%d_n%d" % (args.scene, W, H, depth, world))
-            if pj and pj["kernel"].startswith(dom.split("<")[0]):
-                c, clk = pj["per_launch"], float(pj["clock_ghz"]) * 1e9
+            with open(os.path.join(ROOT, "profiles", "r04_pmc.json")) as f:
+                pfile = json.load(f)
+            here = pkg.csrc_sha256()
+            if pfile.get("csrc_sha256") != here:
+                evidence = "profiles/r04_pmc.json was collected from other kernel sources (csrc sha256 %s..., running %s...): not used" % (
+                    str(pfile.get("csrc_sha256"))[:12], here[:12])
+                traffic = None
+            else:
+                key = "%s_%dx%d_d%d_n%d" % (args.scene, W, H, depth, world)
 
-                def roofs(ms):
-                    t = ms * 1e-3
-                    return {"kernel_ms": round(ms, 4),
-                            "valu": round(c["SQ_INSTS_VALU"] * 2.0 / (N_SIMDS * clk * t), 4),
-                            "l1": round(c["TCP_TOTAL_CACHE_ACCESSES_sum"] * 64.0 / t / (N_CUS * 64.0 * clk), 4)}
-                t_pmc = float(pj["kernel_ms_in_the_clock_pass"]) * 1e-3   # rocprofv3 serialises launches while it counts: the kernel has the chip
-                binding = {"source": "profiles/r03_pmc.json (%s)" % pj["kernel"], "clock_ghz": pj["clock_ghz"],
-                           "lanes": round(c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"] / 64.0, 4),
-                           "in_frame": roofs(dom_ms), "alone": roofs(alone["kernel_ms"]) if alone and alone.get("kernel_ms") else None,
-                           "in_the_counting_pass": {"kernel_ms": round(t_pmc * 1e3, 4), "waiting": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4),
-                                                    "ta_busy": round(c["TA_TA_BUSY_sum"] / (N_CUS * clk * t_pmc), 4),
-                                                    "l1_pending_stall": round(c["TCP_PENDING_STALL_CYCLES_sum"] / (N_CUS * clk * t_pmc), 4)},
-                           "note": "valu = wave-level vector instructions x 2 cycles over 1024 SIMDs and l1 = vector-L1 cache-line accesses over "
-                                   "256 CUs x 1 line/clk: per-launch COUNTS from the committed passes over the duration measured live here.  "
-                                   "lanes = active lanes per vector instruction / 64.  in_the_counting_pass: ratios of cycle counters, valid only "
-                                   "for the launch they were counted in (serialised by the profiler, three workgroups per CU): waiting = "
-                                   "SQ_WAIT_ANY / SQ_WAVE_CYCLES, ta_busy = texture-address busy cycles over 256 CUs, l1_pending_stall = "
-                                   "TCP_PENDING_STALL_CYCLES over 256 CUs.  No unit is saturated: the kernel waits on dependent loads "
-                                   "(a walk is a chain of node -> child gathers that hit in L2 / Infinity Cache)"}
+                def roofs(pj, ms):
+                    """fractions of the nearer roofs for one kernel: counts per launch over the live duration `ms`"""
+                    c, clk, t = pj["per_launch"], float(pj["clock_ghz"]) * 1e9, ms * 1e-3
+                    t_pmc = float(pj["kernel_ms_in_the_clock_pass"]) * 1e-3   # rocprofv3 serialises launches while it counts
+                    r = {"kernel": pj["kernel"], "kernel_ms": round(ms, 4),
+                         # a wave64 vector instruction issues 32 lanes per cycle: 2 cycles on one of 1024 SIMDs
+                         "valu": round(c["SQ_INSTS_VALU"] * 2.0 / (N_SIMDS * clk * t), 4),
+                         # one scalar instruction per cycle and SIMD (the CU's scalar unit serves its four SIMDs in turn: per CU the roof is 4x lower)
+                         "salu": round(c["SQ_INSTS_SALU"] / (N_SIMDS * clk * t), 4),
+                         "salu_if_one_per_cu_clock": round(c["SQ_INSTS_SALU"] / (N_CUS * clk * t), 4),
+                         "l1": round(c["TCP_TOTAL_CACHE_ACCESSES_sum"] * 64.0 / t / (N_CUS * 64.0 * clk), 4),
+                         "lanes": round(c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"] / 64.0, 4),
+                         "in_the_counting_pass": {"kernel_ms": round(t_pmc * 1e3, 4), "waiting": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4),
+                                                  "ta_busy": round(c["TA_TA_BUSY_sum"] / (N_CUS * clk * t_pmc), 4),
+                                                  "l1_pending_stall": round(c["TCP_PENDING_STALL_CYCLES_sum"] / (N_CUS * clk * t_pmc), 4)}}
+                    return r
+                binding = {"source": "profiles/r04_pmc.json", "csrc_sha256": here[:16]}
+                if pfile.get(key):
+                    binding["dominant"] = roofs(pfile[key], dom_ms)
+                    d = binding["dominant"]
+                    cands = {"valu issue": d["valu"], "salu issue (one per CU clock)": d["salu_if_one_per_cu_clock"], "vector L1 line rate": d["l1"],
+                             "texture-address unit busy": d["in_the_counting_pass"]["ta_busy"],
+                             "vector L1 stalled on its miss queue": d["in_the_counting_pass"]["l1_pending_stall"],
+                             "latency: waves waiting": d["in_the_counting_pass"]["waiting"]}
+                    bound, bound_frac = max(cands.items(), key=lambda kv: kv[1])
+                if pfile.get(key + "|levels") and pk_ms > 0:
+                    binding["levels"] = roofs(pfile[key + "|levels"], float(pfile[key + "|levels"]["kernel_ms_in_the_clock_pass"]))
+                binding["note"] = ("per-launch COUNTS from the committed passes over durations measured live here (levels: over the counted launch's own "
+                                   "duration -- in the frame it overlaps the dominant kernel).  valu: 2 cycles per wave64 instruction over 1024 SIMDs; salu: one "
+                                   "per cycle and SIMD (and, were it one per CU clock, 4x that); l1: vector-L1 line accesses over 256 CUs x 1 line/clk; lanes: "
+                                   "active lanes per vector instruction / 64; in_the_counting_pass: ratios of cycle counters, valid only for the launch they "
+                                   "were counted in")
         except Exception as e:
-            binding = {"note": "profiles/r03_pmc.json not usable: %r" % (e,)}
+            evidence = "profiles/r04_pmc.json not usable: %r" % (e,)
+            traffic = None
         out = {
             "metric": "Mpixels/s at 1920x1080 depth 8; HBM GB/s vs roofline",
             "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -447,20 +469,20 @@ def main():
             "host_frame_matches_device": host_ok,
             "kernel_ms": {"first_to_last": round(avg_kernel_ms, 4), "recursion_levels": round(pk_ms, 4),
                           "shadow_pass0_overlapped": round(ln_ms, 4), "shadow_pass1_heavy_resolve": round(rs_ms, 4)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": bound, "bound_frac": bound_frac, "evidence": evidence, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "peak_measured": HBM_MEASURED_GBS, "frac_of_measured": round(achieved / HBM_MEASURED_GBS, 4),
                          "kernel": dom, "kernel_ms": round(dom_ms, 4), "alone": alone, "binding": binding,
                          "executed_bytes_per_launch": int(b_exec_dom),
                          "executed": {"box_tests": executed["shadow_pass0_box_tests"], "tri_tests": executed["shadow_pass0_tri_tests"],
                                       "plan_tests": executed["shadow_pass0_plan_tests"]},
-                         "bound_note": "nominal: SURVEY.md section 8(d) prices this path against HBM bandwidth, and `achieved` is the "
-                                       "bytes of the box / triangle tests the kernel executes (32 B / 52 B each; the tests of the plan "
-                                       "loop against wave-uniform top-level leaf boxes 1 B each) over its duration IN THE FRAME, where it "
-                                       "runs at the lowest priority beside the recursion levels (`alone`: with the chip to itself).  HBM does "
-                                       "not bound this kernel: the scene (a few MB) lives in L2 / Infinity Cache and `traffic` (PMC, fabric side) "
-                                       "is a small fraction of the executed bytes.  `binding` holds the roofs nearer to it (vector issue, "
-                                       "lanes, vector-L1 rate, texture-address busy, waiting) -- see profiles/ and DESIGN.md section 4",
+                         "bound_note": "`bound` names the unit with the highest fraction among the roofs of `binding` (vector issue, scalar issue, "
+                                       "vector-L1 line rate, texture-address busy, L1 miss-queue stall, waves waiting) -- 'latency' when no fresh counters "
+                                       "are at hand.  `achieved` / `frac` stay what SURVEY.md section 8(d) prescribes for this path, priced against HBM: "
+                                       "the bytes of the box / triangle tests the kernel EXECUTES (32 B per child box of a filter node, 52 B per "
+                                       "triangle) over its duration IN THE FRAME, where it runs at the lowest priority beside the recursion levels "
+                                       "(`alone`: with the chip to itself).  HBM does not bound it: the scene lives in L2 / Infinity Cache and `traffic` "
+                                       "(PMC, fabric side) is a fraction of the executed bytes -- profiles/, DESIGN.md section 4",
                          "reference_work": {
                              "note": "what the REFERENCE does for the same rays (counting build == the oracle's counters).  The production "
                                      "kernel skips work that cannot change the result (one walk per mesh and ray, exact shadow early exit), "
@@ -478,7 +500,7 @@ def main():
         }
         if gathered_ok is not None:
             out["gathered_frame_matches_single_rank"] = gathered_ok
-        out["collective"] = ("gloo (rehearsal)" if args.rehearse_gloo else "rccl all_gather_into_tensor") if dist_on else None
+        out["collective"] = ("gloo (rehearsal)" if args.rehearse_gloo else "rccl gather to rank 0") if dist_on else None
         tracer.synchronize()
         fallback = int(tracer.stats().fallback_frames) - fallback_before
         out["fallback_frames"] = fallback                       # in the timed region (and the copy-inclusive one after it)

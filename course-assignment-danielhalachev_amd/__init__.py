@@ -130,7 +130,7 @@ def tuning_from_string(text):
 
 
 # every symbol include/crt_hip.h and include/crt_host.h declare
-DEVICE_SYMBOLS = ["crt_tuning_defaults", "crt_create_tuned", "crt_create", "crt_set_camera", "crt_render", "crt_render_tiles_device", "crt_packed_tile_count",
+DEVICE_SYMBOLS = ["crt_bvh_selftest", "crt_tuning_defaults", "crt_create_tuned", "crt_create", "crt_set_camera", "crt_render", "crt_render_tiles_device", "crt_packed_tile_count",
                   "crt_unpack_tiles_device", "crt_quantize_device", "crt_read_quantized", "crt_kernel_elapsed_ms", "crt_kernel_times_ms",
                   "crt_get_stats", "crt_get_kernel_counters", "crt_synchronize", "crt_destroy", "crt_last_error", "crt_device_count", "crt_test_pow5", "crt_test_gi",
                   "crt_describe_kernels", "crt_debug_stream_counts", "crt_get_executed_counters", "crt_get_executed_plan_tests",
@@ -534,6 +534,20 @@ def test_pow5(x, device=0):
     if rc != CRT_OK:
         raise CrtError(rc, "crt_test_pow5 failed")
     return out
+
+
+def csrc_sha256():
+    """SHA-256 over the kernel sources (csrc/*, sorted by name): profiles/ records it at collection time and bench.py compares it
+    with the running tree's, so that counters of other kernels are never passed off as this build's."""
+    import hashlib
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip", ".cpp")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
 
 
 def device_count():

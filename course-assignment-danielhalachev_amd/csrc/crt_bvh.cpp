@@ -314,7 +314,7 @@ void bvh_build(const crt_scene_desc *s, bool nested_boxes, BvhHost &out) {
         for (int a = 0; a < 3; a++) if (!std::isfinite(v.lo[a]) || !std::isfinite(v.hi[a])) return no("coordinates out of range");
         B.prims.push_back(t);
     }
-    if (B.prims.size() >= (1u << 24)) return no("too many triangles for the leaf links");
+    if (B.prims.size() >= (1u << 24)) return no("too many triangles for the leaf links");   // (also keeps 48-byte entry offsets in 32 bits: kernel_bvh.h, bvh_entry)
     auto ids_of = [&](uint32_t t) { return t | ((s->meshes[out.tri_mesh[t] & ~BVH_TRI_WALK].flags & 1u) ? BVH_ID_REFRACTIVE : 0u); };
     auto empty_node = [] {
         BvhNode N;
@@ -446,4 +446,165 @@ void bvh_build(const crt_scene_desc *s, bool nested_boxes, BvhHost &out) {
     out.cones.resize(out.nodes.size() * 16, 0.0f);
     if (out.nodes.size() >= (1u << 31)) return no("too many nodes");
     out.ok = true;
+}
+
+// =================================================================================================================================
+// crt_bvh_selftest: the filter's two promises, checked on the HOST against brute force (tests/test_bvh_filter.py; no GPU involved).
+// The tests below are the host's copies of kernel_bvh.h's (bvh_ray_setup / bvh_child_test, bvh_line_setup / bvh_line_test, the cone
+// test, bvh_triangle): the same expressions, compiled without contraction like everything else here.
+//   (1) every triangle the reference's test ACCEPTS with a finite distance for a ray is reached by the walk of the hierarchy with
+//       the conservative box test, whatever distance bound the walk has learnt so far (the bound used: that very distance);
+//   (2) every triangle it accepts with ANY distance (an infinite or NaN one included) and whose reference leaves the ray's line can
+//       pass is reached by the miss check's walk (reach boxes, normal cones).
+// out: {rays, accepted finite hits, of which not reached (1), accepted hits of any distance, of which not reached (2), nodes visited
+//       by (1), nodes visited by (2), structural errors}
+namespace {
+
+struct HRay { float ox, oy, oz, dx, dy, dz; };
+struct HBox { float ix, iy, iz, cpx, cpy, cpz, cmx, cmy, cmz; };
+inline float hdot3(float ax, float ay, float az, float bx, float by, float bz) { return ax * bx + ay * by + az * bz; }
+
+HBox h_ray_setup(const HRay &R, float extent, float tiny, float sub) {
+    const float rho = (extent + std::fmax(std::fmax(std::fabs(R.ox), std::fabs(R.oy)), std::fabs(R.oz))) * 0x1p-16f;
+    const float dx = std::fabs(R.dx) < tiny ? std::copysign(sub, R.dx) : R.dx, dy = std::fabs(R.dy) < tiny ? std::copysign(sub, R.dy) : R.dy,
+                dz = std::fabs(R.dz) < tiny ? std::copysign(sub, R.dz) : R.dz;
+    HBox B;
+    B.ix = 1.0f / dx; B.iy = 1.0f / dy; B.iz = 1.0f / dz;
+    B.cpx = -((R.ox + rho) * B.ix); B.cmx = -((R.ox - rho) * B.ix);
+    B.cpy = -((R.oy + rho) * B.iy); B.cmy = -((R.oy - rho) * B.iy);
+    B.cpz = -((R.oz + rho) * B.iz); B.cmz = -((R.oz - rho) * B.iz);
+    return B;
+}
+bool h_box_test(const HBox &B, const float *lo, const float *hi, bool segment, float tmax) {
+    const float ax = __builtin_fmaf(lo[0], B.ix, B.cpx), bx = __builtin_fmaf(hi[0], B.ix, B.cmx);
+    const float ay = __builtin_fmaf(lo[1], B.iy, B.cpy), by = __builtin_fmaf(hi[1], B.iy, B.cmy);
+    const float az = __builtin_fmaf(lo[2], B.iz, B.cpz), bz = __builtin_fmaf(hi[2], B.iz, B.cmz);
+    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    if (segment) { tn = fmaxf(tn, 0.0f); tf = fminf(tf, tmax); }
+    return !(__builtin_fmaf(-std::fabs(tn), 0x1p-20f, tn) > __builtin_fmaf(std::fabs(tf), 0x1p-20f, tf));
+}
+bool h_triangle(const HRay &R, bool primary, const float *T, float &t) {   // T: {v0, nx} {v1, ny} {v2, nz}
+    const float nx = T[3], ny = T[7], nz = T[11];
+    const float nd = hdot3(R.dx, R.dy, R.dz, nx, ny, nz);
+    const float plane = -hdot3(T[0], T[1], T[2], nx, ny, nz);
+    t = -(hdot3(nx, ny, nz, R.ox, R.oy, R.oz) + plane) / nd;
+    const float px = R.ox + R.dx * t, py = R.oy + R.dy * t, pz = R.oz + R.dz * t;
+    float s[3];
+    for (int k = 0; k < 3; k++) {
+        const float *a = T + 4 * k, *b = T + 4 * ((k + 1) % 3);
+        const float ex = b[0] - a[0], ey = b[1] - a[1], ez = b[2] - a[2], cx = px - a[0], cy = py - a[1], cz = pz - a[2];
+        s[k] = hdot3(nx, ny, nz, ey * cz - ez * cy, ez * cx - ex * cz, ex * cy - ey * cx);
+    }
+    return !(primary && nd >= 0) && !(t < 0) && !(s[0] < -FLT_EPSILON) && !(s[1] < -FLT_EPSILON) && !(s[2] < -FLT_EPSILON);
+}
+
+}  // namespace
+
+extern "C" int crt_bvh_selftest(const crt_scene_desc *s, const float *rays, uint32_t n_rays, int primary, uint64_t out[8]) {
+    if (!s || !rays || !out) return CRT_ERR_INVALID;
+    for (int k = 0; k < 8; k++) out[k] = 0;
+    BvhHost H;
+    bvh_build(s, true, H);
+    if (!H.ok) return CRT_ERR_INVALID;
+    const size_t n_entries = H.ids.size(), n_nodes = H.nodes.size();
+    // structure: every child reference inside its array, every entry in exactly one leaf
+    std::vector<uint32_t> seen(n_entries, 0);
+    for (size_t i = 0; i < n_nodes; i++)
+        for (int c = 0; c < 4; c++) {
+            const uint32_t ch = H.nodes[i].child[c];
+            if (ch == BVH_EMPTY) continue;
+            if (ch & BVH_LEAF) {
+                const uint32_t first = ch & 0x00FFFFFFu, n = ((ch >> 24) & 0x7Fu) + 1u;
+                if (first + n > n_entries) { out[7]++; continue; }
+                for (uint32_t k = 0; k < n; k++) seen[first + k]++;
+            } else if (ch >= n_nodes || ch <= i) out[7]++;
+        }
+    for (size_t e = 0; e < n_entries; e++) if (seen[e] != 1) out[7]++;
+    if (H.vnodes.size() != n_nodes * 24 || H.cones.size() != n_nodes * 16 || H.tris.size() != n_entries * 12) out[7]++;
+    if (out[7]) return CRT_OK;
+    // the reach of entry e: can the ray's line pass one of the reference leaves listing its triangle?  (the reference's own slab test,
+    // BoundingBox.h:85-108, on those boxes -- what kernel_bvh.h: bvh_verify decides)
+    auto ref_slab = [](const HRay &R, const float *lo, const float *hi) {
+        float t0 = -FLT_MAX, t1 = FLT_MAX;
+        const float o[3] = {R.ox, R.oy, R.oz}, d[3] = {R.dx, R.dy, R.dz};
+        for (int a = 0; a < 3; a++) {
+            if (std::fabs(d[a]) < FLT_EPSILON) { if (o[a] < lo[a] || o[a] > hi[a]) return false; continue; }
+            const float inv = 1.0f / d[a];
+            float tn = (lo[a] - o[a]) * inv, tf = (hi[a] - o[a]) * inv;
+            if (tn > tf) std::swap(tn, tf);
+            t0 = (t0 < tn) ? tn : t0; t1 = (tf < t1) ? tf : t1;
+            if (t0 > t1) return false;
+        }
+        return true;
+    };
+    std::vector<uint32_t> stack;
+    std::vector<char> reached(n_entries);
+    for (uint32_t r = 0; r < n_rays; r++) {
+        HRay R{rays[6 * r], rays[6 * r + 1], rays[6 * r + 2], rays[6 * r + 3], rays[6 * r + 4], rays[6 * r + 5]};
+        out[0]++;
+        // ---- (1) finite accepted hits against the segment walk, each with its own distance as the bound
+        const HBox B = h_ray_setup(R, H.extent, 1e-12f, 1e-12f);
+        for (size_t e = 0; e < n_entries; e++) {
+            float t;
+            if (!h_triangle(R, primary != 0, &H.tris[12 * e], t) || !(t < INFINITY)) continue;
+            out[1]++;
+            bool found = false;
+            stack.assign(1, 0u);
+            while (!stack.empty() && !found) {
+                const uint32_t cur = stack.back();
+                stack.pop_back();
+                if (cur & BVH_LEAF) {
+                    const uint32_t first = cur & 0x00FFFFFFu, n = ((cur >> 24) & 0x7Fu) + 1u;
+                    if (e >= first && e < first + n) found = true;
+                    continue;
+                }
+                out[5]++;
+                const BvhNode &N = H.nodes[cur];
+                for (int c = 0; c < 4; c++) {
+                    if (N.child[c] == BVH_EMPTY) continue;
+                    const float lo[3] = {N.lox[c], N.loy[c], N.loz[c]}, hi[3] = {N.hix[c], N.hiy[c], N.hiz[c]};
+                    if (h_box_test(B, lo, hi, true, t)) stack.push_back(N.child[c]);
+                }
+            }
+            if (!found) out[2]++;
+        }
+        // ---- (2) accepted hits of any distance against the miss check's walk
+        const HBox Lb = h_ray_setup(R, H.extent, 2.0f * FLT_EPSILON, 1e-30f);
+        std::fill(reached.begin(), reached.end(), 0);
+        stack.assign(1, 0u);
+        while (!stack.empty()) {
+            const uint32_t cur = stack.back();
+            stack.pop_back();
+            if (cur & BVH_LEAF) {
+                const uint32_t first = cur & 0x00FFFFFFu, n = ((cur >> 24) & 0x7Fu) + 1u;
+                for (uint32_t k = 0; k < n; k++) reached[first + k] = 1;
+                continue;
+            }
+            out[6]++;
+            const BvhNode &N = H.nodes[cur];
+            const float *V = &H.vnodes[(size_t)cur * 24], *C = &H.cones[(size_t)cur * 16];
+            for (int c = 0; c < 4; c++) {
+                if (N.child[c] == BVH_EMPTY) continue;
+                const float lo[3] = {V[c], V[4 + c], V[8 + c]}, hi[3] = {V[12 + c], V[16 + c], V[20 + c]};
+                const float sdot = __builtin_fmaf(C[c], R.dx, __builtin_fmaf(C[4 + c], R.dy, C[8 + c] * R.dz));
+                if (!(std::fabs(sdot) > C[12 + c]) && h_box_test(Lb, lo, hi, false, 0.0f)) stack.push_back(N.child[c]);
+            }
+        }
+        for (size_t e = 0; e < n_entries; e++) {
+            float t;
+            if (!h_triangle(R, primary != 0, &H.tris[12 * e], t)) continue;
+            if (t < INFINITY) continue;   // (finite ones are (1)'s)
+            // would the reference test it?  one of its leaves' boxes must pass the reference's slab test
+            const uint32_t tri = H.ids[e] & ~BVH_ID_REFRACTIVE;
+            bool visited = false;
+            if (H.tri_mesh[tri] & BVH_TRI_WALK) visited = true;   // (no list: count it as visited -- the stricter demand)
+            for (uint32_t j = H.tri_leaf_first[tri]; j < H.tri_leaf_first[tri + 1] && !visited; j++)
+                visited = ref_slab(R, &H.tri_leaf_list[8 * (size_t)j], &H.tri_leaf_list[8 * (size_t)j + 4]);
+            if (!visited) continue;
+            out[3]++;
+            if (!reached[e]) out[4]++;
+        }
+    }
+    return CRT_OK;
 }

@@ -1055,7 +1055,8 @@ static int ensure_stream(crt_ctx *ctx, uint32_t n_items) {
     A.s_rayq[0] = ctx->d_rayq[0]; A.s_rayq[1] = ctx->d_rayq[1];
     A.s_shadowq = ctx->d_shadowq; A.s_occluded = ctx->d_occluded; A.s_nodes = ctx->d_nodes;
     A.s_heavy = ctx->d_heavy; A.s_sheavy = ctx->d_sheavy; A.s_hits = ctx->d_hits; A.s_hits_all = ctx->d_hits_all; A.s_heavy_cap = ctx->heavy_cap;
-    A.s_lq = ctx->d_lq; A.s_lq_cap = ctx->d_lq ? A.s_node_cap : 0u;
+    // (an explicit ray capacity -- crt_tuning, the tests' way to an overflow -- bounds the level queue too)
+    A.s_lq = ctx->d_lq; A.s_lq_cap = ctx->d_lq ? (ctx->tuning.ray_cap ? std::min(A.s_ray_cap, A.s_node_cap) : A.s_node_cap) : 0u;
     return CRT_OK;
 }
 

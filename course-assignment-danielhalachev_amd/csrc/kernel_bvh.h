@@ -67,7 +67,14 @@ constexpr int SC_BVH_DIAG = SC_HEAVY_DIAG + 16;
 template <int MODE>
 __device__ __forceinline__ uint32_t bvh_at(const KernelArgs &A, const uint32_t i, const uint32_t n, const uint32_t code) {
     if (MODE == BVH_CHECKED && i >= n) { A.f->s_counts[SC_BVH_DIAG + 2 * code] = 1u; A.f->s_counts[SC_BVH_DIAG + 2 * code + 1] = i; return 0u; }
-    return i < n ? i : 0u;   // (every build keeps its indices inside their arrays, whatever a walk's state says)
+    return i;
+}
+// The record of filter entry e (48 bytes).  The byte offset is computed in 32 bits ON PURPOSE: the entry index comes out of a masked
+// word (`cur & 0x00FFFFFF`), and ROCm 7.2's gfx950 backend lowers zext(x & 0xFFFFFF) * 48 to a v_mad_u64_u32 on the UNMASKED x -- a wild
+// address, a memory fault (found in round 3 on another kernel, met again here: the bounds-checked build, whose compare keeps the mask
+// alive, never faulted and never recorded a violation).  bvh_build keeps 48 x entries below 2^32.
+__device__ __forceinline__ const float4 *bvh_entry(const KernelArgs &A, const uint32_t e) {
+    return reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(A.s->bvh_tris) + (size_t)(uint32_t)(e * 48u));
 }
 
 struct BvhRay { float ix, iy, iz, cpx, cpy, cpz, cmx, cmy, cmz; };
@@ -81,7 +88,9 @@ __device__ __forceinline__ bool bvh_ray_setup(const KernelArgs &A, const Ray &R,
     // rays are less than 1e-5 rho apart, which the slack covers many times over.
     const float dx = fabsf(R.dx) < 1e-12f ? copysignf(1e-12f, R.dx) : R.dx, dy = fabsf(R.dy) < 1e-12f ? copysignf(1e-12f, R.dy) : R.dy,
                 dz = fabsf(R.dz) < 1e-12f ? copysignf(1e-12f, R.dz) : R.dz;
-    B.ix = 1.0f / dx; B.iy = 1.0f / dy; B.iz = 1.0f / dz;
+    // (v_rcp_f32: one unit in the last place off the true quotient -- a ray whose axes are scaled by 1 +- 2 u each; the 2^-20 by which both
+    //  interval ends are widened covers it many times over, and the exact 1/d of the reference's slab test stays in R for the verification)
+    B.ix = __builtin_amdgcn_rcpf(dx); B.iy = __builtin_amdgcn_rcpf(dy); B.iz = __builtin_amdgcn_rcpf(dz);
     B.cpx = -((R.ox + rho) * B.ix); B.cmx = -((R.ox - rho) * B.ix);
     B.cpy = -((R.oy + rho) * B.iy); B.cmy = -((R.oy - rho) * B.iy);
     B.cpz = -((R.oz + rho) * B.iz); B.cmz = -((R.oz - rho) * B.iz);
@@ -257,7 +266,7 @@ __device__ __forceinline__ bool bvh_step(const KernelArgs &A, const Ray &R, cons
 #pragma unroll
         for (uint32_t k = 0; k < TPS; k++) {
             const uint32_t e = first + (k < n_here ? k : n_here - 1u);   // (beyond the leaf: its last triangle again, not tested)
-            const float4 *T = A.s->bvh_tris + 3 * (size_t)e;
+            const float4 *T = bvh_entry(A, e);
             ta[k] = T[0]; tb[k] = T[1]; tc[k] = T[2];
             tid[k] = A.s->bvh_ids[e];
         }
@@ -349,7 +358,7 @@ __device__ __forceinline__ bool bvh_miss_step(const KernelArgs &A, const Ray &R,
         const uint32_t left = (W.cur >> 24) & 0x7Fu;
         const uint32_t first = bvh_at<MODE>(A, W.cur & 0x00FFFFFFu, A.s->n_bvh_entries - (left ? 1u : 0u), 10);
         const uint32_t second = first + (left ? 1u : 0u);
-        const float4 *T0 = A.s->bvh_tris + 3 * (size_t)first, *T1 = A.s->bvh_tris + 3 * (size_t)second;
+        const float4 *T0 = bvh_entry(A, first), *T1 = bvh_entry(A, second);
         const float4 a0 = T0[0], b0 = T0[1], c0 = T0[2], a1 = T1[0], b1 = T1[1], c1 = T1[2];
         const uint32_t id0 = A.s->bvh_ids[first], id1 = A.s->bvh_ids[second];
         W.cur = left >= 2u ? (BVH_LEAF | ((left - 2u) << 24) | (first + 2u)) : BVH_EMPTY;

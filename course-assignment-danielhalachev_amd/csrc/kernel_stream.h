@@ -335,11 +335,20 @@ __device__ __forceinline__ void shade_and_emit(const KernelArgs &A, const uint32
         const unsigned long long below = (1ull << lane) - 1ull;
         const uint32_t n1 = (uint32_t)__popcll(m1), n2 = (uint32_t)__popcll(m2), n3 = GI ? (uint32_t)__popcll(m3) * A.f->gi_samples : 0u;
         uint32_t base = 0;
-        if ((m0 & below) == 0) {
-            base = atomicAdd(out_count, n1 + n2 + n3);
-            if (LQ) atomicAdd(A.f->s_counts + SC_COUNT + gen + 1, n1 + n2 + n3);   // (the levels' sizes: what the queues are sized by)
-        }
+        if ((m0 & below) == 0) base = atomicAdd(out_count, n1 + n2 + n3);
         base = __shfl(base, __ffsll((long long)m0) - 1);
+        if constexpr (LQ) {
+            // the levels' sizes (what the queues are sized by, what the tools print): the calling lanes may be of different levels --
+            // one addition per level present among them
+            unsigned long long left = m0;
+            while (left) {
+                const uint32_t g = (uint32_t)__shfl((int)gen, __ffsll((long long)left) - 1);
+                const unsigned long long same = __ballot(gen == g) & left;
+                const uint32_t kids = (uint32_t)__popcll(m1 & same) + (uint32_t)__popcll(m2 & same);
+                if (kids && lane == (uint32_t)(__ffsll((long long)same) - 1)) atomicAdd(A.f->s_counts + SC_COUNT + g + 1, kids);
+                left &= ~same;
+            }
+        }
         if ((uint64_t)base + n1 + n2 + n3 > out_cap || (uint64_t)child_base + base + n1 + n2 + n3 > A.f->s_node_cap) {
             // (level queue: entries were reserved that will never be written; the waves waiting for them watch this word, from other XCDs too)
             if (LQ) __hip_atomic_store((uint32_t __attribute__((address_space(1))) *)(A.f->s_lq_words + LQ_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -492,6 +492,52 @@ void loadPNG(const std::vector<uint8_t> &d, int &width, int &height, std::vector
   }
 }
 
+// Uncompressed Windows BMP, 24 or 32 bits per pixel (BITMAPINFOHEADER and later; bottom-up unless the height is negative), as
+// stbi_load returns it: rows top-down, red first; a fourth channel is dropped (Texture.cpp:53-57 reads channels 0..2).
+uint32_t le32(const std::vector<uint8_t> &d, size_t p) { return (uint32_t)d[p] | ((uint32_t)d[p + 1] << 8) | ((uint32_t)d[p + 2] << 16) | ((uint32_t)d[p + 3] << 24); }
+uint32_t le16(const std::vector<uint8_t> &d, size_t p) { return (uint32_t)d[p] | ((uint32_t)d[p + 1] << 8); }
+void loadBMP(const std::vector<uint8_t> &d, int &width, int &height, std::vector<uint8_t> &rgb) {
+  if (d.size() < 54) throw SceneParseError("truncated BMP");
+  const uint32_t offset = le32(d, 10), header = le32(d, 14);
+  const int32_t w = (int32_t)le32(d, 18), hraw = (int32_t)le32(d, 22);
+  const uint32_t bpp = le16(d, 28), compression = le32(d, 30);
+  if (header < 40 || w <= 0 || hraw == 0 || (bpp != 24 && bpp != 32) || (compression != 0 && !(compression == 3 && bpp == 32)))
+    throw SceneParseError("unsupported BMP (need uncompressed 24 or 32 bits per pixel)");
+  const int h = hraw < 0 ? -hraw : hraw;
+  const size_t stride = (((size_t)w * bpp + 31) / 32) * 4;
+  if ((uint64_t)offset + stride * (size_t)h > d.size()) throw SceneParseError("truncated BMP");
+  width = w; height = h;
+  rgb.resize((size_t)w * h * 3);
+  for (int y = 0; y < h; y++) {
+    const uint8_t *row = d.data() + offset + stride * (size_t)(hraw < 0 ? y : h - 1 - y);
+    for (int x = 0; x < w; x++) {
+      const uint8_t *px = row + (size_t)x * (bpp / 8);
+      uint8_t *o = &rgb[((size_t)y * w + x) * 3];
+      o[0] = px[2]; o[1] = px[1]; o[2] = px[0];   // stored blue first
+    }
+  }
+}
+
+// Truevision TGA, uncompressed true colour (image type 2), 24 or 32 bits per pixel, no colour map; bottom-up unless the
+// descriptor's bit 5 says otherwise.  (TGA has no signature: taken for one when the header is consistent and the name ends in .tga.)
+void loadTGA(const std::vector<uint8_t> &d, int &width, int &height, std::vector<uint8_t> &rgb) {
+  if (d.size() < 18) throw SceneParseError("truncated TGA");
+  const uint32_t id_len = d[0], cmap = d[1], type = d[2], w = le16(d, 12), h = le16(d, 14), bpp = d[16], desc = d[17];
+  if (cmap != 0 || type != 2 || (bpp != 24 && bpp != 32) || w == 0 || h == 0) throw SceneParseError("unsupported TGA (need uncompressed true colour, 24 or 32 bits per pixel)");
+  const size_t start = 18 + id_len, bytes = bpp / 8;
+  if (start + (size_t)w * h * bytes > d.size()) throw SceneParseError("truncated TGA");
+  width = (int)w; height = (int)h;
+  rgb.resize((size_t)w * h * 3);
+  for (uint32_t y = 0; y < h; y++) {
+    const uint8_t *row = d.data() + start + (size_t)((desc & 0x20u) ? y : h - 1 - y) * w * bytes;
+    for (uint32_t x = 0; x < w; x++) {
+      const uint8_t *px = row + (size_t)((desc & 0x10u) ? w - 1 - x : x) * bytes;
+      uint8_t *o = &rgb[((size_t)y * w + x) * 3];
+      o[0] = px[2]; o[1] = px[1]; o[2] = px[0];
+    }
+  }
+}
+
 }  // namespace
 
 void loadBitmapRGB8(const std::string &path, int &width, int &height, std::vector<uint8_t> &rgb8) {
@@ -501,7 +547,13 @@ void loadBitmapRGB8(const std::string &path, int &width, int &height, std::vecto
   static const uint8_t png_sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
   if (d.size() >= 8 && !memcmp(d.data(), png_sig, 8)) return loadPNG(d, width, height, rgb8);
   if (d.size() >= 2 && d[0] == 'P' && (d[1] == '2' || d[1] == '3' || d[1] == '5' || d[1] == '6')) return loadPNM(d, width, height, rgb8);
-  throw SceneParseError("unsupported bitmap format (PNG or PNM expected): " + path);
+  if (d.size() >= 2 && d[0] == 'B' && d[1] == 'M') return loadBMP(d, width, height, rgb8);
+  if (path.size() >= 4 && (path.compare(path.size() - 4, 4, ".tga") == 0 || path.compare(path.size() - 4, 4, ".TGA") == 0)) return loadTGA(d, width, height, rgb8);
+  // The reference decodes bitmaps with stb_image (Texture.cpp:46-60: JPEG, GIF, PSD, HDR, 16-bit and interlaced PNG ... as well).  This
+  // loader reads 8-bit PNG, PNM, uncompressed BMP and TGA; anything else is decoded by the CALLER and handed over as RGB8:
+  // crt_scene_desc::texels / crt_texture (include/crt_hip.h), three lines with stb_image -- INTEGRATION.md, section B.
+  throw SceneParseError("unsupported bitmap format (8-bit PNG, PNM, uncompressed BMP or TGA expected; decode anything else with stb_image and "
+                        "pass RGB8 texels through crt_scene_desc: INTEGRATION.md section B): " + path);
 }
 
 }  // namespace crt

@@ -326,6 +326,13 @@ int crt_test_pow5(int device, const float *x, float *out, uint64_t n);
  * uniform number u(key a[i], draw b[i]); 3: mix(a[i], b[i]).  b may be NULL for 0 and 1. */
 int crt_test_gi(int device, uint32_t what, const uint32_t *a, const uint32_t *b, uint32_t *out, uint64_t n);
 
+/* Test hook, HOST ONLY (no device is touched): builds the candidate filter of `scene` (csrc/crt_bvh.h) and checks its two promises
+ * against brute force for n_rays rays (6 floats each: origin, direction): out = {rays, triangles the reference's test accepts with a
+ * finite distance, of which the conservative walk does not reach (must be 0), triangles it accepts with an infinite or NaN distance in
+ * a leaf the ray's line passes, of which the miss check does not reach (must be 0), nodes visited by the two walks, structural
+ * errors (must be 0)}.  CRT_ERR_INVALID when the scene has no filter. */
+int crt_bvh_selftest(const crt_scene_desc *scene, const float *rays, uint32_t n_rays, int primary, uint64_t out[8]);
+
 /* Diagnostics for the development tools under tools/ (no counterpart in the reference; not needed to render):
  * the ray-stream pass's queue counters of the last frame (rays per recursion level, walks handed to the
  * wave-per-ray kernels, ...: the SC_* layout of csrc/kernel_stream.h, at most 512 words). */

@@ -117,7 +117,7 @@ def test_crt_main_gi_mode(scenes, oracle, tmp_path):
 
 
 def test_bench_collective_branch_runs_on_hardware(tmp_path):
-    """bench.py's multi-rank path -- init_process_group(backend="nccl", device_id=...), all_gather_into_tensor of the packed
+    """bench.py's multi-rank path -- init_process_group(backend="nccl", device_id=...), gather (to rank 0) of the packed
     tiles, unpack on rank 0, the frames-in-flight loop -- executed once on real hardware with ONE rank (--force-dist): the
     gathered frame must equal the single-rank frame, every timed frame must reach pinned host memory intact."""
     import json
@@ -128,7 +128,7 @@ def test_bench_collective_branch_runs_on_hardware(tmp_path):
                        capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
-    assert line["collective"] == "rccl all_gather_into_tensor"
+    assert line["collective"] == "rccl gather to rank 0"
     assert line["gathered_frame_matches_single_rank"] is True
     assert line["frame_matches_counting_build"] is True and line["host_frame_matches_device"] is True
     assert line["pipelined"]["frames_match_one_at_a_time"] is True and line["fallback_frames"] == 0

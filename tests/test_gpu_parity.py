@@ -105,7 +105,7 @@ def test_many_meshes_stay_on_the_plan_kernels(pkg, scenes, oracle, n_meshes, tun
     if tuning == dict(bvh=0):
         assert ("plan_wide" in tracer.kernels()["level0"]) == (n_meshes <= 256)
     if tuning is None:
-        assert "bvh_trace_shade" in tracer.kernels()["level0"]   # the filter kernels take any number of meshes
+        assert tracer.kernels()["level0"].startswith("bvh_trace_")   # the filter kernels take any number of meshes
     for frame in range(2):
         assert_same_floats(tracer.render(max_depth=4), want, "%d meshes %r frame %d" % (n_meshes, tuning, frame))
     assert tracer.stats().fallback_frames == 0

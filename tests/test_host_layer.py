@@ -167,10 +167,17 @@ def test_unknown_material_keeps_the_reference_message(pkg):
 
 
 def test_png_and_pnm_bitmaps_decode_to_the_same_texels(pkg, scenes, tmp_path):
+    import struct
     from PIL import Image
     rng = np.random.RandomState(3)
     px = rng.randint(0, 256, size=(9, 13, 3), dtype=np.uint8)
     Image.fromarray(px).save(str(tmp_path / "t.png"))
+    Image.fromarray(px).save(str(tmp_path / "t.bmp"))                          # 24-bit, bottom-up, rows padded to 4 bytes
+    Image.fromarray(np.dstack([px, np.full((9, 13), 200, np.uint8)])).save(str(tmp_path / "t32.bmp"))   # 32-bit with alpha (dropped)
+    Image.fromarray(px).save(str(tmp_path / "t.tga"))                          # uncompressed true colour, bottom-up
+    with open(str(tmp_path / "top.tga"), "wb") as f:                           # top-down 32-bit TGA written by hand
+        f.write(struct.pack("<BBBHHBHHHHBB", 0, 0, 2, 0, 0, 0, 0, 0, 13, 9, 32, 0x28))
+        f.write(np.dstack([px[:, :, ::-1], np.full((9, 13), 7, np.uint8)]).tobytes())
     with open(str(tmp_path / "t.ppm"), "wb") as f:
         f.write(b"P6\n13 9\n255\n" + px.tobytes())
     base = ('{"settings":{"background_color":[0,0,0],"image_settings":{"width":8,"height":8,"bucket_size":1}},'
@@ -178,12 +185,15 @@ def test_png_and_pnm_bitmaps_decode_to_the_same_texels(pkg, scenes, tmp_path):
             '"textures":[{"name":"b","type":"bitmap","file_path":"/%s"}],'
             '"materials":[{"type":"diffuse","albedo":"b","smooth_shading":false}],'
             '"objects":[{"material_index":0,"vertices":[0,0,-1,1,0,-1,0,1,-1],"uvs":[0,0,0,1,0,0,0,1,0],"triangles":[0,1,2]}]}')
-    for fn in ("t.png", "t.ppm"):
+    for fn in ("t.png", "t.ppm", "t.bmp", "t32.bmp", "t.tga", "top.tga"):
         hs = pkg.Scene(json_text=base % fn, folder=str(tmp_path))
         d = hs.desc
         assert (d.textures[0].width, d.textures[0].height, d.n_texels) == (13, 9, 117)
         got = np.ctypeslib.as_array(d.texels, shape=(117 * 3,)).reshape(9, 13, 3)
         assert np.array_equal(got, px), fn
+    Image.fromarray(px).save(str(tmp_path / "t.jpg"))                          # what this loader leaves to the caller: the error says how
+    with pytest.raises(pkg.CrtError, match="stb_image"):
+        pkg.Scene(json_text=base % "t.jpg", folder=str(tmp_path))
 
 
 # ---------------------------------------------------------------------------------------------- buckets / camera / PPM

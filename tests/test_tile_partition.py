@@ -31,8 +31,8 @@ def _worker(rank, world, port, width, height, out_path):
     rng = np.random.RandomState(7)  # every rank holds the same "scene": a deterministic frame stands in for the render
     frame = rng.rand(height, width, 3).astype(np.float32)
     mine = torch.from_numpy(tiles.pack_tiles(frame, rank, world))
-    gathered = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(gathered, mine)
+    gathered = [torch.zeros_like(mine) for _ in range(world)] if rank == 0 else None
+    dist.gather(mine, gathered, dst=0)            # only rank 0 assembles the frame: a gather to it, as bench.py does over RCCL
     if rank == 0:
         got = tiles.unpack_tiles(np.stack([g.numpy() for g in gathered]), width, height, world)
         np.save(out_path, np.array([np.array_equal(got, frame)]))
