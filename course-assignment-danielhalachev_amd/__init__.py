@@ -16,7 +16,9 @@ import numpy as np
 from . import scenes  # noqa: F401  (synthetic workload generators)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcrt_hip.so")
+# libcrt_hip.so is the product; libcrt_hip_test.so is the same objects plus the unit-test hooks (TEST_HOOK_SYMBOLS below), which the
+# test suite loads (tests/conftest.py sets CRT_TEST_HOOKS; this package reads the variable, the library itself reads none)
+LIB_PATH = os.path.join(HERE, "libcrt_hip_test.so" if os.environ.get("CRT_TEST_HOOKS") else "libcrt_hip.so")
 
 CRT_OK, CRT_ERR_INVALID, CRT_ERR_NO_DEVICE, CRT_ERR_HIP, CRT_ERR_NOMEM, CRT_ERR_IO, CRT_ERR_PARSE = range(7)
 OPT_NONE, OPT_REGIONS, OPT_BUCKETS_POOL, OPT_BUCKETS_QUEUE, OPT_AABB, OPT_BUCKETS_POOL_AABB, \
@@ -129,7 +131,8 @@ def tuning_from_string(text):
     return make_tuning(**{k: int(v, 0) for k, v in (kv.split("=") for kv in text.split())})
 
 
-# every symbol include/crt_hip.h and include/crt_host.h declare
+# every symbol include/crt_hip.h and include/crt_host.h declare; the test hooks are exported by libcrt_hip_test.so only
+TEST_HOOK_SYMBOLS = ["crt_bvh_selftest", "crt_test_pow5", "crt_test_gi", "crt_debug_multi_force_staged", "crt_debug_multi_fail_next_alloc"]
 DEVICE_SYMBOLS = ["crt_bvh_selftest", "crt_tuning_defaults", "crt_create_tuned", "crt_create", "crt_set_camera", "crt_render", "crt_render_tiles_device", "crt_packed_tile_count",
                   "crt_unpack_tiles_device", "crt_quantize_device", "crt_read_quantized", "crt_kernel_elapsed_ms", "crt_kernel_times_ms",
                   "crt_get_stats", "crt_get_kernel_counters", "crt_synchronize", "crt_destroy", "crt_last_error", "crt_device_count", "crt_test_pow5", "crt_test_gi",
@@ -158,7 +161,7 @@ def lib():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise ImportError("libcrt_hip.so is not built (%s): run __graft_entry__.build(); there is no fallback path"
+        raise ImportError("the library is not built (%s): run __graft_entry__.build(); there is no fallback path"
                           % LIB_PATH)
     L = C.CDLL(LIB_PATH)
     vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int

@@ -15,7 +15,7 @@ constexpr double UNIT_ROUNDOFF = 5.9604644775390625e-8;  // 2^-24
 bool is_leaf_link(uint32_t link) { return (link & CRT_LINK_LEAF) != 0 && link != CRT_LINK_END; }
 
 // The nodes of the tree under `root`, ascending (= visit order: both links of a node point forward).  Children of an inner node:
-// `link` and -- unless it is the node's own `miss` -- the `miss` of that first child (crt_device.hip finds the top-level tree the same way).
+// `link` and -- unless it is the node's own `miss` -- the `miss` of that first child (crt_scene.hip finds the top-level tree the same way).
 void collect_tree(const crt_scene_desc *s, uint32_t root, std::vector<bool> &mark, std::vector<uint32_t> &out) {
     std::vector<uint32_t> stack{root};
     while (!stack.empty()) {
@@ -448,6 +448,7 @@ void bvh_build(const crt_scene_desc *s, bool nested_boxes, BvhHost &out) {
     out.ok = true;
 }
 
+#ifdef CRT_TEST_HOOKS   // (libcrt_hip_test.so only)
 // =================================================================================================================================
 // crt_bvh_selftest: the filter's two promises, checked on the HOST against brute force (tests/test_bvh_filter.py; no GPU involved).
 // The tests below are the host's copies of kernel_bvh.h's (bvh_ray_setup / bvh_child_test, bvh_line_setup / bvh_line_test, the cone
@@ -608,3 +609,4 @@ extern "C" int crt_bvh_selftest(const crt_scene_desc *s, const float *rays, uint
     }
     return CRT_OK;
 }
+#endif  // CRT_TEST_HOOKS

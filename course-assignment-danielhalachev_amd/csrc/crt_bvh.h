@@ -70,5 +70,5 @@ struct BvhHost {
     uint32_t walk_triangles = 0;     // triangles verified by the pruned tree walk
 };
 
-// Builds the filter for a validated scene description (crt_device.hip: validate_scene has checked every index).
+// Builds the filter for a validated scene description (crt_scene.hip: validate_scene has checked every index).
 void bvh_build(const crt_scene_desc *s, bool nested_boxes, BvhHost &out);

@@ -35,7 +35,6 @@
 // kernels and the bulk shadow pass fit on a CU together), the rest -- rarely reached -- in a device buffer (FrameArgs::bvh_spill, one
 // column per thread of the largest grid).  SceneArgs::bvh_stack entries in all, sized by crt_create from the hierarchy's depth -- three
 // entries per inner node on a path is all a walk can push -- so that no walk outgrows it.
-constexpr uint32_t BVH_LDS_STACK = 16;
 struct BvhStack { uint32_t *lds; uint32_t *spill; uint32_t stride; };   // lds + threadIdx.x; spill + global thread; threads of the grid
 __device__ __forceinline__ void bvh_push(const BvhStack &S, uint32_t &sp, const uint32_t v) {
     if (sp < BVH_LDS_STACK) S.lds[sp * BLOCK] = v;

@@ -18,6 +18,27 @@ enum : int { C_BOX = 0, C_TRI, C_LEAFIDX, C_HIT, C_LIGHT, C_TEXEL, C_PRIMARY, C_
 constexpr int C_PUBLIC = C_N;
 constexpr int SC_OVERFLOW_WORD = 5 * 64 + 2;  // == SC_OVERFLOW of kernel_stream.h (static_assert there)
 
+// ---- what the host side (crt_scene.hip, crt_launch.hip, crt_abi.hip) reads of the kernels' layouts ----
+constexpr int MAX_GENERATIONS = 64;
+// layout of KernelArgs::s_counts (uint32): [g] rays of level g, [SC_FETCH + g] fetch cursor of level g
+//   [SC_HEAVY + g] rays evicted to the heavy kernel at level g, [SC_HEAVY_FETCH + g] / [SC_EVICT_FETCH + g] their cursors
+enum : int { SC_COUNT = 0, SC_FETCH = MAX_GENERATIONS, SC_HEAVY = 2 * MAX_GENERATIONS, SC_HEAVY_FETCH = 3 * MAX_GENERATIONS,
+             SC_EVICT_FETCH = 4 * MAX_GENERATIONS, SC_SHADOW = 5 * MAX_GENERATIONS, SC_SHADOW_FETCH, SC_OVERFLOW, SC_SHEAVY,
+             SC_SHEAVY_FETCH, SC_SHEAVY_FETCH2, SC_GUARD, SC_SHADOW_SPLIT, SC_SHADOW_FETCH2, SC_SHEAVY_SPLIT,
+             SC_WORDS,
+             SC_HEAVY_DIAG = 384,  // diagnostics of a collect_counters == 2 render (kernel_heavy.h): 8 words closest-hit walks, 8 words shadow walks
+             SC_ALLOC_WORDS = 512 };
+// kernel_bvh.h, the level queue's words (FrameArgs::s_lq_words): rays reserved / claimed / finished, and a copy of the overflow word for
+// the waves that wait -- 64 KB apart: hundreds of waves poll them, and words that share a memory channel share its request rate (with
+// each other and with the bulk shadow pass's cursor, were they in the counter block)
+enum : int { LQ_TAIL = 0, LQ_HEAD = 16384, LQ_DONE = 32768, LQ_ABORT = 49152, LQ_WORDS = 65536 };
+static_assert(SC_WORDS <= SC_HEAVY_DIAG, "counter block too small");
+
+static_assert(SC_OVERFLOW == SC_OVERFLOW_WORD, "kernel_common.h SC_OVERFLOW_WORD must match");
+constexpr int PLAN_LEAF_DWORDS = 16;                        // kernel_plan.h: one top-level leaf of the plan
+constexpr int PLAN_GROUP_LEAVES = 16, PLAN_GROUP_DWORDS = 8;  // ... and one group of the wide plan
+constexpr uint32_t BVH_LDS_STACK = 16;                      // kernel_bvh.h: entries of a walk's stack that live in LDS
+
 // constant address space: loads with a wave-uniform address become scalar loads (one s_load for the whole wave)
 typedef const float __attribute__((address_space(4))) *kfp;
 typedef const uint32_t __attribute__((address_space(4))) *ku32p;

@@ -30,12 +30,10 @@
 #include "kernel_walk.h"
 
 // one top-level leaf: {lo.xyz, first entry} {hi.xyz, entry count} {shadow mask words 0..3} {words 4..7}: 16 dwords, one s_load_dwordx16
-constexpr int PLAN_LEAF_DWORDS = 16;
 // The WIDE plan (more than 64 top-level leaves or meshes, up to 256 meshes): the leaves in groups of PLAN_GROUP_LEAVES consecutive
 // ones (visit order is spatial order) under their union box -- {lo.xyz, first leaf} {hi.xyz, leaves}, one s_load_dwordx8.  A ray
 // that passes a leaf's box passes any box containing it (the slab test is monotone, kernel_heavy.h), so a group none of the wave's
 // rays passes holds no leaf any of them passes: skipping it changes nothing.
-constexpr int PLAN_GROUP_LEAVES = 16, PLAN_GROUP_DWORDS = 8;
 typedef float v8f __attribute__((ext_vector_type(8)));
 typedef const __attribute__((address_space(4))) v8f *kv8p;
 __device__ __forceinline__ v8f plan_group(const KernelArgs &A, uint32_t g) {

@@ -36,22 +36,7 @@ enum : uint32_t { TN_CONST = 0, TN_DIFFUSE = 1, TN_REFLECT = 2, TN_REFRACT = 3, 
                   TN_GI = 0x400u, TN_GI_DONE_SHIFT = 16 };
 constexpr uint32_t CHILD_BG = 0xFFFFFFFFu;     // child ray beyond MAX_DEPTH: background without tracing (RayTracer.cpp:427-429)
 constexpr uint32_t CHILD_NONE = 0xFFFFFFFEu;   // total internal reflection: no refraction child (RayTracer.cpp:416)
-constexpr int MAX_GENERATIONS = 64;
-// layout of KernelArgs::s_counts (uint32): [g] rays of level g, [SC_FETCH + g] fetch cursor of level g
-//   [SC_HEAVY + g] rays evicted to the heavy kernel at level g, [SC_HEAVY_FETCH + g] / [SC_EVICT_FETCH + g] their cursors
-enum : int { SC_COUNT = 0, SC_FETCH = MAX_GENERATIONS, SC_HEAVY = 2 * MAX_GENERATIONS, SC_HEAVY_FETCH = 3 * MAX_GENERATIONS,
-             SC_EVICT_FETCH = 4 * MAX_GENERATIONS, SC_SHADOW = 5 * MAX_GENERATIONS, SC_SHADOW_FETCH, SC_OVERFLOW, SC_SHEAVY,
-             SC_SHEAVY_FETCH, SC_SHEAVY_FETCH2, SC_GUARD, SC_SHADOW_SPLIT, SC_SHADOW_FETCH2, SC_SHEAVY_SPLIT,
-             SC_WORDS,
-             SC_HEAVY_DIAG = 384,  // diagnostics of a collect_counters == 2 render (kernel_heavy.h): 8 words closest-hit walks, 8 words shadow walks
-             SC_ALLOC_WORDS = 512 };
-// kernel_bvh.h, the level queue's words (FrameArgs::s_lq_words): rays reserved / claimed / finished, and a copy of the overflow word for
-// the waves that wait -- 64 KB apart: hundreds of waves poll them, and words that share a memory channel share its request rate (with
-// each other and with the bulk shadow pass's cursor, were they in the counter block)
-enum : int { LQ_TAIL = 0, LQ_HEAD = 16384, LQ_DONE = 32768, LQ_ABORT = 49152, LQ_WORDS = 65536 };
-static_assert(SC_WORDS <= SC_HEAVY_DIAG, "counter block too small");
-
-static_assert(SC_OVERFLOW == SC_OVERFLOW_WORD, "kernel_common.h SC_OVERFLOW_WORD must match");
+// (MAX_GENERATIONS, the SC_* layout of the counter block and the level queue's LQ_* words: kernel_common.h -- the host side reads them too)
 
 // Level 0 holds level0_samples rays per pixel (the GI mode's RAYS_PER_PIXEL, RayTracer.cpp:90-104; otherwise one): ray r is
 // pixel r & 63 of work item (r >> 6) % n_items, sample (r >> 6) / n_items -- the samples are whole copies of the item list, so

@@ -127,7 +127,8 @@ typedef struct crt_scene_desc {
  * (AccelerationStructure.cpp:67-71).  The reference seeds that mode's generator from clock() ^ thread id (RayTracer.cpp:28-30):
  * only the distribution of its images is defined.  Here the random numbers come from a counter-based generator keyed by
  * (gi_seed, pixel, sample, position in the ray tree) -- csrc/gi_random.h -- so a frame is a function of its options, whatever
- * the device count or tile order; the GI mode is rendered pixel by pixel (csrc/kernel_lane.h), not by the ray-stream kernels. */
+ * the device count or tile order (the GI mode's frames go through the ray-stream kernels like any other: csrc/kernel_stream.h,
+ * csrc/kernel_plan.h; pixel by pixel -- csrc/kernel_lane.h -- only when level 0 does not fit 31-bit ray indices). */
 typedef struct crt_options {
     uint32_t max_depth;      /* MAX_DEPTH, default 5 */
     float shadow_bias;       /* SHADOW_BIAS, default 1e-4 */
@@ -319,6 +320,8 @@ int crt_get_executed_counters(crt_ctx *ctx, uint64_t out[4]);
  * They are NOT part of the counts above. */
 int crt_get_executed_plan_tests(crt_ctx *ctx, uint64_t out[2]);
 
+/* ---- Test hooks: exported by libcrt_hip_test.so only (the product's objects + csrc/crt_testhooks.hip; libcrt_hip.so has none of them):
+ * crt_test_pow5, crt_test_gi, crt_bvh_selftest, crt_debug_multi_force_staged, crt_debug_multi_fail_next_alloc. ---- */
 /* Test hook: out[i] = the device build of the restated glibc powf(x[i], 5) (the Fresnel term, RayTracer.cpp:407). */
 int crt_test_pow5(int device, const float *x, float *out, uint64_t n);
 /* Test hook for the GI mode's arithmetic (csrc/glibc_sincosf.h, csrc/gi_random.h), evaluated on `device`, or by the host

@@ -3,6 +3,8 @@ import os
 import sys
 
 import pytest
+
+os.environ.setdefault("CRT_TEST_HOOKS", "1")   # the package then loads libcrt_hip_test.so: the product's objects + the unit-test hooks
 # torch brings its own copy of the HIP runtime: when a test uses both torch.cuda and libcrt_hip.so in one process,
 # torch's copy has to be the first one loaded (the other order leaves torch with "No HIP GPUs are available")
 import torch  # noqa: F401

@@ -28,6 +28,15 @@ def test_library_exports_every_declared_symbol(pkg, header):
         assert hasattr(lib, name), "%s declared in include/%s is not exported" % (name, header)
 
 
+def test_the_product_library_exports_no_test_hook(pkg):
+    """libcrt_hip.so (what crt_main, crt_animation and bench.py load) is the test flavour minus the hooks."""
+    plain = C.CDLL(os.path.join(os.path.dirname(pkg.LIB_PATH), "libcrt_hip.so"))
+    for name in declared_functions("crt_hip.h"):
+        assert hasattr(plain, name) == (name not in pkg.TEST_HOOK_SYMBOLS), name
+    for name in pkg.TEST_HOOK_SYMBOLS:
+        assert hasattr(pkg.lib(), name)
+
+
 def test_python_symbol_lists_match_headers(pkg):
     assert sorted(pkg.DEVICE_SYMBOLS) == declared_functions("crt_hip.h")
     assert sorted(pkg.HOST_SYMBOLS) == sorted(set(declared_functions("crt_host.h")) - set(declared_functions("crt_hip.h")))

@@ -12,6 +12,7 @@ depth = sc.CONFIGS[name][3]
 opts = pkg.make_options(depth)
 dev = torch.device('cuda', 0)
 worlds = [int(w) for w in sys.argv[2].split(',')] if len(sys.argv) > 2 else [1, 2, 4, 8]
+base_ms = None
 for world in worlds:
     per = tiles.tiles_per_rank(tr.width, tr.height, world)
     buf = torch.zeros(per * 192, dtype=torch.float32, device=dev)
@@ -24,5 +25,6 @@ for world in worlds:
         tr.render_tiles_device(opts, 0, world, buf.data_ptr())
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / n * 1e3
-    print('world %d: rank 0 renders its share in %.2f ms -> %.1f Mpx/s whole job, efficiency %.2f' % (world, ms, tr.width * tr.height / ms / 1e3, 0), flush=True)
+    base_ms = base_ms or ms * world
+    print('world %d: rank 0 renders its share in %.2f ms -> %.1f Mpx/s whole job before the gather, strong-scaling ceiling %.2f' % (world, ms, tr.width * tr.height / ms / 1e3, base_ms / (ms * world)), flush=True)
     print('   phases', ['%.2f' % x for x in tr.kernel_times_ms(1)[-1]])

@@ -1,5 +1,5 @@
 // Dev tool (GPU box): how many scalar ALU instructions does a CU of gfx950 issue per clock?  Waves that do nothing but independent
-// s_add_u32 -- one wave per SIMD, then two, four -- timed with HIP events; the clock from s_memrealtime (100 MHz) against s_memtime.
+// s_add_u32 -- one wave per SIMD, then two, four -- timed with HIP events; the clock from clock64 against the 100 MHz wall_clock64.
 //   hipcc --offload-arch=gfx950 -O2 tools/salu_rate.hip -o course-assignment-danielhalachev_amd/build/salu_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -13,17 +13,19 @@ __global__ void salu_chain(uint32_t *out, int iters) {
                      : "+s"(a), "+s"(b), "+s"(c), "+s"(d), "+s"(e), "+s"(f), "+s"(g), "+s"(h));
     if (threadIdx.x == 0) out[blockIdx.x] = a + b + c + d + e + f + g + h;
 }
-__global__ void clock_probe(unsigned long long *out) {
-    const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - r0 < 100000ull) {}   // 1 ms at 100 MHz
-    out[0] = __builtin_readcyclecounter() - t0; out[1] = __builtin_amdgcn_s_memrealtime() - r0;
+__global__ void clock_probe(unsigned long long *out, uint32_t *sink) {
+    // shader clocks (clock64) against the 100 MHz wall clock (wall_clock64) over a BOUNDED loop
+    const unsigned long long t0 = clock64(), r0 = wall_clock64();
+    uint32_t a = 1;
+    for (int i = 0; i < 200000; i++) asm volatile("s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1" : "+s"(a));
+    out[0] = clock64() - t0; out[1] = wall_clock64() - r0; sink[0] = a;
 }
 int main() {
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
     const int cus = p.multiProcessorCount, iters = 20000;
     uint32_t *out; hipMalloc(&out, 1 << 20);
     unsigned long long *clk; hipMalloc(&clk, 16);
-    hipLaunchKernelGGL(clock_probe, dim3(1), dim3(64), 0, 0, clk);
+    hipLaunchKernelGGL(clock_probe, dim3(1), dim3(64), 0, 0, clk, out);
     unsigned long long hc[2]; hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost);
     const double ghz = (double)hc[0] / ((double)hc[1] * 10.0);   // cycles per ns
     printf("CUs %d, shader clock while spinning %.3f GHz\n", cus, ghz);
