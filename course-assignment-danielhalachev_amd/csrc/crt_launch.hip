@@ -145,11 +145,7 @@ static bool grow_queue_sizing(crt_ctx *ctx, uint32_t vitems, uint32_t max_depth)
     const double shadows = (double)c[SC_SHADOW] * (total / known);
     double node_mult = std::max(ctx->node_mult, total * 1.25 / px), ray_mult = std::max(ctx->ray_mult, widest * 1.25 / px);
     double shadow_extra = std::max(ctx->shadow_extra, shadows * 1.25 / (px * lights) - 1.0);
-    if (ctx->scene.bvh_ok && ctx->tuning.bvh && ctx->tuning.level_queue && !ctx->frame.use_gi) {
-        // a frame of the level queue (kernel_bvh.h) that ran out stopped in the middle of ALL its levels at once: its counts are no
-        // level-by-level record to extrapolate from.  Four times everything; an attempt that still does not fit quadruples again.
-        node_mult = ctx->node_mult * 4.0; ray_mult = ctx->ray_mult * 4.0; shadow_extra = std::max(1.0, ctx->shadow_extra) * 4.0;
-    }
+
     if (node_mult == ctx->node_mult && ray_mult == ctx->ray_mult && shadow_extra == ctx->shadow_extra) {
         node_mult *= 2.0; ray_mult *= 2.0; shadow_extra = std::max(0.5, shadow_extra * 2.0);  // (the counters explain nothing: an eviction list, say)
     }
@@ -398,7 +394,8 @@ static int launch_stream_tail(crt_ctx *ctx, FramePlan &P, KernelArgs &A, hipStre
         const uint32_t cap1 = std::max(level_budget, ctx->tuning.shadow_budget);
         S1.step_budget = P.heavy ? (est1 >= cap1 ? cap1 : (est1 < 64u ? 64u : (uint32_t)est1)) : 0u;
     }
-    if (P.bvh) {
+    if (P.queue) {}   // (the level queue's lanes have walked the deeper levels' shadow rays themselves: kernel_bvh.h, BVH_SHADOWS)
+    else if (P.bvh) {
         if (P.exec_count) launch(bvh_trace_shadow<1, BVH_TALLY>, P.lane_blocks, stream, S1);
         else if (ctx->tuning.bvh == 2) launch(bvh_trace_shadow<1, BVH_CHECKED>, P.lane_blocks, stream, S1);
         else launch(bvh_trace_shadow<1, BVH_PLAIN>, P.lane_blocks, stream, S1);
@@ -508,7 +505,17 @@ static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, fl
     const bool wide = lean && !SC.plan_ok;  // the wide plan (kernel_plan.h): more than 64 top-level leaves or meshes
     // the filter kernels (kernel_bvh.h): whenever the scene has a filter -- they need nothing of the plan or of the wave-per-ray kernels
     const bool bvh = stream_mode && SC.bvh_ok && ctx->tuning.bvh && !gi && !count;
-    const bool queue = bvh && ctx->tuning.level_queue;
+    // ... the levels below level 0 as one self-feeding launch -- once a frame of this size is known to fit its queues: an attempt that
+    // PROBES them (launch_render) runs level by level, because a level-by-level run that overflows leaves the counts the next attempt is
+    // sized from, where the level queue stops in the middle of all its levels at once (same pixels either way)
+    // And only where it pays: the queue trades launches and their tails (latency) for hand-overs through memory (throughput).  A frame whose
+    // levels hold hundreds of thousands of rays each is throughput -- a mirror room at 1080p: 11.5 ms level by level, 20 ms through the queue;
+    // HW12 at 3840x2160 (229 k rays per level): the same either way; HW14 / HW11 (20 - 85 k): 4.1 -> 3.3, 5.2 -> 4.0 ms -- so the widest
+    // level of the last completed frame of this size decides.
+    uint32_t widest = 0;
+    if (ctx->last_counts_items == vitems && ctx->last_counts_cfg == frame_config_of(o))
+        for (uint32_t g = 1; g <= o->max_depth && g < (uint32_t)MAX_GENERATIONS; g++) widest = std::max(widest, ctx->last_counts[SC_COUNT + g]);
+    const bool queue = bvh && ctx->tuning.level_queue && last_resort && (widest <= 250000u || ctx->tuning.level_queue >= 16u);
     g_debug_sync = ctx->tuning.bvh == 3 ? 1 : 0;
     if (g_debug_sync) fprintf(stderr, "[frame] bvh_trace_shade %p tally %p checked %p shadow0 %p shadow1 %p heavy_closest %p shade_evicted %p resolve %p heavy_shadow %p\n",
                               (void *)bvh_trace_shade, (void *)bvh_trace_shade_tally, (void *)bvh_trace_shade_checked, (void *)bvh_trace_shadow<0, BVH_PLAIN>,

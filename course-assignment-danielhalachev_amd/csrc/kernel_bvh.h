@@ -297,7 +297,9 @@ __device__ __forceinline__ bool bvh_step(const KernelArgs &A, const Ray &R, cons
 }
 
 // a lane: wants a ray; walks it through the filter; nothing left to fetch; its walk has ended; checks the miss its walk ended with
-enum : int { BVH_FETCH = 0, BVH_WALK = 1, BVH_OUT = 2, BVH_FINISHED = 3, BVH_MISS_CHECK = 4, BVH_WAIT = 5 };   // (WAIT: for the record of the ray it has claimed, bvh_trace_queue)
+enum : int { BVH_FETCH = 0, BVH_WALK = 1, BVH_OUT = 2, BVH_FINISHED = 3, BVH_MISS_CHECK = 4,
+             BVH_WAIT = 5,       // bvh_trace_queue: for the record of the ray it has claimed
+             BVH_SHADOWS = 6 };  // bvh_trace_queue: walks the shadow rays of the diffuse hit it has just shaded
 
 // The miss check's view of the ray: its whole LINE (the reference's slab test has no t >= 0, BoundingBox.h:85-108), with the reference's
 // notion of a parallel axis -- |d| < FLT_EPSILON is a containment test there (BoundingBox.h:90-93) -- kept as a superset: such a
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(BLOCK) void bvh_trace_shade_checked(const KernelArg
     bvh_shade_level<BVH_CHECKED>(A, gen, stack_lds);
 }
 template <int MODE>
-__global__ __launch_bounds__(BLOCK) void bvh_trace_level0(const KernelArgs A) {
+__global__ __launch_bounds__(BLOCK) void bvh_trace_level0(const KernelArgs A) {   // (bounded to 128 VGPRs for four waves per SIMD: 2 spills, 3.40 vs 3.31 ms)
     __shared__ uint32_t stack_lds[BVH_LDS_STACK * BLOCK];
     bvh_shade_level<MODE, true>(A, 0u, stack_lds);
 }
@@ -502,13 +504,19 @@ __device__ __forceinline__ void bvh_queue_levels(const KernelArgs &A, uint32_t *
     bvh_walk_begin(W, INFINITY);
     int state = BVH_FETCH;
     uint32_t r = 0, gen = 1, spins = 0, idle_polls = 0;
+    // the shadow rays of a diffuse hit are walked by the lane that shaded it, one light after the other (they have no children: nothing to
+    // hand over, and no launch of their own behind the queue): first slot and stride in the shadow queue, light in turn, walk under way?
+    uint32_t sh_first = 0, sh_stride = 0, sh_li = 0, sh_slot = 0;
+    bool sh_walking = false;
+    float light_dist = 0;
+    const uint32_t n_lights = A.s->n_lights;
     for (;;) {
         if (++spins > (1u << 20)) { A.f->s_counts[SC_GUARD] = 1; A.f->s_counts[SC_OVERFLOW] = 1; __hip_atomic_store(ovf_p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         const unsigned long long fin = __ballot(state == BVH_FINISHED), idle = __ballot(state == BVH_FETCH);
-        const bool walking = __ballot(state == BVH_WALK || state == BVH_MISS_CHECK) != 0;
+        const bool walking = __ballot(state == BVH_WALK || state == BVH_MISS_CHECK || state == BVH_SHADOWS) != 0;
         // a round of housekeeping -- shading, counting, claiming -- costs the lanes that walk two round trips to the queue's words: when
         // enough walks have finished, when nothing (or little) walks, and otherwise, for the idle lanes' sake, every sixteenth turn
-        const uint32_t n_walk = (uint32_t)__popcll(__ballot(state == BVH_WALK || state == BVH_MISS_CHECK));
+        const uint32_t n_walk = (uint32_t)__popcll(__ballot(state == BVH_WALK || state == BVH_MISS_CHECK || state == BVH_SHADOWS));
         if ((uint32_t)__popcll(fin) >= BVH_BATCH || !walking || (fin && n_walk <= 8u) || ((fin | idle) && (spins & A.bundle) == 0u)) {
             if (state == BVH_FINISHED) {
                 if (MODE == BVH_TALLY && gen < 10u) {
@@ -516,8 +524,10 @@ __device__ __forceinline__ void bvh_queue_levels(const KernelArgs &A, uint32_t *
                     atomicMax(dg + 0, W.steps); atomicAdd(dg + 1, W.steps); atomicAdd(dg + 2, 1u);
                 }
                 if (W.give_up) { A.f->s_counts[SC_GUARD] = 1; A.f->s_counts[SC_OVERFLOW] = 1; __hip_atomic_store(ovf_p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                shade_and_emit<false, false, true>(A, gen, r, count0, count0, R, W.have, W.best, W.btri, W.bmesh, nullptr, lane);
-                state = BVH_FETCH;
+                bool diffuse = false;
+                shade_and_emit<false, false, true>(A, gen, r, count0, count0, R, W.have, W.best, W.btri, W.bmesh, nullptr, lane, &diffuse, &sh_first, &sh_stride);
+                state = (diffuse && n_lights) ? BVH_SHADOWS : BVH_FETCH;
+                sh_li = 0; sh_walking = false;
             }
             // (the children's reservations above have returned: the finished rays may count as done)
             uint32_t t = 0, h = 0;
@@ -567,7 +577,34 @@ __device__ __forceinline__ void bvh_queue_levels(const KernelArgs &A, uint32_t *
             }
         }
         if (!__ballot(state != BVH_OUT)) break;
-        if (!__ballot(state == BVH_WALK || state == BVH_MISS_CHECK || state == BVH_FINISHED)) {   // only waiting: poll gently, and ever more gently
+        if (state == BVH_SHADOWS) {
+            if (!sh_walking) {   // the next light's ray, as shade_hit queued it
+                sh_slot = sh_first + sh_li * sh_stride;
+                const float4 q0 = A.f->s_shadowq[2 * (size_t)sh_slot], q1 = A.f->s_shadowq[2 * (size_t)sh_slot + 1];
+                if (q1.w == 0.0f) {   // a light behind the surface: no walk (kernel_plan.h has the argument)
+                    A.f->s_occluded[sh_slot] = 0;
+                    if (++sh_li == n_lights) state = BVH_FETCH;
+                } else {
+                    R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
+                    R.dx = q1.x; R.dy = q1.y; R.dz = q1.z;
+                    ray_prepare(R);
+                    light_dist = q0.w;
+                    bvh_walk_begin(W, light_dist * (1.0f + 0x1p-16f));
+                    if (bvh_ray_setup(A, R, W.B)) sh_walking = true;
+                    else { A.f->s_counts[SC_GUARD] = 1; A.f->s_counts[SC_OVERFLOW] = 1; A.f->s_occluded[sh_slot] = 0; if (++sh_li == n_lights) state = BVH_FETCH; }
+                }
+            }
+            if (state == BVH_SHADOWS && sh_walking) {
+                for (int it = 0; it < BVH_STEPS; ++it)
+                    if (sh_walking && !bvh_step<true, MODE>(A, R, false, light_dist, false, W, stack, nbox, ntri)) {
+                        if (W.give_up) { A.f->s_counts[SC_GUARD] = 1; A.f->s_counts[SC_OVERFLOW] = 1; }
+                        A.f->s_occluded[sh_slot] = W.have ? 1 : 0;
+                        sh_walking = false;
+                        if (++sh_li == n_lights) state = BVH_FETCH;
+                    }
+            }
+        }
+        if (!__ballot(state == BVH_WALK || state == BVH_MISS_CHECK || state == BVH_FINISHED || state == BVH_SHADOWS)) {   // only waiting: poll gently, and ever more gently
             __builtin_amdgcn_s_sleep(127);
             if (idle_polls >= 1u) __builtin_amdgcn_s_sleep(127);
             if (idle_polls >= 2u) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }

@@ -195,7 +195,9 @@ typedef struct crt_tuning {
     uint32_t bvh;             /* 1: rays are walked through the candidate filter (csrc/crt_bvh.h, csrc/kernel_bvh.h) where the scene has one;
                                * 0: by the reference-order kernels alone; 2: the filter kernels' bounds-checked build (development) */
     uint32_t level_queue;     /* 2: with the filter kernels, every recursion level below level 0 in ONE launch that feeds itself through a queue
-                               * (csrc/kernel_bvh.h: bvh_trace_queue), on this many workgroups per CU; 0: one launch per level */
+                               * (csrc/kernel_bvh.h: bvh_trace_queue), on this many workgroups per CU -- for frames whose levels held at most
+                               * 250 k rays each a frame ago (wider levels are throughput: one launch per level is as fast or faster);
+                               * 0: always one launch per level */
 } crt_tuning;
 void crt_tuning_defaults(crt_tuning *tuning);
 
