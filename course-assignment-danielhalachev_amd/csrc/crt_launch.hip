@@ -250,6 +250,7 @@ struct FramePlan {
     bool heavy, lean, wide;       // wave-per-ray kernels on; plan kernels; the wide plan
     bool bvh;                     // the filter kernels (kernel_bvh.h) walk the rays
     bool queue;                   // ... and every level below level 0 is one launch (bvh_trace_queue)
+    uint32_t widest;              // rays of the widest level below level 0 a frame ago (0: not known)
     uint32_t level_budget;        // steps after which a deeper level's per-lane walk is evicted
     const uint32_t *prev;         // counters of a completed frame of this size and kind, or null
     bool last_resort;             // render_lanes behind the stream pass
@@ -360,7 +361,11 @@ static int launch_stream_levels(crt_ctx *ctx, const crt_options *o, FramePlan &P
         if (P.queue) {
             // every level below level 0: one launch that feeds itself (kernel_bvh.h); two workgroups per CU hold more lanes than the
             // widest level of a frame of this size has rays
-            const uint32_t qblocks = std::min(P.lane_blocks, (uint32_t)ctx->num_cus * std::max(1u, ctx->tuning.level_queue));
+            const uint32_t qblocks = std::min(P.lane_blocks, (uint32_t)ctx->num_cus * std::max(1u, ctx->tuning.level_queue & 15u));
+            // A reflection child continues in the lane that shaded its parent (no hand-over through memory) where the launch is a matter of
+            // latency -- few rays: HW14 3.37 -> 3.29 ms, an eighth of its tiles 2.25 -> 2.04 -- and goes through the queue like the others where
+            // it is a matter of balance (HW11, 65 - 85 k rays per level: 4.0 ms through the queue, 4.5 with chains kept in their lanes)
+            A.force_whole = (P.widest > 70000u || (ctx->tuning.level_queue & 256u)) ? 1u : 0u;
             if (o->max_depth >= 1) {
                 A.bundle = ctx->tuning.level0_budget ? ctx->tuning.level0_budget - 1u : 15u;   // (development: turns between two housekeeping rounds, as a mask)
                 if (P.exec_count) launch(bvh_trace_queue<BVH_TALLY>, qblocks, stream, A);
@@ -515,7 +520,7 @@ static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, fl
     uint32_t widest = 0;
     if (ctx->last_counts_items == vitems && ctx->last_counts_cfg == frame_config_of(o))
         for (uint32_t g = 1; g <= o->max_depth && g < (uint32_t)MAX_GENERATIONS; g++) widest = std::max(widest, ctx->last_counts[SC_COUNT + g]);
-    const bool queue = bvh && ctx->tuning.level_queue && last_resort && (widest <= 250000u || ctx->tuning.level_queue >= 16u);
+    const bool queue = bvh && ctx->tuning.level_queue && last_resort && widest <= 250000u;
     g_debug_sync = ctx->tuning.bvh == 3 ? 1 : 0;
     if (g_debug_sync) fprintf(stderr, "[frame] bvh_trace_shade %p tally %p checked %p shadow0 %p shadow1 %p heavy_closest %p shade_evicted %p resolve %p heavy_shadow %p\n",
                               (void *)bvh_trace_shade, (void *)bvh_trace_shade_tally, (void *)bvh_trace_shade_checked, (void *)bvh_trace_shadow<0, BVH_PLAIN>,
@@ -534,7 +539,7 @@ static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, fl
     A.s = (scene_args_p)ctx->d_scene;
     A.f = (frame_args_p)(ctx->d_frame_ring + slot);
     A.counters = ctx->d_counters;
-    FramePlan P{slot, n_items, vitems, lane_blocks, gi, count, exec_count, heavy, lean, wide, bvh, queue, 0u, nullptr, last_resort};
+    FramePlan P{slot, n_items, vitems, lane_blocks, gi, count, exec_count, heavy, lean, wide, bvh, queue, widest, 0u, nullptr, last_resort};
     rc = stream_mode ? launch_stream_levels(ctx, o, P, A, stream) : launch_lanes_pass(ctx, P, A, stream);
     if (rc == CRT_OK && stream_mode) rc = launch_stream_tail(ctx, P, A, stream);
     if (rc) return rc;

@@ -525,9 +525,22 @@ __device__ __forceinline__ void bvh_queue_levels(const KernelArgs &A, uint32_t *
                 }
                 if (W.give_up) { A.f->s_counts[SC_GUARD] = 1; A.f->s_counts[SC_OVERFLOW] = 1; __hip_atomic_store(ovf_p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                 bool diffuse = false;
-                shade_and_emit<false, false, true>(A, gen, r, count0, count0, R, W.have, W.best, W.btri, W.bmesh, nullptr, lane, &diffuse, &sh_first, &sh_stride);
+                float keep[6];
+                uint32_t keep_index = NONE;
+                shade_and_emit<false, false, true>(A, gen, r, count0, count0, R, W.have, W.best, W.btri, W.bmesh, nullptr, lane, &diffuse, &sh_first, &sh_stride,
+                                                   A.force_whole ? nullptr : keep, &keep_index);   // (force_whole: every child through the queue, crt_tuning::level_queue | 256)
                 state = (diffuse && n_lights) ? BVH_SHADOWS : BVH_FETCH;
                 sh_li = 0; sh_walking = false;
+                if (keep_index != NONE) {
+                    // the reflection child goes on in this lane: no hand-over through memory for the chain it heads (its entry is marked taken)
+                    r = keep_index; gen = gen + 1u;
+                    R.ox = keep[0]; R.oy = keep[1]; R.oz = keep[2]; R.dx = keep[3]; R.dy = keep[4]; R.dz = keep[5];
+                    normalize3(R.dx, R.dy, R.dz);  // shootRay entry (RayTracer.cpp:420)
+                    ray_prepare(R);
+                    bvh_walk_begin(W, INFINITY);
+                    if (bvh_ray_setup(A, R, W.B)) state = BVH_WALK;
+                    else { W.give_up = true; state = BVH_FINISHED; }
+                }
             }
             // (the children's reservations above have returned: the finished rays may count as done)
             uint32_t t = 0, h = 0;
@@ -567,7 +580,9 @@ __device__ __forceinline__ void bvh_queue_levels(const KernelArgs &A, uint32_t *
         }
         if (state == BVH_WAIT) {   // is my ray there?
             uint32_t level = 0;
-            if (lq_load_ray(A, r, R.ox, R.oy, R.oz, R.dx, R.dy, R.dz, level)) {
+            const int what = lq_load_ray(A, r, R.ox, R.oy, R.oz, R.dx, R.dy, R.dz, level);
+            if (what == LQ_TAKEN) state = BVH_FETCH;   // its parent's lane walks it: nothing to do (and nothing to count) here
+            if (what == LQ_RAY) {
                 gen = level;
                 normalize3(R.dx, R.dy, R.dz);  // shootRay entry (RayTracer.cpp:420)
                 ray_prepare(R);

@@ -280,11 +280,20 @@ __device__ __forceinline__ void lq_store_ray(const KernelArgs &A, const uint32_t
 #pragma unroll
     for (int k = 0; k < 8; k++) __hip_atomic_store(g + k, tag | v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// false: not (yet) there (one granule is looked at first: a lane that waits for its record asks for eight bytes per look, not sixty-four)
-__device__ __forceinline__ bool lq_load_ray(const KernelArgs &A, const uint32_t index, float &ox, float &oy, float &oz, float &dx, float &dy,
-                                            float &dz, uint32_t &level) {
+// An entry whose ray its parent's lane walks itself (bvh_trace_queue: the reflection child continues in the lane that shaded the hit): the
+// entry exists -- it owns the ray's node and is counted -- but whoever claims it has nothing to do: granule 7 carries the mark.
+__device__ __forceinline__ void lq_store_taken(const KernelArgs &A, const uint32_t index) {
     lq_ptr g = (lq_ptr)(A.f->s_lq + 8 * (size_t)index);
-    if ((uint32_t)(__hip_atomic_load(g + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) != A.f->lq_epoch) return false;
+    __hip_atomic_store(g + 7, ((unsigned long long)A.f->lq_epoch << 32) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+enum : int { LQ_NOT_YET = 0, LQ_RAY = 1, LQ_TAKEN = 2 };
+// (one granule is looked at first: a lane that waits for its record asks for eight bytes per look, not sixty-four)
+__device__ __forceinline__ int lq_load_ray(const KernelArgs &A, const uint32_t index, float &ox, float &oy, float &oz, float &dx, float &dy,
+                                           float &dz, uint32_t &level) {
+    lq_ptr g = (lq_ptr)(A.f->s_lq + 8 * (size_t)index);
+    const unsigned long long g7 = __hip_atomic_load(g + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)(g7 >> 32) != A.f->lq_epoch) return LQ_NOT_YET;
+    if ((uint32_t)g7 == 1u) return LQ_TAKEN;
     unsigned long long x[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) x[k] = __hip_atomic_load(g + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -293,7 +302,7 @@ __device__ __forceinline__ bool lq_load_ray(const KernelArgs &A, const uint32_t 
     for (int k = 0; k < 8; k++) ok = ok && (uint32_t)(x[k] >> 32) == A.f->lq_epoch;
     ox = __uint_as_float((uint32_t)x[0]); oy = __uint_as_float((uint32_t)x[1]); oz = __uint_as_float((uint32_t)x[2]); level = (uint32_t)x[3];
     dx = __uint_as_float((uint32_t)x[4]); dy = __uint_as_float((uint32_t)x[5]); dz = __uint_as_float((uint32_t)x[6]);
-    return ok;
+    return ok ? LQ_RAY : LQ_NOT_YET;
 }
 
 // shade_hit + the per-level queues: ray `r` of level `gen` writes node node_base + r, its children are appended to the
@@ -304,7 +313,11 @@ template <bool COUNT, bool GI, bool LQ = false>
 __device__ __forceinline__ void shade_and_emit(const KernelArgs &A, const uint32_t gen, const uint32_t r, const uint32_t node_base,
                                        const uint32_t child_base, const Ray &R, const bool have, const float bt,
                                        const uint32_t btri, const uint32_t bmesh, uint32_t *cnt, const uint32_t lane,
-                                       bool *out_diffuse = nullptr, uint32_t *out_first = nullptr, uint32_t *out_stride = nullptr) {
+                                       bool *out_diffuse = nullptr, uint32_t *out_first = nullptr, uint32_t *out_stride = nullptr,
+                                       float *keep = nullptr, uint32_t *keep_index = nullptr) {
+    // keep (level queue only): the reflection child is not written to the queue -- its entry is marked taken -- but handed back to the
+    // caller, whose lane walks it next: {origin, direction} in keep[0..5], its entry in *keep_index (NONE: there is no such child)
+    if (keep_index) *keep_index = NONE;
     Shaded E;
     shade_hit<COUNT, GI>(A, gen, r, R, have, bt, btri, bmesh, cnt, lane, E, out_diffuse, out_first, out_stride);
     constexpr bool gi_mode = GI;
@@ -340,7 +353,13 @@ __device__ __forceinline__ void shade_and_emit(const KernelArgs &A, const uint32
             A.f->s_counts[SC_OVERFLOW] = 1;
         } else if (E.reflect) {
             const uint32_t i1 = base + (uint32_t)__popcll(m1 & below);
-            if constexpr (LQ) lq_store_ray(A, i1, E.rox, E.roy, E.roz, E.rdx, E.rdy, E.rdz, gen + 1u);
+            if constexpr (LQ) {
+                if (keep) {
+                    lq_store_taken(A, i1);
+                    keep[0] = E.rox; keep[1] = E.roy; keep[2] = E.roz; keep[3] = E.rdx; keep[4] = E.rdy; keep[5] = E.rdz;
+                    *keep_index = i1;
+                } else lq_store_ray(A, i1, E.rox, E.roy, E.roz, E.rdx, E.rdy, E.rdz, gen + 1u);
+            }
             else store_child_ray(out_q, i1, E.rox, E.roy, E.roz, E.rdx, E.rdy, E.rdz, gi_mode ? crt_gi_child_key(key, 0u) : gen + 1u, child_base + i1);
             E.N.a = child_base + i1;
             if (E.transmit) {

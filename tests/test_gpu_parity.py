@@ -62,6 +62,7 @@ KERNEL_PATHS = [
     dict(bvh=1, side_blocks=4, level_queue=1),                   # ... the bulk shadow pass on four workgroups per CU, the queue on one
     dict(bvh=2),                                                 # ... their bounds-checked build
     dict(bvh=1, level_queue=0),                                  # ... one launch per level
+    dict(bvh=1, level_queue=258),                                # ... every child ray through the queue (none continues in its parent's lane)
     dict(bvh=2, level_queue=0, side_blocks=0),
     dict(bvh=0),                                                 # the reference-order kernels: plan kernels + wave-per-ray kernels
     dict(bvh=0, step_budget=8, shadow_budget=8, level0_budget=8),       # nearly every walk through the wave-per-ray kernels
