@@ -107,7 +107,7 @@ class Tuning(C.Structure):
     """crt_tuning (include/crt_hip.h): kernel selection and sizing; no setting changes a pixel."""
     _fields_ = [(n, C.c_uint32) for n in (
         "size", "mode", "step_budget", "shadow_budget", "level0_budget", "heavy_level", "side_blocks",
-        "node_cap", "ray_cap", "shadow_cap", "bvh", "level_queue")]
+        "node_cap", "ray_cap", "shadow_cap", "bvh", "level_queue", "fetch_chunk")]
 
 
 def make_tuning(**fields):

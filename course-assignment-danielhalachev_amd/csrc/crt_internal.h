@@ -72,6 +72,8 @@ struct crt_ctx {
     uint32_t *d_lq_words = nullptr;       // ... and its counters (kernel_stream.h: LQ_*)
     uint32_t *d_bvh_spill = nullptr;  // kernel_bvh.h: the walks' stacks beyond their LDS part: one region for the caller's stream, one for the side stream
     hipStream_t side = nullptr;       // shadow pass 0 overlaps the deeper recursion levels on this stream
+    hipStream_t early = nullptr;      // the level queue's launch starts WITH level 0 on this one (crt_launch.hip)
+    hipEvent_t ev_reset[EV_RING] = {}, ev_queue[EV_RING] = {};   // the frame's counters are zeroed / the level queue's launch has ended
     // What a finished frame tells the next ones (queue sizing, launch sizes, fallback count): every frame copies its counter
     // block and the fallback total to ITS slot of this pinned ring, and the host reads a slot only once that frame's last
     // event has completed (harvest_counts), so launch decisions are a function of a completed frame, never of a copy in flight.

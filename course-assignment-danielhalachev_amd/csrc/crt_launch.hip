@@ -259,7 +259,7 @@ struct FramePlan {
 // Levels 0 .. MAX_DEPTH on `stream`; after level 0 the bulk shadow pass (and the walks it gives up) on the side stream.
 static int launch_stream_levels(crt_ctx *ctx, const crt_options *o, FramePlan &P, KernelArgs &A, hipStream_t stream) {
     CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_scounts, 0, SC_ALLOC_WORDS * sizeof(uint32_t), stream));
-    if (P.queue) for (int w : {LQ_TAIL, LQ_HEAD, LQ_DONE, LQ_ABORT}) CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_lq_words + w, 0, 16, stream));
+    if (P.queue) for (int w : {LQ_TAIL, LQ_HEAD, LQ_DONE, LQ_ABORT, LQ_LEVEL0}) CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_lq_words + w, 0, 16, stream));
     const uint32_t side_per_cu = ctx->tuning.side_blocks;  // workgroups per CU of the bulk shadow pass beside the levels
     A.exec_count = P.exec_count ? 1u : 0u;
     A.exec_counters = ctx->d_exec;
@@ -271,8 +271,10 @@ static int launch_stream_levels(crt_ctx *ctx, const crt_options *o, FramePlan &P
     A.force_whole = 0u;
     if (ctx->frame.fixed0) CRT_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->d_scounts + SC_SHADOW), (int)((uint32_t)P.vitems * 64u * ctx->n_lights), 1, stream));
     const uint32_t plds = ctx->scene.plan_list_words * BLOCK * (uint32_t)sizeof(uint32_t);  // kernel_plan.h: mesh lists
+    A.chunk = ctx->tuning.fetch_chunk >> 16;   // (level 0's claims; crt_tuning::fetch_chunk)
     KernelArgs S = A;  // argument block of the bulk shadow pass
     S.wave_prio = 0u;
+    S.chunk = ctx->tuning.fetch_chunk & 0xFFFFu;
     S.counters = ctx->d_counters + C_N;
     S.exec_counters = ctx->d_exec + 2;  // it tallies on its own
     S.exec_plan = ctx->d_exec + 5;
@@ -298,6 +300,21 @@ static int launch_stream_levels(crt_ctx *ctx, const crt_options *o, FramePlan &P
     const uint64_t est0 = (uint64_t)P.vitems * 64u * 70u / ((uint64_t)P.lane_blocks * BLOCK);
     uint32_t budget0 = est0 >= level_budget ? level_budget : (est0 < 64u ? 64u : (uint32_t)est0);
     if (ctx->tuning.level0_budget) budget0 = ctx->tuning.level0_budget;
+    // every level below level 0: one launch that feeds itself (kernel_bvh.h); one workgroup per CU holds more lanes than the widest
+    // level of a frame of this size has rays
+    const bool early_queue = P.queue && side_per_cu && !(ctx->tuning.level_queue & 512u) && !g_debug_sync;   // (level_queue bit 9: the launch behind level 0, as it used to be)
+    auto launch_queue = [&](hipStream_t where) {
+        KernelArgs Q = A;
+        const uint32_t qblocks = std::min(P.lane_blocks, (uint32_t)ctx->num_cus * std::max(1u, ctx->tuning.level_queue & 15u));
+        // A reflection child continues in the lane that shaded its parent (no hand-over through memory) where the launch is a matter of
+        // latency -- few rays: HW14 3.37 -> 3.29 ms, an eighth of its tiles 2.25 -> 2.04 -- and goes through the queue like the others where
+        // it is a matter of balance (HW11, 65 - 85 k rays per level: 4.0 ms through the queue, 4.5 with chains kept in their lanes)
+        Q.force_whole = (P.widest > 70000u || (ctx->tuning.level_queue & 256u)) ? 1u : 0u;
+        Q.bundle = ctx->tuning.level0_budget ? ctx->tuning.level0_budget - 1u : 15u;   // (development: turns between two housekeeping rounds, as a mask)
+        if (P.exec_count) launch(bvh_trace_queue<BVH_TALLY>, qblocks, where, Q);
+        else if (ctx->tuning.bvh == 2) launch(bvh_trace_queue<BVH_CHECKED>, qblocks, where, Q);
+        else launch(bvh_trace_queue<BVH_PLAIN>, qblocks, where, Q);
+    };
     for (uint32_t g = 0; g <= o->max_depth; g++) {
         A.step_budget = P.heavy ? (g == 0 ? budget0 : level_budget) : 0u;
         // The per-lane kernel of a deeper level fetches its rays through a cursor, so any grid does the whole level; beside
@@ -310,6 +327,14 @@ static int launch_stream_levels(crt_ctx *ctx, const crt_options *o, FramePlan &P
             level_blocks = std::min(P.lane_blocks, want);
         }
         if (P.queue && g == 0) {
+            // The level queue's launch starts WITH level 0, on a stream of its own: its waves sleep until level 0's first reflective or
+            // refractive hits reserve entries, and a pixel's chain of up to eight dependent walks -- the frame's critical path -- begins while
+            // the other primary rays are still being walked, not after the last of them.  It may end once level 0 has (LQ_LEVEL0).
+            if (early_queue && o->max_depth >= 1) {
+                CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_reset[P.slot], stream));
+                CRT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->early, ctx->ev_reset[P.slot], 0));
+                launch_queue(ctx->early);
+            }
             if (P.exec_count) launch(bvh_trace_level0<BVH_TALLY>, P.lane_blocks, stream, A);
             else if (ctx->tuning.bvh == 2) launch(bvh_trace_level0<BVH_CHECKED>, P.lane_blocks, stream, A);
             else launch(bvh_trace_level0<BVH_PLAIN>, P.lane_blocks, stream, A);
@@ -332,6 +357,7 @@ static int launch_stream_levels(crt_ctx *ctx, const crt_options *o, FramePlan &P
             else launch(stream_shade_evicted<false>, 256u, stream, A, g);
         }
         if (g == 0) {
+            if (P.queue) hipLaunchKernelGGL(bvh_mark_level0_done, dim3(1), dim3(64), 0, stream, A);
             // where level 0's shadow rays end; they start now, on the side stream, beside the deeper levels
             hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, stream, A, (uint32_t)SC_SHADOW_SPLIT, (uint32_t)SC_SHADOW);
             hipStream_t where = side_per_cu ? ctx->side : stream;
@@ -359,19 +385,15 @@ static int launch_stream_levels(crt_ctx *ctx, const crt_options *o, FramePlan &P
             CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_s2[P.slot], where));
         }
         if (P.queue) {
-            // every level below level 0: one launch that feeds itself (kernel_bvh.h); two workgroups per CU hold more lanes than the
-            // widest level of a frame of this size has rays
-            const uint32_t qblocks = std::min(P.lane_blocks, (uint32_t)ctx->num_cus * std::max(1u, ctx->tuning.level_queue & 15u));
-            // A reflection child continues in the lane that shaded its parent (no hand-over through memory) where the launch is a matter of
-            // latency -- few rays: HW14 3.37 -> 3.29 ms, an eighth of its tiles 2.25 -> 2.04 -- and goes through the queue like the others where
-            // it is a matter of balance (HW11, 65 - 85 k rays per level: 4.0 ms through the queue, 4.5 with chains kept in their lanes)
-            A.force_whole = (P.widest > 70000u || (ctx->tuning.level_queue & 256u)) ? 1u : 0u;
-            if (o->max_depth >= 1) {
-                A.bundle = ctx->tuning.level0_budget ? ctx->tuning.level0_budget - 1u : 15u;   // (development: turns between two housekeeping rounds, as a mask)
-                if (P.exec_count) launch(bvh_trace_queue<BVH_TALLY>, qblocks, stream, A);
-                else if (ctx->tuning.bvh == 2) launch(bvh_trace_queue<BVH_CHECKED>, qblocks, stream, A);
-                else launch(bvh_trace_queue<BVH_PLAIN>, qblocks, stream, A);
+            if (early_queue && o->max_depth >= 1) {
+                // ... and once more behind level 0 AND the first launch: nothing promises that two streams' kernels run side by side, so the
+                // first launch's patience with an empty queue is bounded, and what it left is walked here (normally nothing: ~15 us)
+                CRT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->early, ctx->ev_fork[P.slot], 0));
+                launch_queue(ctx->early);
+                CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_queue[P.slot], ctx->early));
+                CRT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_queue[P.slot], 0));
             }
+            else if (o->max_depth >= 1) launch_queue(stream);
             break;
         }
     }

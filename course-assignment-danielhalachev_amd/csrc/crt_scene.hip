@@ -105,10 +105,11 @@ extern "C" void crt_tuning_defaults(crt_tuning *t) {
     t->size = (uint32_t)sizeof(*t);
     t->mode = CRT_MODE_STREAM;
     t->step_budget = 384; t->shadow_budget = 4096; t->level0_budget = 0;
-    t->heavy_level = 100000; t->side_blocks = 2;
+    t->heavy_level = 100000; t->side_blocks = 3;
     t->node_cap = t->ray_cap = t->shadow_cap = 0;
     t->bvh = 1;
-    t->level_queue = 2;
+    t->level_queue = 1;
+    t->fetch_chunk = 256u | (64u << 16);
 }
 
 extern "C" int crt_create(const crt_scene_desc *s, int device, crt_ctx **out) { return crt_create_tuned(s, device, nullptr, out); }
@@ -126,6 +127,11 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
         memcpy(&tune, tuning, tuning->size);  // an older, shorter struct keeps the defaults of the newer fields
         tune.size = (uint32_t)sizeof(crt_tuning);
         if (tune.mode > CRT_MODE_LANES) { g_create_error = "crt_tuning.mode out of range"; return CRT_ERR_INVALID; }
+        const uint32_t c_lo = tune.fetch_chunk & 0xFFFFu, c_hi = tune.fetch_chunk >> 16;
+        if (c_lo < 64u || c_hi < 64u || (c_lo & 63u) || (c_hi & 63u)) {
+            g_create_error = "crt_tuning.fetch_chunk: both halves must be multiples of 64, at least 64";
+            return CRT_ERR_INVALID;
+        }
     }
     int rc = validate_scene(s, g_create_error);
     if (rc != CRT_OK) return rc;
@@ -163,6 +169,7 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
         int least = 0, greatest = 0;
         CK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         CK(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, least));
+        CK(hipStreamCreateWithPriority(&ctx->early, hipStreamNonBlocking, greatest));   // (a hardware queue of its own: the level queue's launch must run BESIDE level 0)
     }
     for (int i = 0; i < crt_ctx::EV_RING; i++) {
         CK(hipEventCreate(&ctx->ev0[i]));
@@ -174,6 +181,8 @@ extern "C" int crt_create_tuned(const crt_scene_desc *s, int device, const crt_t
         CK(hipEventCreate(&ctx->ev_s0[i]));
         CK(hipEventCreate(&ctx->ev_s1[i]));
         CK(hipEventCreate(&ctx->ev_s2[i]));
+        CK(hipEventCreateWithFlags(&ctx->ev_reset[i], hipEventDisableTiming));
+        CK(hipEventCreateWithFlags(&ctx->ev_queue[i], hipEventDisableTiming));
     }
 
     ctx->width = s->width;
@@ -598,11 +607,14 @@ extern "C" void crt_destroy(crt_ctx *ctx) {
         if (ctx->ev_s0[i]) (void)hipEventDestroy(ctx->ev_s0[i]);
         if (ctx->ev_s1[i]) (void)hipEventDestroy(ctx->ev_s1[i]);
         if (ctx->ev_s2[i]) (void)hipEventDestroy(ctx->ev_s2[i]);
+        if (ctx->ev_reset[i]) (void)hipEventDestroy(ctx->ev_reset[i]);
+        if (ctx->ev_queue[i]) (void)hipEventDestroy(ctx->ev_queue[i]);
     }
     if (ctx->ev_call0) (void)hipEventDestroy(ctx->ev_call0);
     if (ctx->ev_call1) (void)hipEventDestroy(ctx->ev_call1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
+    if (ctx->early) (void)hipStreamDestroy(ctx->early);
     delete ctx;
 }
 

@@ -56,6 +56,7 @@ constexpr float BVH_WIDEN = 0x1p-20f;
 // A wave looks after its free lanes -- output of the finished walks, new rays -- when BVH_BATCH of them have gathered (or none walks
 // any more): every such round costs the lanes that still walk a shading's worth of time, so the rounds must be few.
 constexpr uint32_t BVH_BATCH = 24;
+// (level 0 and the bulk shadow pass claim their work indices in chunks: KernelArgs::chunk, crt_tuning::fetch_chunk)
 constexpr int BVH_STEPS = 4;         // walk steps between two looks at the lanes' states
 
 // Builds of the kernels: plain; tallying the tests they execute (crt_options::collect_counters == 2); bounds-checked (crt_tuning::bvh
@@ -399,6 +400,7 @@ __device__ __forceinline__ void bvh_shade_level(const KernelArgs &A, const uint3
     bvh_walk_begin(W, INFINITY);
     int state = BVH_FETCH;
     uint32_t r = 0, spins = 0;
+    WaveChunk chunk{0u, 0u};
     for (;;) {
         if (MODE == BVH_CHECKED && ++spins > (1u << 22)) { bvh_at<MODE>(A, spins, 0u, 15); break; }   // (a loop that does not end: say so and leave)
         const uint32_t n_free = (uint32_t)__popcll(__ballot(state == BVH_FETCH || state == BVH_FINISHED));
@@ -414,8 +416,11 @@ __device__ __forceinline__ void bvh_shade_level(const KernelArgs &A, const uint3
             }
             // one fetch per free lane and round (a lane whose ray needs no walk here -- an uncovered pixel -- asks again next round): no
             // inner loop, no `continue` (compiler notes)
+            // (level 0: millions of rays, claimed A.chunk at a time; a deeper level's few thousand are dealt out one refill at a time)
+            uint32_t claimed = 0;
+            if (gen == 0) claimed = wave_fetch_chunked(A.f->s_counts + SC_FETCH, lane, state == BVH_FETCH, chunk, A.chunk, count);
             if (state == BVH_FETCH) {
-                r = wave_fetch(A.f->s_counts + SC_FETCH + gen, lane);
+                r = gen == 0 ? claimed : wave_fetch(A.f->s_counts + SC_FETCH + gen, lane);
                 if (r >= count) state = BVH_OUT;
                 else {
                     bool walk = true;
@@ -493,7 +498,7 @@ __device__ __forceinline__ void bvh_queue_levels(const KernelArgs &A, uint32_t *
     if (A.f->s_counts[SC_OVERFLOW]) return;
     typedef uint32_t __attribute__((address_space(1))) *gu32;
     const gu32 tail_p = (gu32)(A.f->s_lq_words + LQ_TAIL), head_p = (gu32)(A.f->s_lq_words + LQ_HEAD), done_p = (gu32)(A.f->s_lq_words + LQ_DONE),
-               ovf_p = (gu32)(A.f->s_lq_words + LQ_ABORT);
+               ovf_p = (gu32)(A.f->s_lq_words + LQ_ABORT), l0_p = (gu32)(A.f->s_lq_words + LQ_LEVEL0);
     const uint32_t count0 = stream_level_count(A, 0);
     const BvhStack stack = bvh_stack_of(A, stack_lds, false);
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -503,7 +508,7 @@ __device__ __forceinline__ void bvh_queue_levels(const KernelArgs &A, uint32_t *
     BvhWalk W;
     bvh_walk_begin(W, INFINITY);
     int state = BVH_FETCH;
-    uint32_t r = 0, gen = 1, spins = 0, idle_polls = 0;
+    uint32_t r = 0, gen = 1, spins = 0, idle_polls = 0, early_polls = 0;
     // the shadow rays of a diffuse hit are walked by the lane that shaded it, one light after the other (they have no children: nothing to
     // hand over, and no launch of their own behind the queue): first slot and stride in the shadow queue, light in turn, walk under way?
     uint32_t sh_first = 0, sh_stride = 0, sh_li = 0, sh_slot = 0;
@@ -562,16 +567,25 @@ __device__ __forceinline__ void bvh_queue_levels(const KernelArgs &A, uint32_t *
                 idle_polls = 0;
             } else if (n_want || __ballot(state == BVH_WAIT)) {
                 // nothing to claim: is it the end?
-                uint32_t d = 0, t2 = 0, ovf = 0;
+                uint32_t d = 0, t2 = 0, ovf = 0, l0 = 0;
                 if (lane == 0) {
+                    // (the launch starts WITH level 0, whose rays reserve entries too: has it ended?  Read first: its reservations are in
+                    //  `tail` by then)
+                    l0 = __hip_atomic_load(l0_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     d = __hip_atomic_load(done_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // done BEFORE tail (see above)
                     t2 = __hip_atomic_load(tail_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     ovf = __hip_atomic_load(ovf_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 d = __builtin_amdgcn_readfirstlane(d); t2 = __builtin_amdgcn_readfirstlane(t2); ovf = __builtin_amdgcn_readfirstlane(ovf);
+                l0 = __builtin_amdgcn_readfirstlane(l0);
+                // Before level 0 has ended an empty queue is no reason to leave -- up to a point: nothing guarantees that level 0 RUNS beside
+                // this launch (two streams may share a hardware queue), so the patience is bounded, and a second launch behind level 0
+                // (crt_launch.hip) takes whatever this one left.
+                if (!l0 && early_polls < 160u) { early_polls++; idle_polls = 0; }
                 // nothing is in flight and nothing can be reserved any more (or the frame is lost): whoever has no ray leaves
-                if ((ovf || d == t2) && (state == BVH_FETCH || ovf || (state == BVH_WAIT && r >= t2))) state = BVH_OUT;
+                if ((ovf || (l0 && d == t2)) && (state == BVH_FETCH || ovf || (state == BVH_WAIT && r >= t2))) state = BVH_OUT;
                 // A wave without a single ray that keeps finding nothing to claim leaves too: the waves that hold the rays in flight
                 // claim what those rays reserve (a wave that has just reserved rays looks for work at once), and a frame's levels shrink:
                 // most waves are only needed for the first of them -- and every idle wave is one more poller of the queue's words.
@@ -638,6 +652,11 @@ __device__ __forceinline__ void bvh_queue_levels(const KernelArgs &A, uint32_t *
     }
     exec_counters_flush(A, nbox, ntri, lane);
 }
+// (behind level 0, on its stream: the level queue's launch, which runs beside it, may end when its queue is empty)
+__global__ void bvh_mark_level0_done(const KernelArgs A) {
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        __hip_atomic_store((uint32_t __attribute__((address_space(1))) *)(A.f->s_lq_words + LQ_LEVEL0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void bvh_trace_queue(const KernelArgs A) {
     __shared__ uint32_t stack_lds[BVH_LDS_STACK * BLOCK];
@@ -646,7 +665,7 @@ __global__ __launch_bounds__(BLOCK) void bvh_trace_queue(const KernelArgs A) {
 
 // The shadow rays [first, first + total) of the queue (pass 0: level 0's fixed slots; pass 1: the deeper levels'); `cursor` hands them
 // out, consecutive slots to the lanes that refill together: one tile's rays towards one light (kernel_stream.h: level0_shadow_place).
-template <int MODE>
+template <int MODE, bool CHUNKED>
 __device__ __forceinline__ void bvh_shadow_rays(const KernelArgs &A, const uint32_t first, const uint32_t total, uint32_t *cursor, uint32_t *stack_lds) {
     const uint32_t lane = threadIdx.x & 63u;
     if (A.f->s_counts[SC_OVERFLOW]) return;
@@ -660,6 +679,7 @@ __device__ __forceinline__ void bvh_shadow_rays(const KernelArgs &A, const uint3
     float light_dist = 0;
     int state = BVH_FETCH;
     uint32_t r = 0, spins = 0;
+    WaveChunk chunk{0u, 0u};
     for (;;) {
         if (MODE == BVH_CHECKED && ++spins > (1u << 22)) { bvh_at<MODE>(A, spins, 0u, 15); break; }   // (a loop that does not end: say so and leave)
         const uint32_t n_free = (uint32_t)__popcll(__ballot(state == BVH_FETCH || state == BVH_FINISHED));
@@ -675,8 +695,10 @@ __device__ __forceinline__ void bvh_shadow_rays(const KernelArgs &A, const uint3
                 A.f->s_occluded[r] = W.have ? 1 : 0;
                 state = BVH_FETCH;
             }
+            uint32_t claimed = 0;
+            if (CHUNKED) claimed = wave_fetch_chunked(cursor, lane, state == BVH_FETCH, chunk, A.chunk, total);
             if (state == BVH_FETCH) {   // (one fetch per free lane and round, as in bvh_shade_level)
-                r = wave_fetch(cursor, lane);
+                r = CHUNKED ? claimed : wave_fetch(cursor, lane);
                 if (r >= total) state = BVH_OUT;
                 else {
                     r += first;
@@ -710,7 +732,7 @@ template <uint32_t pass, int MODE>  // (the passes are kernels of their own in a
 __global__ __launch_bounds__(BLOCK) void bvh_trace_shadow(const KernelArgs A) {
     __shared__ uint32_t stack_lds[BVH_LDS_STACK * BLOCK];
     const uint32_t split = A.f->s_counts[SC_SHADOW_SPLIT];
-    bvh_shadow_rays<MODE>(A, pass == 0 ? 0u : split, pass == 0 ? split : A.f->s_counts[SC_SHADOW] - split,
+    bvh_shadow_rays<MODE, pass == 0>(A, pass == 0 ? 0u : split, pass == 0 ? split : A.f->s_counts[SC_SHADOW] - split,
                           A.f->s_counts + (pass == 0 ? SC_SHADOW_FETCH : SC_SHADOW_FETCH2), stack_lds);
 }
 

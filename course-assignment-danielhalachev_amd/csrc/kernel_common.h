@@ -31,7 +31,7 @@ enum : int { SC_COUNT = 0, SC_FETCH = MAX_GENERATIONS, SC_HEAVY = 2 * MAX_GENERA
 // kernel_bvh.h, the level queue's words (FrameArgs::s_lq_words): rays reserved / claimed / finished, and a copy of the overflow word for
 // the waves that wait -- 64 KB apart: hundreds of waves poll them, and words that share a memory channel share its request rate (with
 // each other and with the bulk shadow pass's cursor, were they in the counter block)
-enum : int { LQ_TAIL = 0, LQ_HEAD = 16384, LQ_DONE = 32768, LQ_ABORT = 49152, LQ_WORDS = 65536 };
+enum : int { LQ_TAIL = 0, LQ_HEAD = 16384, LQ_DONE = 32768, LQ_ABORT = 49152, LQ_LEVEL0 = 57344, LQ_WORDS = 65536 };   // (LQ_LEVEL0: level 0 has ended -- nothing but the queue's own rays reserves entries any more)
 static_assert(SC_WORDS <= SC_HEAVY_DIAG, "counter block too small");
 
 static_assert(SC_OVERFLOW == SC_OVERFLOW_WORD, "kernel_common.h SC_OVERFLOW_WORD must match");
@@ -195,6 +195,7 @@ struct KernelArgs {
     uint32_t only_if_overflow;    // lane kernel: run only when the stream pass overflowed its queues
     uint32_t force_whole;         // this level's per-lane kernel was not launched: the wave-per-ray kernel takes all its rays (kernel_stream.h)
     uint32_t wave_prio;           // s_setprio of the recursion levels' waves over the bulk shadow pass's, which shares the SIMDs with them
+    uint32_t chunk;               // filter kernels: indices a wave claims from the launch's cursor per atomic (kernel_stream.h: wave_fetch_chunked)
 };
 
 // ---------------------------------------------------------------------------------------------

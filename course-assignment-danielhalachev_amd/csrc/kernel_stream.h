@@ -93,6 +93,38 @@ __device__ __forceinline__ uint32_t wave_fetch(uint32_t *cursor, uint32_t lane) 
     return base + (uint32_t)rank;
 }
 
+// The same for the two launches with MILLIONS of indices to hand out (level 0's primary rays, the bulk shadow pass's slots): a wave
+// claims a CHUNK of consecutive indices with ONE atomic and serves its next refills from it.  One cursor word serves ~100-150 atomics
+// per microsecond whatever the number of waves asking: 8.3 M shadow slots claimed ~28 at a time were 300 k atomics -- the pass took
+// 1.9 ms on one, two or five workgroups per CU alike, 1.4 claimed 256 at a time.  Chunks shrink towards the end of the launch (a wave
+// takes at most its share of HALF of what it sees left, never less than 64): beside the recursion levels the pass's waves advance at very
+// different rates, and whole chunks of 512 left it 0.5 ms of stragglers.  (Indices past the end are claimed and dropped.)
+struct WaveChunk { uint32_t next, end; };   // wave-uniform
+// (EVERY lane of the wave calls this, `want` or not: the chunk is the wave's, and a lane that skipped the call would keep a stale copy)
+__device__ __forceinline__ uint32_t wave_fetch_chunked(uint32_t *cursor, uint32_t lane, bool want, WaveChunk &C, const uint32_t chunk_max, const uint32_t total) {
+    const unsigned long long need = __ballot(want);
+    const uint32_t n = (uint32_t)__popcll(need);
+    const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+    const uint32_t avail = C.end - C.next;
+    if (avail >= n) {   // (wave-uniform)
+        const uint32_t idx = C.next + rank;
+        C.next += n;
+        return idx;
+    }
+    // what is left, as of this wave's own previous claim (C.end: reading the cursor word itself would be one more request to the one
+    // channel the claims queue up at -- measured: the frame 3.5 -> 5.9 ms)
+    const uint32_t left = C.end < total ? total - C.end : 0u;
+    const uint32_t share = (left / (2u * gridDim.x * (BLOCK / 64u))) & ~63u;
+    const uint32_t c = share > chunk_max ? chunk_max : (share < 64u ? 64u : share);   // (>= 64: a refill of all 64 lanes fits in one claim)
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(cursor, c);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    const uint32_t idx = rank < avail ? C.next + rank : base + (rank - avail);   // (the old chunk's last indices first)
+    C.next = base + (n - avail);
+    C.end = base + c;
+    return idx;
+}
+
 // wave-aggregated append of this lane's ray id to an eviction list; false when the list is full
 __device__ __forceinline__ bool evict_ray(uint32_t *list, uint32_t cap, uint32_t *count, uint32_t r, uint32_t lane) {
     const unsigned long long em = __ballot(1);

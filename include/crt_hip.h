@@ -189,15 +189,18 @@ typedef struct crt_tuning {
     uint32_t shadow_budget;   /* 4096: cap of the same for the bulk shadow pass (the launch scales it down with its size) */
     uint32_t level0_budget;   /* 0 (= min(step_budget, what a lane gets through in the launch)): the same for PRIMARY rays */
     uint32_t heavy_level;     /* 100000: recursion levels with fewer rays skip the per-lane kernel */
-    uint32_t side_blocks;     /* 2: workgroups per CU of the bulk shadow pass on the side stream; 0 = no side stream */
+    uint32_t side_blocks;     /* 3: workgroups per CU of the bulk shadow pass on the side stream; 0 = no side stream */
     uint32_t node_cap, ray_cap, shadow_cap; /* 0 = the queues follow the frames; explicit values make
                                              * queue overflow -- and the fallback -- reachable in tests */
     uint32_t bvh;             /* 1: rays are walked through the candidate filter (csrc/crt_bvh.h, csrc/kernel_bvh.h) where the scene has one;
                                * 0: by the reference-order kernels alone; 2: the filter kernels' bounds-checked build (development) */
-    uint32_t level_queue;     /* 2: with the filter kernels, every recursion level below level 0 in ONE launch that feeds itself through a queue
+    uint32_t level_queue;     /* 1: with the filter kernels, every recursion level below level 0 in ONE launch that feeds itself through a queue
                                * (csrc/kernel_bvh.h: bvh_trace_queue), on this many workgroups per CU -- for frames whose levels held at most
                                * 250 k rays each a frame ago (wider levels are throughput: one launch per level is as fast or faster);
                                * 0: always one launch per level */
+    uint32_t fetch_chunk;     /* 256 | 64 << 16: work indices a wave claims from a launch's cursor with ONE atomic -- bits 0-15 the bulk shadow
+                               * pass's slots, bits 16-31 level 0's primary rays (both >= 64, multiples of 64); a cursor word serves ~100
+                               * atomics per microsecond however many waves ask, which bounded the pass until it claimed in chunks */
 } crt_tuning;
 void crt_tuning_defaults(crt_tuning *tuning);
 

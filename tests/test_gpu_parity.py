@@ -59,9 +59,12 @@ KERNEL_PATHS = [
     dict(mode=1),                                                # recursive one-ray-per-lane kernel for every pixel (the queue-less fallback)
     dict(bvh=1),                                                 # the filter kernels (csrc/kernel_bvh.h), the levels below level 0 through the level queue
     dict(bvh=1, side_blocks=0),                                  # ... without a side stream
-    dict(bvh=1, side_blocks=4, level_queue=1),                   # ... the bulk shadow pass on four workgroups per CU, the queue on one
+    dict(bvh=1, side_blocks=4, level_queue=2),                   # ... the bulk shadow pass on four workgroups per CU, the queue on two
+    dict(bvh=1, fetch_chunk=0x400040),                           # ... cursor claims of 64 (a wave's refill) in the bulk shadow pass
+    dict(bvh=1, fetch_chunk=0x1000800, side_blocks=2),           # ... of 2048 slots and 256 primary rays
     dict(bvh=2),                                                 # ... their bounds-checked build
     dict(bvh=1, level_queue=0),                                  # ... one launch per level
+    dict(bvh=1, level_queue=513),                                # ... the queue's launch behind level 0 instead of beside it
     dict(bvh=1, level_queue=258),                                # ... every child ray through the queue (none continues in its parent's lane)
     dict(bvh=2, level_queue=0, side_blocks=0),
     dict(bvh=0),                                                 # the reference-order kernels: plan kernels + wave-per-ray kernels
@@ -565,3 +568,15 @@ def test_top_level_nodes_interleaved_with_a_mesh_tree(pkg, scenes, oracle):
         assert st.counters() == counters
     finally:
         L.crt_destroy(ctx)
+
+
+@pytest.mark.gpu
+def test_tuning_that_the_kernels_cannot_run_is_refused(pkg, scenes):
+    """crt_create_tuned: a cursor chunk below 64 (a refill of a whole wave must fit in one claim, kernel_stream.h: wave_fetch_chunked)
+    or not a multiple of 64, and an unknown mode."""
+    scene, _, _ = small_case(scenes, "hw07")
+    hs = pkg.Scene(json_text=scenes.to_json(scene))
+    for bad in (dict(fetch_chunk=0x400020), dict(fetch_chunk=0x100), dict(fetch_chunk=0x410100), dict(mode=7)):
+        with pytest.raises(pkg.CrtError) as e:
+            pkg.Tracer(hs, tuning=pkg.make_tuning(**bad))
+        assert e.value.code == pkg.CRT_ERR_INVALID, bad

@@ -57,6 +57,11 @@ def test_no_device_is_an_error_not_a_fallback(pkg, scenes):
     assert e.value.code == pkg.CRT_ERR_NO_DEVICE
 
 
+def test_tuning_defaults(pkg):
+    t = pkg.make_tuning()
+    assert (t.fetch_chunk & 0xFFFF, t.fetch_chunk >> 16, t.level_queue, t.side_blocks, t.bvh) == (256, 64, 1, 3, 1)
+
+
 # ---------------------------------------------------------------------------------------------- loader
 @pytest.mark.parametrize("name", ["hw07", "hw11", "hw14", "hw12"])
 def test_loader_builder_match_the_oracle(pkg, scenes, oracle, name, tmp_path):

@@ -16,7 +16,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "gpurun_out", "profiles_" + tag)
 os.makedirs(out, exist_ok=True)
 env = dict(os.environ, TMPDIR="/tmp")
-DOM = "bvh_trace_shadow<0"      # the dominant kernel (most executed tests): the bulk shadow pass
+DOM = "bvh_trace_shadow<0u, 0>"     # the dominant kernel (most executed tests): the bulk shadow pass
 LEVELS = "bvh_trace_queue<0"     # the frame's critical path below level 0
 import importlib
 sys.path.insert(0, root)
