@@ -261,6 +261,9 @@ def main():
         host_ok = bool(torch.equal(hosts2[last].view(torch.int32), frames2[last].cpu().view(torch.int32)))
         host_frame = hosts2[last].numpy().copy()   # what the timed region delivered: compared with the reference's frame below
     # the same loop with the frame left in HBM (reported beside `value`)
+    # (the comparisons above leave the GPU idle for tens of milliseconds and its clocks drop: the same W warm-up frames as before `value`'s loop)
+    for _ in range(args.warmup):
+        step(False)
     resident_elapsed = timed(args.steps, False)
 
     # The same K steps once more with several frames in flight (reported beside `value`, never as it): frame k on context k % F

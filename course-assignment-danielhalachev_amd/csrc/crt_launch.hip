@@ -357,7 +357,6 @@ static int launch_stream_levels(crt_ctx *ctx, const crt_options *o, FramePlan &P
             else launch(stream_shade_evicted<false>, 256u, stream, A, g);
         }
         if (g == 0) {
-            if (P.queue) hipLaunchKernelGGL(bvh_mark_level0_done, dim3(1), dim3(64), 0, stream, A);
             // where level 0's shadow rays end; they start now, on the side stream, beside the deeper levels
             hipLaunchKernelGGL(stream_mark_split, dim3(1), dim3(64), 0, stream, A, (uint32_t)SC_SHADOW_SPLIT, (uint32_t)SC_SHADOW);
             hipStream_t where = side_per_cu ? ctx->side : stream;

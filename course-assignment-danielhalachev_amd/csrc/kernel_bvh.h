@@ -477,6 +477,13 @@ template <int MODE>
 __global__ __launch_bounds__(BLOCK) void bvh_trace_level0(const KernelArgs A) {   // (bounded to 128 VGPRs for four waves per SIMD: 2 spills, 3.40 vs 3.31 ms)
     __shared__ uint32_t stack_lds[BVH_LDS_STACK * BLOCK];
     bvh_shade_level<MODE, true>(A, 0u, stack_lds);
+    // The level queue's launch runs BESIDE this one and may only end once nothing but its own rays can reserve entries any more: the
+    // last workgroup to get here says so (LQ_LEVEL0).  Every reservation of a workgroup has RETURNED (an atomic with a result) before
+    // the workgroup counts itself; the flag is the launch's own word, not a kernel behind it: a kernel behind it may be held back until
+    // the queue's launch has ended (a profiler that serialises launches does that), and the queue's launch would wait for it for ever.
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(A.f->s_lq_words + LQ_LEVEL0 + 1, 1u) == gridDim.x - 1u)
+        __hip_atomic_store((uint32_t __attribute__((address_space(1))) *)(A.f->s_lq_words + LQ_LEVEL0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // EVERY ray below level 0, in one launch (crt_tuning::level_queue).  Launched level by level a frame waits, at each of its levels,
@@ -651,11 +658,6 @@ __device__ __forceinline__ void bvh_queue_levels(const KernelArgs &A, uint32_t *
         }
     }
     exec_counters_flush(A, nbox, ntri, lane);
-}
-// (behind level 0, on its stream: the level queue's launch, which runs beside it, may end when its queue is empty)
-__global__ void bvh_mark_level0_done(const KernelArgs A) {
-    if (threadIdx.x == 0 && blockIdx.x == 0)
-        __hip_atomic_store((uint32_t __attribute__((address_space(1))) *)(A.f->s_lq_words + LQ_LEVEL0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void bvh_trace_queue(const KernelArgs A) {

@@ -70,6 +70,11 @@ if "--stats-only" in sys.argv:
     print("done", flush=True)
     sys.exit(0)
 
+# rocprofv3 serialises launches while it counts: the level queue's launch cannot run BESIDE level 0 there (it would sit out its patience
+# and leave the work to its second launch: two launches per frame, one of them idle, averaged into one row).  The counting passes
+# therefore put it behind level 0 (crt_tuning::level_queue bit 9): one launch per frame, the kernel with the chip to itself, as every
+# counted kernel is.
+PMC_EXTRA = ["--no-alone", "--tuning", "level_queue=513"]
 GROUPS = [["FETCH_SIZE"], ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"], ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum"],
           ["TA_TA_BUSY_sum", "TA_FLAT_READ_WAVEFRONTS_sum"], ["TCP_PENDING_STALL_CYCLES_sum"],
           ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SMEM"],
@@ -77,7 +82,7 @@ GROUPS = [["FETCH_SIZE"], ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"], ["TCP
 pmc = {}
 for counters in GROUPS:
     name = "pmc_" + "_".join(c.replace("_sum", "") for c in counters)[:60]
-    d = run(["--pmc"] + counters, name, ["--no-alone"])
+    d = run(["--pmc"] + counters, name, PMC_EXTRA)
     f = find(d, "counter_collection.csv")
     if not f:
         continue
@@ -93,7 +98,7 @@ for counters in GROUPS:
 # the clock the chip holds in this kernel: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / the launch's duration, both from ONE pass
 clock = None
 clock_levels, ms_levels = None, None
-d = run(["--pmc", "GRBM_GUI_ACTIVE", "--kernel-trace"], "pmc_clock", ["--no-alone"])
+d = run(["--pmc", "GRBM_GUI_ACTIVE", "--kernel-trace"], "pmc_clock", PMC_EXTRA)
 fc, ft = find(d, "counter_collection.csv"), find(d, "kernel_trace.csv")
 if fc and ft:
     dur = {r["Dispatch_Id"]: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(ft)) if short(r["Kernel_Name"]).startswith(DOM)}
@@ -118,7 +123,7 @@ if dom:
     doc = {"csrc_sha256": CSRC,
            key: {"kernel": dom[0], "per_launch": per, "launches": max(v["launches"] for v in pmc[dom[0]].values()),
                  "clock_ghz": round(clock, 4) if clock else 2.0, "kernel_ms_in_the_clock_pass": round(ms_in_pass, 4) if clock else None,
-                 "how": "rocprofv3 --pmc <group> -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --in-flight 0 --no-alone, one pass per group "
+                 "how": "rocprofv3 --pmc <group> -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --in-flight 0 --no-alone --tuning level_queue=513 (the level queue's launch behind level 0: launches are serialised while counting), one pass per group "
                         "(tools/collect_profiles.py); counts averaged over the launches of the kernel in the pass"}}
     lev = [k for k in pmc if k.startswith(LEVELS)]
     if lev and clock_levels:

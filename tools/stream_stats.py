@@ -12,7 +12,7 @@ s = sc.scatter_meshes(sc.make('hw11', detail=0.6), int(name[4:])) if many else (
 if s.get('textures'): sc.write_bitmaps(s, folder)
 hs = pkg.Scene(json_text=sc.to_json(s), folder=folder); tr = pkg.Tracer(hs, tuning=pkg.tuning_from_string(__import__('os').environ.get('CRT_TUNING', '')))
 depth = 8 if many else (gi[2] if gi else sc.CONFIGS[name][3])
-for i in range(3):
+for i in range(int(os.environ.get('CRT_FRAMES', '3'))):
     if gi: tr.render(options=pkg.make_options(depth, use_gi=True, gi_sample_size=gi[3], rays_per_pixel=gi[4], gi_seed=i))
     else: tr.render(max_depth=depth)
 print('phase ms', tr.kernel_times_ms(3))
@@ -21,6 +21,7 @@ L = pkg.lib(); L.crt_debug_stream_counts.argtypes = [C.c_void_p, C.POINTER(C.c_u
 L.crt_debug_stream_counts(tr.ctx, out, 512)
 print('rays per level   ', [out[g] for g in range(depth + 2)])
 print('evicted per level', [out[128 + g] for g in range(depth + 1)])
+print('diag', [out[k] for k in range(int(os.environ.get('CRT_DIAG', '0')), int(os.environ.get('CRT_DIAG', '0')) + 8)])
 print('shadow rays', out[320], 'level-0 split', out[327], 'evicted shadow', out[323], 'overflow', out[322], 'guard', out[326], 'fallback frames', tr.stats().fallback_frames)
 
 # what the group-per-ray (or wave-per-ray) walks of a frame consist of (a render with counters=2 tallies them)
