@@ -143,7 +143,7 @@ DEVICE_SYMBOLS = ["crt_bvh_selftest", "crt_tuning_defaults", "crt_create_tuned",
                   "crt_multi_create", "crt_multi_set_camera", "crt_multi_render", "crt_multi_read_quantized", "crt_multi_get_stats",
                   "crt_multi_device_count", "crt_multi_context", "crt_multi_last_error", "crt_multi_destroy",
                   "crt_multi_staged_parts", "crt_multi_peer_note", "crt_debug_multi_force_staged", "crt_debug_multi_fail_next_alloc"]
-HOST_SYMBOLS = ["crt_host_scene_parse_file", "crt_host_scene_parse_text", "crt_host_scene_parse_text_ex",
+HOST_SYMBOLS = ["crt_host_tracer_note", "crt_host_scene_parse_file", "crt_host_scene_parse_text", "crt_host_scene_parse_text_ex",
                 "crt_host_scene_build_seconds", "crt_host_scene_free", "crt_host_scene_desc",
                 "crt_host_scene_settings", "crt_host_scene_camera", "crt_host_scene_mesh_count",
                 "crt_host_tree_node_count", "crt_host_tree_index_total", "crt_host_tree_dump", "crt_host_mesh_sizes",
@@ -228,6 +228,8 @@ def lib():
     L.crt_host_tracer_free.restype = None
     L.crt_host_tracer_set_camera.argtypes = [vp, vp, vp]
     L.crt_host_tracer_render.argtypes = [vp, C.c_char_p, i32, C.POINTER(Options), vp]
+    L.crt_host_tracer_note.argtypes = [vp]
+    L.crt_host_tracer_note.restype = C.c_char_p
     L.crt_host_tracer_ctx.restype = vp
     L.crt_host_tracer_ctx.argtypes = [vp]
     L.crt_host_export_ppm.argtypes = [C.c_char_p, vp, u32, u32]
@@ -429,6 +431,11 @@ class Tracer:
         _host_check(lib().crt_host_tracer_render(self._h, ppm_path.encode() if ppm_path else None, optimization,
                                                  C.byref(o), _p(rgb)))
         return rgb
+
+    def note(self) -> str:
+        """What the last render did differently from the reference ("" when nothing): a non-tree RenderOptimization renders with the
+        tree modes' semantics (crt_host.h: crt_host_tracer_note)."""
+        return (lib().crt_host_tracer_note(self._h) or b"").decode()
 
     def synchronize(self):
         """crt_synchronize on the first context: waits for everything enqueued on its device; afterwards stats() reflects the

@@ -63,6 +63,7 @@ int main(int argc, char **argv) {
       auto b = std::chrono::high_resolution_clock::now();
       best = std::min(best, std::chrono::duration<double>(b - a).count());
     }
+    if (!tracer.renderNote().empty()) std::fprintf(stderr, "note: %s\n", tracer.renderNote().c_str());
     crt_stats st = tracer.stats();
     // the reference prints the elapsed seconds of the render window (MEASURE_TIME, RayTracer.cpp:289-293)
     std::printf("%.6fs\n", best);

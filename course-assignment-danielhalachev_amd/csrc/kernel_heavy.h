@@ -46,18 +46,18 @@ __device__ __forceinline__ uint32_t lane_value(uint32_t v, int lane_uniform) {
 // order is the order of their bit patterns as unsigned integers, and an integer minimum folds into one DPP instruction per step
 // (a float minimum costs five: the compiler canonicalises both operands of every fminf).
 // minimum over the wave, returned uniformly (NaNs never reach it: callers pass +inf for "no value"); the result compares equal, as a
-// float, to the key of every lane that holds the minimum.  One v_min_u32 with a DPP source per step: a lane without a source (or outside
-// the row mask) is not written and keeps its value; s_nop 1 = the two wait states between a VALU write and a DPP read of the register.
+// float, to the key of every lane that holds the minimum.  Six DPP steps (row_shr 1 / 2 / 4 / 8, then row_bcast 15 into rows 1 and 3 and
+// row_bcast 31 into rows 2 and 3: lane 63 ends with the wave's minimum) through the compiler's DPP builtin, which knows the wait states
+// a DPP read needs after a VALU write and after a write of EXEC (round 3 had them as inline assembly, which the hazard recogniser cannot
+// see into); a lane without a source (or outside the row mask) gets `old` = its own value.  EVERY lane of the wave must be active at the
+// call: all call sites are in wave-uniform control flow (kernel_heavy.h's loops run on ballots).
 __device__ __forceinline__ float wave_min(float key) {
     uint32_t v = __float_as_uint(key + 0.0f);  // (-0 -> +0: the one non-negative value whose pattern is out of order)
-    asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"   // lane 15 of every row: its row's minimum
-                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"  // into rows 1 and 3
-                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"  // into rows 2 and 3: lane 63 has the wave's
-                 "s_nop 1"
-                 : "+v"(v));
+#define CRT_DPP_MIN(ctrl, rows) { const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rows, 0xf, false); v = o < v ? o : v; }
+    CRT_DPP_MIN(0x111, 0xf) CRT_DPP_MIN(0x112, 0xf) CRT_DPP_MIN(0x114, 0xf) CRT_DPP_MIN(0x118, 0xf)   // row_shr:1, 2, 4, 8: lane 15 of every row has its row's minimum
+    CRT_DPP_MIN(0x142, 0xa)   // row_bcast:15 into rows 1 and 3
+    CRT_DPP_MIN(0x143, 0xc)   // row_bcast:31 into rows 2 and 3
+#undef CRT_DPP_MIN
     return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)v, 63));
 }
 

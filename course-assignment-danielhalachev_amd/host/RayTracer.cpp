@@ -212,6 +212,8 @@ int RayTracer::renderFlat(const std::string &pathToImage, const RenderOptions &r
   // All ten modes render with the tree's semantics: the three BVH* modes are pixel-identical in the
   // reference, the non-tree modes differ from them in a handful of pixels and are not
   // part of this path.  The mode still selects the pixel coverage.
+  note = ro.optimization < BVH ? "RenderOptimization " + std::to_string((int)ro.optimization) + " is rendered with the tree modes' semantics (the reference's brute-force and "
+                                 "single-box modes differ from its tree modes in a handful of pixels); the mode selects the pixel coverage only" : std::string();
   std::vector<crt_rect> rects = bucketRectangles(W, H, scene.sceneSettings.bucketSize, ro.optimization,
                                                  std::thread::hardware_concurrency());
   rc = multi ? crt_multi_render(multi, &o, rects.data(), (uint32_t)rects.size(), outRGB)

@@ -100,8 +100,13 @@ class RayTracer {
   const FlatScene &flatScene() const { return flat; }
   const AccelerationStructure &acceleration() const { return accelerationStructure; }
   crt_stats stats() const;
+  // What the last render did differently from the reference, in words ("" when nothing): the reference's seven non-tree
+  // RenderOptimization modes (brute force, single AABB) accept a handful of hits its tree modes drop; every mode renders
+  // with the TREE's semantics here, the mode only selects the pixel coverage -- a caller that asks for one of them is told so.
+  const std::string &renderNote() const { return note; }
 
  private:
+  std::string note;
   const AccelerationStructure accelerationStructure;
   const Scene &scene;
   Camera camera;

@@ -233,6 +233,7 @@ extern "C" int crt_host_tracer_render(crt_host_tracer *t, const char *ppm_path, 
   });
 }
 
+extern "C" const char *crt_host_tracer_note(const crt_host_tracer *t) { return t ? t->tracer->renderNote().c_str() : ""; }
 extern "C" crt_ctx *crt_host_tracer_ctx(crt_host_tracer *t) { return t ? t->tracer->context() : nullptr; }
 extern "C" crt_multi *crt_host_tracer_multi(crt_host_tracer *t) { return t ? t->tracer->multiContext() : nullptr; }
 

@@ -225,7 +225,12 @@ int crt_render(crt_ctx *ctx, const crt_options *options, const crt_rect *rects, 
  * quantised bytes, PPMColor rule; either may be NULL; pinned host memory keeps the copies asynchronous) is enqueued and the
  * call returns.  crt_wait finishes it and fills the statistics.  One frame per context at a time: a second crt_render_async
  * first waits for the previous frame.  Frames IN FLIGHT together need one context each (the reference's animation driver,
- * app/animation.cpp:24-38, renders frame after frame; crt::RayTracer::renderAsync alternates two contexts). */
+ * app/animation.cpp:24-38, renders frame after frame; crt::RayTracer::renderAsync alternates two contexts).
+ * THE FIRST FRAME OF A SIZE / DEPTH ON A CONTEXT IS NOT ASYNCHRONOUS: its queue capacities are probed -- the call waits for the
+ * attempt (hipEventSynchronize on the frame's stream) and repeats it with larger queues if it overflowed (crt_stats::queue_regrows) --
+ * and so is the frame after one that overflowed.  That also holds for crt_render_tiles_device on a caller's stream: such a call
+ * cannot be captured into a hipGraph; render one frame first, capture the following ones.  The library also uses two streams of its
+ * own beside the caller's (the bulk shadow pass; the level queue's launch), joined to it by events before the call's last launch. */
 int crt_render_async(crt_ctx *ctx, const crt_options *options, const crt_rect *rects, uint32_t n_rects, float *out_rgb,
                      uint8_t *out_rgb8);
 int crt_wait(crt_ctx *ctx);

@@ -70,6 +70,10 @@ int crt_host_tracer_set_camera(crt_host_tracer *tracer, const float position[3],
 /* ppm_path may be NULL or "" (no file, RayTracer.cpp:294); out_rgb = H*W*3 floats or NULL */
 int crt_host_tracer_render(crt_host_tracer *tracer, const char *ppm_path, int optimization, const crt_options *options,
                            float *out_rgb);
+/* what the last render did differently from the reference, in words ("" when nothing): a non-tree RenderOptimization (0..6) is
+ * rendered with the tree modes' semantics -- the reference's brute-force / single-box modes differ from its tree modes in a handful of
+ * pixels (RayTracer.cpp:459-478, 421-425); the mode still selects the pixel coverage.  Owned by the tracer, valid until its next render. */
+const char *crt_host_tracer_note(const crt_host_tracer *tracer);
 crt_ctx *crt_host_tracer_ctx(crt_host_tracer *tracer);
 crt_multi *crt_host_tracer_multi(crt_host_tracer *tracer); /* NULL for a single-device tracer */
 /* statistics of the last render (summed over the devices of a multi-device tracer) */

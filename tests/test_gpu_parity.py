@@ -580,3 +580,17 @@ def test_tuning_that_the_kernels_cannot_run_is_refused(pkg, scenes):
         with pytest.raises(pkg.CrtError) as e:
             pkg.Tracer(hs, tuning=pkg.make_tuning(**bad))
         assert e.value.code == pkg.CRT_ERR_INVALID, bad
+
+
+@pytest.mark.gpu
+def test_a_non_tree_mode_says_that_it_renders_with_tree_semantics(pkg, scenes):
+    """RayTracer.cpp:459-478: the reference's brute-force / single-box modes accept a handful of hits its tree modes drop; this
+    path renders every mode with the tree's semantics -- same pixels as the BVH modes -- and says so instead of staying silent."""
+    scene, depth, _ = small_case(scenes, "hw07")
+    tracer = make_tracer(pkg, scenes, scene)
+    tree = tracer.render(max_depth=depth, optimization=pkg.OPT_BVH).copy()
+    assert tracer.note() == ""
+    for mode in (0, 4):   # NoOptimization, AABB
+        got = tracer.render(max_depth=depth, optimization=mode)
+        assert_same_floats(got, tree, "mode %d" % mode)
+        assert "tree" in tracer.note() and "RenderOptimization %d" % mode in tracer.note()
