@@ -33,7 +33,7 @@ struct BvhNode {
 };
 static_assert(sizeof(BvhNode) == 128, "BvhNode is one 128-byte line");
 constexpr uint32_t BVH_LEAF = 0x80000000u, BVH_EMPTY = 0xFFFFFFFFu;
-constexpr uint32_t BVH_LEAF_MAX = 4;          // triangles per leaf
+constexpr uint32_t BVH_LEAF_MAX = 2;          // triangles per leaf: one step of a walk (kernel_bvh.h: two triangles per step).  Measured 1 / 2 / 4: HW14 2.75 / 2.65 / 2.76 ms, HW11 3.38 / 3.29 / 3.48
 constexpr uint32_t BVH_ID_REFRACTIVE = 0x80000000u;  // bvh_ids: the triangle's mesh is refractive (shadow rays skip it outside the GI mode)
 // A triangle listed by more reference leaves than this has no leaf list (where more than eight triangles share a vertex -- the pole of a
 // sphere -- the reference's tree subdivides down to its depth limit and lists each of them in thousands of leaves): its hits are
