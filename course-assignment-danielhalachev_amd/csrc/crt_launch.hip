@@ -258,18 +258,18 @@ struct FramePlan {
 
 // Levels 0 .. MAX_DEPTH on `stream`; after level 0 the bulk shadow pass (and the walks it gives up) on the side stream.
 static int launch_stream_levels(crt_ctx *ctx, const crt_options *o, FramePlan &P, KernelArgs &A, hipStream_t stream) {
-    CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_scounts, 0, SC_ALLOC_WORDS * sizeof(uint32_t), stream));
-    if (P.queue) for (int w : {LQ_TAIL, LQ_HEAD, LQ_DONE, LQ_ABORT, LQ_LEVEL0}) CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_lq_words + w, 0, 16, stream));
+    // the frame's counters, the level queue's words, the tallies: zeroed (and the shadow queue's fill preset to level 0's fixed slots) in one launch
+    hipLaunchKernelGGL(stream_frame_reset, dim3(1), dim3(256), 0, stream, ctx->d_scounts, P.queue ? ctx->d_lq_words : (uint32_t *)nullptr,
+                       P.exec_count ? ctx->d_exec : (unsigned long long *)nullptr,
+                       ctx->frame.fixed0 ? (uint32_t)P.vitems * 64u * ctx->n_lights : 0u);
     const uint32_t side_per_cu = ctx->tuning.side_blocks;  // workgroups per CU of the bulk shadow pass beside the levels
     A.exec_count = P.exec_count ? 1u : 0u;
     A.exec_counters = ctx->d_exec;
     A.exec_plan = ctx->d_exec + 4;
-    if (P.exec_count) CRT_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_exec, 0, 6 * sizeof(unsigned long long), stream));
     // the plan kernels pay a wave-uniform loop per refill, whatever the number of new rays: refill in bundles
     A.bundle = REFILL_BUNDLE;
     A.wave_prio = 3u;  // the levels' waves (the frame's critical path) ahead of the bulk shadow pass's, which share their SIMDs
     A.force_whole = 0u;
-    if (ctx->frame.fixed0) CRT_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->d_scounts + SC_SHADOW), (int)((uint32_t)P.vitems * 64u * ctx->n_lights), 1, stream));
     const uint32_t plds = ctx->scene.plan_list_words * BLOCK * (uint32_t)sizeof(uint32_t);  // kernel_plan.h: mesh lists
     A.chunk = ctx->tuning.fetch_chunk >> 16;   // (level 0's claims; crt_tuning::fetch_chunk)
     KernelArgs S = A;  // argument block of the bulk shadow pass
