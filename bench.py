@@ -99,6 +99,29 @@ def cpu_baseline(sc, scene_name, depth, w, h, budget_s=30.0, gpu_frame=None):
                       % (scene_name.upper(), size_note, depth, buckets)}
 
 
+def committed_evidence(profiles_dir, key, running_hash):
+    """The counters committed under profiles/ -- used ONLY when they were collected from the kernel sources that are running.
+    Returns (pmc, traffic, why_not): the parsed r04_pmc.json or None; the dominant kernel's HBM bytes per launch
+    (hbm_traffic.json[key]) or None; and, when the PMC file is not used, the reason (a string for roofline.evidence)."""
+    traffic = None
+    try:
+        with open(os.path.join(profiles_dir, "hbm_traffic.json")) as f:
+            tj = json.load(f)
+        if key in tj and tj[key].get("csrc_sha256") == running_hash:   # (counters of THESE kernels only)
+            traffic = tj[key]["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
+    try:
+        with open(os.path.join(profiles_dir, "r04_pmc.json")) as f:
+            pmc = json.load(f)
+    except Exception as e:
+        return None, None, "profiles/r04_pmc.json not usable: %r" % (e,)
+    if pmc.get("csrc_sha256") != running_hash:
+        return None, None, "profiles/r04_pmc.json was collected from other kernel sources (csrc sha256 %s..., running %s...): not used" % (
+            str(pmc.get("csrc_sha256"))[:12], running_hash[:12])
+    return pmc, traffic, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -368,17 +391,8 @@ def main():
         # collect_counters == 2 launch above) over its own duration from HIP events on the stream it runs on.
         dom, dom_ms = tracer.kernels().get("shadow0", "stream_trace_shadow"), ln_ms
         achieved = b_exec_dom / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tp):
-            try:
-                with open(tp) as f:
-                    tj = json.load(f)
-                key = "%s_%dx%d_d%d_n%d" % (args.scene, W, H, depth, world)
-                if key in tj and tj[key].get("csrc_sha256") == pkg.csrc_sha256():   # (counters of THESE kernels only)
-                    traffic = tj[key]["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
+        key = "%s_%dx%d_d%d_n%d" % (args.scene, W, H, depth, world)
+        pfile, traffic, evidence_why = committed_evidence(os.path.join(ROOT, "profiles"), key, pkg.csrc_sha256())
         # The bulk shadow pass is launched on a lowest-priority stream beside the recursion levels, whose waves run at
         # s_setprio 3: nothing waits for it until the levels are done, so its duration in the frame is
         # what the levels leave it, not how fast it is.  Its duration ALONE is measured here as well, live, outside the timed
@@ -410,14 +424,9 @@ def main():
         # COUNTS, which do not depend on timing) over the launch durations measured LIVE above.  The file records the SHA-256 of the
         # kernel sources it was collected from (tools/collect_profiles.py); when that is not the running tree's, its counts describe
         # other kernels and nothing of it is used: `binding` and `traffic` are null and say why.
-        binding, bound, bound_frac, evidence = None, "latency", None, None
+        binding, bound, bound_frac, evidence = None, "latency", None, evidence_why
         try:
-            with open(os.path.join(ROOT, "profiles", "r04_pmc.json")) as f:
-                pfile = json.load(f)
-            here = pkg.csrc_sha256()
-            if pfile.get("csrc_sha256") != here:
-                evidence = "profiles/r04_pmc.json was collected from other kernel sources (csrc sha256 %s..., running %s...): not used" % (
-                    str(pfile.get("csrc_sha256"))[:12], here[:12])
+            if pfile is None:
                 traffic = None
             else:
                 key = "%s_%dx%d_d%d_n%d" % (args.scene, W, H, depth, world)
@@ -438,7 +447,7 @@ def main():
                                                   "ta_busy": round(c["TA_TA_BUSY_sum"] / (N_CUS * clk * t_pmc), 4),
                                                   "l1_pending_stall": round(c["TCP_PENDING_STALL_CYCLES_sum"] / (N_CUS * clk * t_pmc), 4)}}
                     return r
-                binding = {"source": "profiles/r04_pmc.json", "csrc_sha256": here[:16]}
+                binding = {"source": "profiles/r04_pmc.json", "csrc_sha256": str(pfile.get("csrc_sha256"))[:16]}
                 if pfile.get(key):
                     binding["dominant"] = roofs(pfile[key], dom_ms)
                     d = binding["dominant"]
