@@ -339,6 +339,10 @@ static int launch_stream_levels(crt_ctx *ctx, const crt_options *o, FramePlan &P
             else if (ctx->tuning.bvh == 2) launch(bvh_trace_level0<BVH_CHECKED>, P.lane_blocks, stream, A);
             else launch(bvh_trace_level0<BVH_PLAIN>, P.lane_blocks, stream, A);
         }
+        else if (P.bvh && P.gi) {   // the GI mode: the walk alone, then the level's shading with every lane busy (as the plan kernels' GI builds)
+            launch(bvh_trace_shade_gi, P.lane_blocks, stream, A, g);
+            launch(stream_shade_all<true>, P.lane_blocks, stream, A, g);
+        }
         else if (P.bvh) launch(P.exec_count ? bvh_trace_shade_tally : ctx->tuning.bvh == 2 ? bvh_trace_shade_checked : bvh_trace_shade, g == 0 ? P.lane_blocks : level_blocks, stream, A, g);
         else if (P.count) { if (P.gi) launch(stream_trace_shade<true, true>, P.lane_blocks, stream, A, g); else launch(stream_trace_shade<true>, P.lane_blocks, stream, A, g); }
         else if (P.lean && P.gi) {
@@ -530,7 +534,8 @@ static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, fl
     const bool lean = heavy && ctx->lean_ok && (SC.plan_ok || SC.plan_wide);
     const bool wide = lean && !SC.plan_ok;  // the wide plan (kernel_plan.h): more than 64 top-level leaves or meshes
     // the filter kernels (kernel_bvh.h): whenever the scene has a filter -- they need nothing of the plan or of the wave-per-ray kernels
-    const bool bvh = stream_mode && SC.bvh_ok && ctx->tuning.bvh && !gi && !count;
+    // (the GI mode too -- level by level, its levels are millions of rays -- except in the tallying and bounds-checked builds, which have no GI kernels)
+    const bool bvh = stream_mode && SC.bvh_ok && ctx->tuning.bvh && !count && !(gi && (exec_count || ctx->tuning.bvh == 2));
     // ... the levels below level 0 as one self-feeding launch -- once a frame of this size is known to fit its queues: an attempt that
     // PROBES them (launch_render) runs level by level, because a level-by-level run that overflows leaves the counts the next attempt is
     // sized from, where the level queue stops in the middle of all its levels at once (same pixels either way)
@@ -541,7 +546,7 @@ static int launch_frame(crt_ctx *ctx, const crt_options *o, uint32_t n_items, fl
     uint32_t widest = 0;
     if (ctx->last_counts_items == vitems && ctx->last_counts_cfg == frame_config_of(o))
         for (uint32_t g = 1; g <= o->max_depth && g < (uint32_t)MAX_GENERATIONS; g++) widest = std::max(widest, ctx->last_counts[SC_COUNT + g]);
-    const bool queue = bvh && ctx->tuning.level_queue && last_resort && widest <= 250000u;
+    const bool queue = bvh && !gi && ctx->tuning.level_queue && last_resort && widest <= 250000u;
     g_debug_sync = ctx->tuning.bvh == 3 ? 1 : 0;
     if (g_debug_sync) fprintf(stderr, "[frame] bvh_trace_shade %p tally %p checked %p shadow0 %p shadow1 %p heavy_closest %p shade_evicted %p resolve %p heavy_shadow %p\n",
                               (void *)bvh_trace_shade, (void *)bvh_trace_shade_tally, (void *)bvh_trace_shade_checked, (void *)bvh_trace_shadow<0, BVH_PLAIN>,

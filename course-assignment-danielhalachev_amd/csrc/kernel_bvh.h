@@ -385,7 +385,7 @@ __device__ __forceinline__ bool bvh_miss_step(const KernelArgs &A, const Ray &R,
 // finite hit goes through the miss check (above) in the same lane.  When enough lanes of the wave have finished, they shade together
 // -- shootRay's material dispatch (kernel_stream.h: shade_and_emit) -- and take the next rays of the level (consecutive ones: at
 // level 0 neighbouring pixels of a tile).
-template <int MODE, bool LQ = false>   // LQ: level 0 of a frame whose deeper levels are bvh_trace_queue's: the children go to the level queue
+template <int MODE, bool LQ = false, bool GI = false>   // LQ: level 0 of a frame whose deeper levels are bvh_trace_queue's: the children go to the level queue; GI: the GI / multi-sample mode's build
 __device__ __forceinline__ void bvh_shade_level(const KernelArgs &A, const uint32_t gen, uint32_t *stack_lds) {
     if (A.wave_prio) __builtin_amdgcn_s_setprio(3);
     const uint32_t lane = threadIdx.x & 63u;
@@ -414,7 +414,10 @@ __device__ __forceinline__ void bvh_shade_level(const KernelArgs &A, const uint3
                     atomicMax(dg + 0, W.steps); atomicAdd(dg + 1, W.steps); atomicAdd(dg + 2, 1u);
                 }
                 if (W.give_up) { A.f->s_counts[SC_GUARD] = 1; A.f->s_counts[SC_OVERFLOW] = 1; }   // a ray the filter cannot take, a miss refuted: the frame goes to the last resort
-                shade_and_emit<false, false, LQ>(A, gen, r, node_base, child_base, R, W.have, W.best, W.btri, W.bmesh, nullptr, lane);
+                // (the GI build only walks: the hit goes to the level's record and stream_shade_all<true> shades the level in a launch of its
+                //  own with every lane busy -- with the sample directions and the gi_samples child rays inlined here the kernel needs 231 VGPRs)
+                if constexpr (GI) A.f->s_hits_all[r] = make_float4(W.best, __uint_as_float(W.btri), __uint_as_float(W.bmesh), __uint_as_float(W.have ? 1u : 0u));
+                else shade_and_emit<false, false, LQ>(A, gen, r, node_base, child_base, R, W.have, W.best, W.btri, W.bmesh, nullptr, lane);
                 state = BVH_FETCH;
             }
             // one fetch per free lane and round (a lane whose ray needs no walk here -- an uncovered pixel -- asks again next round): no
@@ -428,12 +431,13 @@ __device__ __forceinline__ void bvh_shade_level(const KernelArgs &A, const uint3
                 else {
                     bool walk = true;
                     if (gen == 0) {
-                        const Level0Ray P = level0_decode<false>(A, r);
+                        const Level0Ray P = level0_decode<GI>(A, r);
                         if (!P.covered) {
                             reinterpret_cast<uint32_t *>(A.f->s_nodes + 2 * (size_t)r)[3] = TN_SKIP;
                             level0_release_shadow_slots(A, r);
+                            if constexpr (GI) A.f->s_hits_all[r] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(3u));   // (not a ray: stream_shade_all skips it)
                             walk = false;
-                        } else level0_ray<false>(A, P, R);
+                        } else level0_ray<GI>(A, P, R);
                     } else {
                         const float4 q0 = in_q[2 * (size_t)r], q1 = in_q[2 * (size_t)r + 1];
                         R.ox = q0.x; R.oy = q0.y; R.oz = q0.z;
@@ -467,6 +471,12 @@ __device__ __forceinline__ void bvh_shade_level(const KernelArgs &A, const uint3
 __global__ __launch_bounds__(BLOCK) void bvh_trace_shade(const KernelArgs A, const uint32_t gen) {
     __shared__ uint32_t stack_lds[BVH_LDS_STACK * BLOCK];
     bvh_shade_level<BVH_PLAIN>(A, gen, stack_lds);
+}
+// the GI / multi-sample mode's levels (jittered samples of a pixel at level 0, gi_samples child rays per diffuse hit: kernel_stream.h,
+// shade_and_emit<., true>) through the same filter: only the rays' origin and the shading differ, and the shadow rays skip no mesh
+__global__ __launch_bounds__(BLOCK) void bvh_trace_shade_gi(const KernelArgs A, const uint32_t gen) {
+    __shared__ uint32_t stack_lds[BVH_LDS_STACK * BLOCK];
+    bvh_shade_level<BVH_PLAIN, false, true>(A, gen, stack_lds);
 }
 __global__ __launch_bounds__(BLOCK) void bvh_trace_shade_tally(const KernelArgs A, const uint32_t gen) {
     __shared__ uint32_t stack_lds[BVH_LDS_STACK * BLOCK];

@@ -208,15 +208,19 @@ def test_gi_frame_equals_the_oracles(pkg, scenes, oracle, case, tmp_path):
 
 
 GI_PATHS = [dict(mode=1),                                                  # render_lanes: the whole recursion per lane
-            dict(step_budget=0),                                           # faithful ray-stream kernels
-            dict(step_budget=8, shadow_budget=8, level0_budget=8),         # nearly every walk through the wave-per-ray kernels
-            dict(heavy_level=0), dict(heavy_level=1000000),                # the levels per lane first / by the wave-per-ray kernel whole
-            dict(step_budget=100000, shadow_budget=100000, heavy_level=0), # nothing evicted
-            dict(side_blocks=0)]
+            dict(bvh=0, step_budget=0),                                    # faithful ray-stream kernels
+            dict(bvh=0, step_budget=8, shadow_budget=8, level0_budget=8),  # nearly every walk through the wave-per-ray kernels
+            dict(bvh=0, heavy_level=0), dict(bvh=0, heavy_level=1000000),  # the levels per lane first / by the wave-per-ray kernel whole
+            dict(bvh=0, step_budget=100000, shadow_budget=100000, heavy_level=0), # nothing evicted
+            dict(bvh=0, side_blocks=0),
+            dict(bvh=0),                                                   # the reference-order kernels' defaults
+            dict(),                                                        # the defaults: the candidate-filter kernels, level by level
+            dict(bvh=1, side_blocks=0),                                    # ... without a side stream
+            dict(bvh=1, fetch_chunk=0x400040, side_blocks=4)]              # ... cursor claims of 64, the bulk shadow pass on four workgroups per CU
 
 
 # every path on the room; the knot scene and the wide plan on the paths that differ there
-GI_PATH_CASES = [("hw11", 0, t) for t in GI_PATHS] + [("hw14", 0, GI_PATHS[k]) for k in (2, 3, 5)] + [("hw11", 100, GI_PATHS[k]) for k in (1, 2, 5)]
+GI_PATH_CASES = [("hw11", 0, t) for t in GI_PATHS] + [("hw14", 0, GI_PATHS[k]) for k in (2, 3, 5, 8, 9)] + [("hw11", 100, GI_PATHS[k]) for k in (1, 2, 5, 8)]
 
 
 @pytest.mark.gpu
