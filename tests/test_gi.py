@@ -291,3 +291,26 @@ def test_gi_mean_image_matches_the_references(pkg, scenes):
     noisy = (ref_var > 1e-10) | (var > 1e-10)
     z = (mean - ref_mean)[noisy] / np.sqrt(ref_var[noisy] / ref_frames + var[noisy] / frames)
     assert abs(z.mean()) < 0.12 and 0.85 < z.std() < 1.15, (z.mean(), z.std())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,depth", [("hw14", 3), ("hw11", 4), ("hw12", 2)])
+def test_gi_filter_kernels_equal_the_reference_order_kernels_at_full_detail(pkg, scenes, name, depth, tmp_path):
+    """The GI mode through the candidate filter (kernel_bvh.h: bvh_trace_shade_gi) against the reference-order GI kernels (crt_tuning::bvh = 0,
+    which the other tests pin to the oracle) on the FULL-detail benchmark scenes (207,954 / 60,156 triangles) at 480x270: the same floats,
+    two seeds, with and without the side stream (tools/gi_big.py is the same comparison as a tool)."""
+    scene = scenes.make(name, width=480, height=270)
+    folder = ""
+    if scene.get("textures"):
+        folder = str(tmp_path) + "/"
+        scenes.write_bitmaps(scene, folder)
+    hs = pkg.Scene(json_text=scenes.to_json(scene), folder=folder)
+    frames = {}
+    for tag, tuning in (("reference-order", dict(bvh=0)), ("filter", dict()), ("filter, no side stream", dict(side_blocks=0))):
+        tracer = pkg.Tracer(hs, tuning=pkg.make_tuning(**tuning))
+        for seed in (5, 6):
+            frames[(tag, seed)] = tracer.render(options=pkg.make_options(depth, use_gi=True, gi_sample_size=2, rays_per_pixel=2, gi_seed=seed)).copy()
+        assert tracer.stats().fallback_frames == 0
+    for seed in (5, 6):
+        for tag in ("filter", "filter, no side stream"):
+            assert_same_floats(frames[(tag, seed)], frames[("reference-order", seed)], "GI %s seed %d: %s vs reference-order kernels" % (name, seed, tag))
