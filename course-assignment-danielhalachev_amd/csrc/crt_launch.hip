@@ -334,6 +334,12 @@ static int launch_stream_levels(crt_ctx *ctx, const crt_options *o, FramePlan &P
                 CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_reset[P.slot], stream));
                 CRT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->early, ctx->ev_reset[P.slot], 0));
                 launch_queue(ctx->early);
+                if (ctx->tuning.level_queue & 4096u) {
+                    // (tests: level 0 held back until that launch has ENDED -- what a profiler that serialises launches, or two streams on one
+                    //  hardware queue, do to it: the launch must sit out its patience and leave, and the one behind level 0 must walk everything)
+                    CRT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_queue[P.slot], ctx->early));
+                    CRT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_queue[P.slot], 0));
+                }
             }
             if (P.exec_count) launch(bvh_trace_level0<BVH_TALLY>, P.lane_blocks, stream, A);
             else if (ctx->tuning.bvh == 2) launch(bvh_trace_level0<BVH_CHECKED>, P.lane_blocks, stream, A);

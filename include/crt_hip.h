@@ -197,7 +197,8 @@ typedef struct crt_tuning {
     uint32_t level_queue;     /* 1: with the filter kernels, every recursion level below level 0 in ONE launch that feeds itself through a queue
                                * (csrc/kernel_bvh.h: bvh_trace_queue), on this many workgroups per CU -- for frames whose levels held at most
                                * 250 k rays each a frame ago (wider levels are throughput: one launch per level is as fast or faster);
-                               * 0: always one launch per level */
+                               * 0: always one launch per level.  Development bits: 8 no child ray continues in its parent's lane; 9 the launch behind
+                               * level 0 instead of beside it; 12 (tests) level 0 held back until the launch beside it has given up */
     uint32_t fetch_chunk;     /* 256 | 64 << 16: work indices a wave claims from a launch's cursor with ONE atomic -- bits 0-15 the bulk shadow
                                * pass's slots, bits 16-31 level 0's primary rays (both >= 64, multiples of 64); a cursor word serves ~100
                                * atomics per microsecond however many waves ask, which bounded the pass until it claimed in chunks */

@@ -64,6 +64,7 @@ KERNEL_PATHS = [
     dict(bvh=1, fetch_chunk=0x1000800, side_blocks=2),           # ... of 2048 slots and 256 primary rays
     dict(bvh=2),                                                 # ... their bounds-checked build
     dict(bvh=1, level_queue=0),                                  # ... one launch per level
+    dict(bvh=1, level_queue=4097),                               # ... level 0 held back until the queue's first launch has given up (a serialising profiler does that)
     dict(bvh=1, level_queue=513),                                # ... the queue's launch behind level 0 instead of beside it
     dict(bvh=1, level_queue=258),                                # ... every child ray through the queue (none continues in its parent's lane)
     dict(bvh=2, level_queue=0, side_blocks=0),
