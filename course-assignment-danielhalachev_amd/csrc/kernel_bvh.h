@@ -57,7 +57,8 @@ constexpr float BVH_WIDEN = 0x1p-20f;
 // any more): every such round costs the lanes that still walk a shading's worth of time, so the rounds must be few.
 constexpr uint32_t BVH_BATCH = 24;
 // (level 0 and the bulk shadow pass claim their work indices in chunks: KernelArgs::chunk, crt_tuning::fetch_chunk)
-constexpr int BVH_STEPS = 4;         // walk steps between two looks at the lanes' states
+constexpr int BVH_STEPS = 16;        // walk steps between two looks at the lanes' states (measured 4 / 8 / 16 / 32: HW14 2.64 / 2.57 / 2.49 / 2.50 ms, HW12 9.16 / 8.93 / 8.78 / 8.84)
+constexpr int BVH_STEPS_QUEUE = 8;   // ... in the level queue's launch, where a finished lane waits for the turn's end with its children (HW11 3.27 / 3.11 / 3.15 / 3.26)
 
 // Builds of the kernels: plain; tallying the tests they execute (crt_options::collect_counters == 2); bounds-checked (crt_tuning::bvh
 // == 2: every index is compared with its array's size first; a violation is recorded in the frame's counter block -- word
@@ -653,7 +654,7 @@ __device__ __forceinline__ void bvh_queue_levels(const KernelArgs &A, uint32_t *
         {
             const bool sh_lane = state == BVH_SHADOWS;
             bool stepping = state == BVH_WALK || (sh_lane && sh_walking);
-            for (int it = 0; it < BVH_STEPS; ++it)
+            for (int it = 0; it < BVH_STEPS_QUEUE; ++it)
                 if (stepping && !bvh_step<2, MODE>(A, R, false, light_dist, false, W, stack, nbox, ntri, sh_lane)) {
                     stepping = false;
                     if (sh_lane) {
@@ -666,7 +667,7 @@ __device__ __forceinline__ void bvh_queue_levels(const KernelArgs &A, uint32_t *
                 }
         }
         if (state == BVH_MISS_CHECK) {
-            for (int it = 0; it < BVH_STEPS; ++it)
+            for (int it = 0; it < BVH_STEPS_QUEUE; ++it)
                 if (state == BVH_MISS_CHECK && !bvh_miss_step<MODE>(A, R, false, W, stack, nbox, ntri)) state = BVH_FINISHED;
         }
     }
